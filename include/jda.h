@@ -1,0 +1,219 @@
+/*
+ * jda.h -- C ABI of the MI355X-native JDA sliding-window detector (libjda.so).
+ *
+ * Section 1 is the drop-in boundary: the six entry points of the reference
+ * header (reference c/jda.h:31-68) with identical names, argument order,
+ * argument meaning and ownership rules, so a program written against the
+ * reference C library links against this one unchanged.
+ *
+ * Section 2 is additive: batch / device-resident entry points, a second
+ * numeric dialect (the fp64 `src/jda` path), per-window trace output used by
+ * the parity tests, and an error channel.  Nothing in section 2 changes the
+ * behaviour of section 1.
+ *
+ * Plain C types only: pointers, ints, floats.  No C++/HIP/torch types cross
+ * this boundary (a HIP stream is passed as an opaque void*).
+ */
+#ifndef JDA_AMD_JDA_H_
+#define JDA_AMD_JDA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(_MSC_VER)
+#  if defined(JDA_EXPORTS)
+#    define JDA_API __declspec(dllexport)
+#  else
+#    define JDA_API __declspec(dllimport)
+#  endif
+#else
+#  define JDA_API __attribute__((visibility("default")))
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* 1. Reference-compatible surface                                          */
+/* ------------------------------------------------------------------------ */
+
+/* Detection list, returned BY VALUE (reference c/jda.h:18-24).
+ * bboxes is n triples (x, y, size); shapes is n rows of 2*landmark_n floats
+ * in absolute pixel coordinates (x1, y1, x2, y2, ...); scores is n floats.
+ * The three arrays are malloc()ed by the library and owned by the caller
+ * until jdaResultRelease(). */
+typedef struct {
+  int n;
+  int landmark_n;
+  int *bboxes;
+  float *shapes;
+  float *scores;
+} jdaResult;
+
+/* replaces reference c/jda.c:486-561 (c/jda.h:31).  Loads a model whose real
+ * fields are 8-byte doubles (the trainer's format, src/jda/cascador.cpp:79).
+ * Returns NULL if the file cannot be opened.  Unlike the reference, the
+ * cascade dimensions are taken from the file header at run time, and a file
+ * whose size does not match its header is refused (NULL). */
+JDA_API void *jdaCascadorCreateDouble(const char *model);
+
+/* replaces reference c/jda.c:563-638 (c/jda.h:32).  Same for the 4-byte float
+ * layout that jdaCascadorSerializeTo() writes. */
+JDA_API void *jdaCascadorCreateFloat(const char *model);
+
+/* replaces reference c/jda.c:644-716 (c/jda.h:41).  Writes the float layout,
+ * including the reference's header convention (stage index T+1, cart -1).
+ * Silently returns if the file cannot be created, like the reference. */
+JDA_API void jdaCascadorSerializeTo(void *cascador, const char *model);
+
+/* replaces reference c/jda.c:718-720 (c/jda.h:47). NULL is accepted. */
+JDA_API void jdaCascadorRelease(void *cascador);
+
+/* replaces reference c/jda.c:443-480 (c/jda.h:62-63).
+ *   data      borrowed, width*height contiguous 8-bit gray, row stride = width
+ *   scale     growth factor of the window size between pyramid levels
+ *   step      accepted and ignored, exactly like the reference, which
+ *             overrides it with 10 % of the window size (c/jda.c:333)
+ *   min_size  raised to 24 if smaller (c/jda.c:459)
+ *   max_size  <= 0 means min(width, height) (c/jda.c:460)
+ *   th        final score cut (c/jda.c:414)
+ * Output order: scan order (level, y, x) of the windows that survive NMS.
+ * Runs the cascade on the GPU (HIP device selected with jdaSetDevice, default
+ * the current device).  There is no CPU fallback: if no HIP device is usable
+ * the call returns an empty result, sets jdaGetLastError() and prints the
+ * reason on stderr. */
+JDA_API jdaResult jdaDetect(void *cascador, unsigned char *data, int width, int height,
+                            float scale, float step, int min_size, int max_size, float th);
+
+/* replaces reference c/jda.c:722-727 (c/jda.h:68). */
+JDA_API void jdaResultRelease(jdaResult result);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Additive extensions                                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Numeric dialects of the same cascade.
+ * JDA_DIALECT_C   : fp32, truncating coordinates, growing window with 10 %
+ *                   step -- reference c/jda.c (what jdaDetect runs).
+ * JDA_DIALECT_CPP : fp64, round() coordinates, fixed pixel step, no final
+ *                   threshold, score-ordered NMS -- reference
+ *                   src/jda/cascador.cpp:166-211,310-477 (method 1). */
+enum { JDA_DIALECT_C = 0, JDA_DIALECT_CPP = 1 };
+
+/* Thread-local message of the last failed call on this thread ("" if none). */
+JDA_API const char *jdaGetLastError(void);
+
+/* Opens a model of either layout; the layout is inferred from the file size
+ * implied by the header (the file has no discriminator). */
+JDA_API void *jdaCascadorCreate(const char *model);
+
+typedef struct {
+  int T;            /* stages                                   */
+  int K;            /* carts per stage                          */
+  int landmark_n;   /* landmarks L; a shape has 2L coordinates  */
+  int tree_depth;   /* D; a cart has 2^(D-1)-1 split nodes      */
+  int multi_scale;  /* 1 if any split node reads the half/quarter image */
+  int source_real_bytes; /* 8 or 4: layout of the file it came from */
+} jdaModelInfo;
+
+JDA_API int jdaCascadorInfo(void *cascador, jdaModelInfo *info);
+
+/* Pin a cascador to a HIP device ordinal (default: device current at first
+ * use).  Must be called before the first detect on this cascador. */
+JDA_API int jdaSetDevice(void *cascador, int device);
+
+/* Window enumeration of reference c/jda.c:320-339 without running anything:
+ * number of candidate windows and pyramid levels for one frame. */
+JDA_API int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
+                            long long *n_windows, int *n_levels);
+
+/* Work counters of one detect call: the DetectionStatisic of reference
+ * include/jda/cascador.hpp:14-25, plus what the roofline accounting needs. */
+typedef struct {
+  long long patch_n;          /* candidate windows scanned                    */
+  long long face_patch_n;     /* windows that passed every cart (+ final th)  */
+  long long nonface_patch_n;  /* patch_n - face_patch_n                       */
+  long long cart_gothrough_n; /* carts evaluated, counted as the reference    */
+                              /* counts `n` in Validate (cascador.cpp:187)    */
+  long long stage_done_n[16]; /* windows that completed stage t (shape update) */
+  double average_cart_n;      /* cart_gothrough_n / nonface_patch_n           */
+  double gpu_ms;              /* device time of the call (HIP events)         */
+  double scan_ms;             /* device time of the stage-0 scan kernel alone */
+  double host_ms;             /* host post-processing (sort, NMS, relocation) */
+} jdaStats;
+
+typedef struct {
+  int dialect;          /* JDA_DIALECT_*                                      */
+  int nms;              /* 1: apply NMS (default), 0: return every survivor   */
+  float nms_overlap;    /* IoU threshold, 0.3 in reference c/jda.c:238        */
+  int cpp_step;         /* dialect CPP: pixel step (config fddb.step)         */
+  void *hip_stream;     /* hipStream_t to enqueue on, NULL = library's own    */
+  jdaStats *stats;      /* optional out                                       */
+} jdaDetectOptions;
+
+JDA_API void jdaDetectOptionsInit(jdaDetectOptions *opt);
+
+/* Batch of n equally sized frames in HOST memory (frames[i] is width*height
+ * bytes).  out must point at n jdaResult slots; each is released separately
+ * with jdaResultRelease.  Per frame the result is identical to n separate
+ * jdaDetect calls.  Returns 0 on success. */
+JDA_API int jdaDetectBatch(void *cascador, const unsigned char *const *frames, int n,
+                           int width, int height, float scale, float step,
+                           int min_size, int max_size, float th,
+                           const jdaDetectOptions *opt, jdaResult *out);
+
+/* Same, frames already resident in device memory: frame i starts at
+ * d_frames + i*frame_stride (frame_stride >= width*height).  This is the
+ * entry the throughput benchmark times. */
+JDA_API int jdaDetectBatchDevice(void *cascador, const unsigned char *d_frames,
+                                 size_t frame_stride, int n, int width, int height,
+                                 float scale, float step, int min_size, int max_size,
+                                 float th, const jdaDetectOptions *opt, jdaResult *out);
+
+/* Per-window trace of the cascade (parity instrumentation; HOST output
+ * arrays of n*windows_per_frame entries in scan order, any may be NULL):
+ *   carts_n    number of carts evaluated, counted like `n` in the reference's
+ *              Validate (index of the rejecting cart + 1, or T*K)
+ *   score      score when the walk stopped (before the final threshold)
+ *   path_hash  FNV-1a over the leaf index of every evaluated cart
+ *   shapes     2L floats, window-normalised shape after the last completed
+ *              stage (mean shape if none completed)
+ * Frames are host memory. Dialect C only. */
+JDA_API int jdaTraceBatch(void *cascador, const unsigned char *const *frames, int n,
+                          int width, int height, float scale, int min_size, int max_size,
+                          int *carts_n, float *score, unsigned int *path_hash, float *shapes);
+
+/* The image pair of reference c/jda.c:450-457 (half = 1/sqrt(2), quarter =
+ * 1/2) built by the device resize kernel; exposed for the parity tests.
+ * half/quarter are HOST buffers of hw*hh and qw*qh bytes. */
+JDA_API int jdaBuildPyramid(void *cascador, const unsigned char *data, int width, int height,
+                            unsigned char *half, int *hw, int *hh,
+                            unsigned char *quarter, int *qw, int *qh);
+
+/* Dialect CPP results carry doubles (reference Detect fills
+ * vector<Rect>, vector<double>, vector<Mat_<double>>). */
+typedef struct {
+  int n;
+  int landmark_n;
+  int *rects;      /* n * (x, y, w, h)            */
+  double *shapes;  /* n * 2L absolute coordinates */
+  double *scores;  /* n                           */
+} jdaResultD;
+
+JDA_API void jdaResultDRelease(jdaResultD result);
+
+/* Dialect CPP batch detect on host frames: reference JoinCascador::Detect with
+ * fddb.method = 1 (src/jda/cascador.cpp:431-477): minimum_size, pixel step,
+ * scale factor, NMS overlap, nms on/off come from the arguments instead of
+ * the Config singleton. */
+JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames, int n,
+                              int width, int height, int minimum_size, int step,
+                              double factor, double overlap, int nms,
+                              jdaStats *stats, jdaResultD *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* JDA_AMD_JDA_H_ */

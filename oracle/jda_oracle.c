@@ -1,0 +1,645 @@
+/*
+ * jda_oracle.c -- CPU restatement of the JDA sliding-window detect path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this.  The shipped library (libjda.so)
+ * never links, loads or calls anything in oracle/.
+ *
+ * What it restates (each function cites the reference lines it follows):
+ *   dialect C   -- reference c/jda.c (fp32, truncating coordinates)
+ *   dialect CPP -- reference src/jda/{cascador,cart,data,btcart}.cpp (fp64,
+ *                  round() coordinates), restricted to scale==0 split nodes
+ *                  and similarity transform off (the shipped configuration;
+ *                  see SURVEY.md 8c for why the rest is unpinned)
+ *
+ * Pinning: dialect C is checked bit-for-bit against the reference's own
+ * c/jda.c compiled from /root/reference (oracle/_ref, see oracle/Makefile)
+ * by tests/test_oracle_vs_reference.py, and against the golden vectors under
+ * tests/golden/ that were produced by that build.  Dialect CPP cannot be
+ * compiled here (needs OpenCV/jsmnpp/liblinear): PARITY UNPINNED for it; it
+ * is cross-checked only against dialect C where the two must agree.
+ *
+ * Unlike the reference, cascade dimensions are run-time values, and every
+ * window reports where and why the walk stopped (carts evaluated, score,
+ * leaf-path hash, shape) so reject decisions and tree paths can be compared
+ * window by window.
+ *
+ * Build: gcc -std=c99 -O2 -ffp-contract=off (no -march=native, no
+ * -ffast-math): an FMA contraction changes results.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  int scale, lm1, lm2, th;
+  double off[4]; /* o1x o1y o2x o2y, as stored (f32 files widen exactly) */
+} orc_node;
+
+typedef struct {
+  int T, K, L, D, node_n, leaf_n, dim;
+  int real_bytes;
+  double *mean_shape;             /* [dim]                 */
+  orc_node *nodes;                /* [T*K*node_n]          */
+  double *leaf, *cth, *cmean, *cstd;
+  double *w;                      /* [T][K*leaf_n][dim]    */
+  /* fp32 views for dialect C: plain narrowing casts, c/jda.c:509-552 */
+  float *mean_shape_f, *off_f, *leaf_f, *cth_f, *cmean_f, *cstd_f, *w_f;
+} orc_model;
+
+/* ------------------------------------------------------------------ model */
+
+static long long orc_stream_bytes(int T, int K, int L, int D, int rb) {
+  long long node_n = (1LL << (D - 1)) - 1, leaf_n = 1LL << (D - 1);
+  long long cart = node_n * (16 + 4 * rb) + leaf_n * rb + 3 * rb;
+  return 28 + 2LL * L * rb + (long long)T * (K * cart + (long long)K * leaf_n * 2 * L * rb) + 4;
+}
+
+static double rd_real(const unsigned char **p, int rb) {
+  double v;
+  if (rb == 8) { memcpy(&v, *p, 8); }
+  else { float f; memcpy(&f, *p, 4); v = f; }
+  *p += rb;
+  return v;
+}
+static int rd_i32(const unsigned char **p) { int v; memcpy(&v, *p, 4); *p += 4; return v; }
+
+void orc_free(orc_model *m) {
+  if (!m) return;
+  free(m->mean_shape); free(m->nodes); free(m->leaf); free(m->cth); free(m->cmean); free(m->cstd);
+  free(m->w); free(m->mean_shape_f); free(m->off_f); free(m->leaf_f); free(m->cth_f);
+  free(m->cmean_f); free(m->cstd_f); free(m->w_f); free(m);
+}
+
+/* Stream layout: reference README.md:84-111, cascador.cpp:79-164, cart.cpp:406-450. */
+orc_model *orc_load(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return NULL;
+  fseek(f, 0, SEEK_END);
+  long long size = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  unsigned char *buf = (unsigned char *)malloc(size > 0 ? size : 1);
+  if (size < 32 || fread(buf, 1, size, f) != (size_t)size) { fclose(f); free(buf); return NULL; }
+  fclose(f);
+  const unsigned char *p = buf;
+  orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
+  (void)rd_i32(&p);
+  m->T = rd_i32(&p); m->K = rd_i32(&p); m->L = rd_i32(&p); m->D = rd_i32(&p);
+  (void)rd_i32(&p); (void)rd_i32(&p);
+  if (m->T < 1 || m->T > 16 || m->K < 1 || m->L < 1 || m->D < 2 || m->D > 12) { free(buf); free(m); return NULL; }
+  int rb = 0;
+  if (size == orc_stream_bytes(m->T, m->K, m->L, m->D, 8)) rb = 8;
+  else if (size == orc_stream_bytes(m->T, m->K, m->L, m->D, 4)) rb = 4;
+  if (!rb) { free(buf); free(m); return NULL; }
+  m->real_bytes = rb;
+  m->node_n = (1 << (m->D - 1)) - 1; m->leaf_n = 1 << (m->D - 1); m->dim = 2 * m->L;
+  long long carts = (long long)m->T * m->K;
+  size_t wn = (size_t)carts * m->leaf_n * m->dim;
+  m->mean_shape = (double *)malloc(sizeof(double) * m->dim);
+  m->nodes = (orc_node *)malloc(sizeof(orc_node) * carts * m->node_n);
+  m->leaf = (double *)malloc(sizeof(double) * carts * m->leaf_n);
+  m->cth = (double *)malloc(sizeof(double) * carts);
+  m->cmean = (double *)malloc(sizeof(double) * carts);
+  m->cstd = (double *)malloc(sizeof(double) * carts);
+  m->w = (double *)malloc(sizeof(double) * wn);
+  for (int i = 0; i < m->dim; i++) m->mean_shape[i] = rd_real(&p, rb);
+  for (int t = 0; t < m->T; t++) {
+    for (int k = 0; k < m->K; k++) {
+      long long c = (long long)t * m->K + k;
+      for (int i = 0; i < m->node_n; i++) {
+        orc_node *n = &m->nodes[c * m->node_n + i];
+        n->scale = rd_i32(&p); n->lm1 = rd_i32(&p); n->lm2 = rd_i32(&p);
+        for (int j = 0; j < 4; j++) n->off[j] = rd_real(&p, rb);
+        n->th = rd_i32(&p);
+      }
+      for (int i = 0; i < m->leaf_n; i++) m->leaf[c * m->leaf_n + i] = rd_real(&p, rb);
+      m->cth[c] = rd_real(&p, rb); m->cmean[c] = rd_real(&p, rb); m->cstd[c] = rd_real(&p, rb);
+    }
+    size_t per = (size_t)m->K * m->leaf_n * m->dim;
+    for (size_t i = 0; i < per; i++) m->w[(size_t)t * per + i] = rd_real(&p, rb);
+  }
+  free(buf);
+  /* fp32 views */
+  m->mean_shape_f = (float *)malloc(sizeof(float) * m->dim);
+  m->off_f = (float *)malloc(sizeof(float) * 4 * carts * m->node_n);
+  m->leaf_f = (float *)malloc(sizeof(float) * carts * m->leaf_n);
+  m->cth_f = (float *)malloc(sizeof(float) * carts);
+  m->cmean_f = (float *)malloc(sizeof(float) * carts);
+  m->cstd_f = (float *)malloc(sizeof(float) * carts);
+  m->w_f = (float *)malloc(sizeof(float) * wn);
+  for (int i = 0; i < m->dim; i++) m->mean_shape_f[i] = (float)m->mean_shape[i];
+  for (long long i = 0; i < carts * m->node_n; i++)
+    for (int j = 0; j < 4; j++) m->off_f[4 * i + j] = (float)m->nodes[i].off[j];
+  for (long long i = 0; i < carts * m->leaf_n; i++) m->leaf_f[i] = (float)m->leaf[i];
+  for (long long i = 0; i < carts; i++) {
+    m->cth_f[i] = (float)m->cth[i]; m->cmean_f[i] = (float)m->cmean[i]; m->cstd_f[i] = (float)m->cstd[i];
+  }
+  for (size_t i = 0; i < wn; i++) m->w_f[i] = (float)m->w[i];
+  return m;
+}
+
+void orc_dims(const orc_model *m, int *out6) {
+  out6[0] = m->T; out6[1] = m->K; out6[2] = m->L; out6[3] = m->D; out6[4] = m->real_bytes; out6[5] = m->dim;
+}
+
+/* ---------------------------------------------------------------- resize */
+
+/* Bilinear down-scale, reference c/jda.c:203-230: ratio=(src-1)/dst in float,
+ * source index by truncation, four taps summed left to right, truncated to u8. */
+void orc_resize(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh) {
+  const float rx = (float)(sw - 1) / dw;
+  const float ry = (float)(sh - 1) / dh;
+  for (int i = 0; i < dh; i++) {
+    const float fy = ry * i;
+    const int y0 = (int)fy;
+    const float wy = fy - y0;
+    for (int j = 0; j < dw; j++) {
+      const float fx = rx * j;
+      const int x0 = (int)fx;
+      const float wx = fx - x0;
+      const unsigned char *q = src + (size_t)y0 * sw + x0;
+      const int p00 = q[0], p01 = q[1], p10 = q[sw], p11 = q[sw + 1];
+      const float v = p00 * (1.f - wx) * (1.f - wy) + p01 * (wx) * (1.f - wy) +
+                      p10 * (1.f - wx) * (wy) + p11 * (wx) * (wy);
+      dst[(size_t)i * dw + j] = (unsigned char)v;
+    }
+  }
+}
+
+void orc_pyramid_dims(int w, int h, int *hw, int *hh, int *qw, int *qh) {
+  const float r = 1.f / sqrtf(2.f); /* c/jda.c:450-456 */
+  *hw = (int)(w * r); *hh = (int)(h * r);
+  *qw = w / 2; *qh = h / 2;
+}
+
+/* ------------------------------------------------------------ enumeration */
+
+typedef struct { int win, step, nx, ny; long long base; } orc_level;
+
+/* Window sizes and steps of reference c/jda.c:320-339 (+459-460).
+ * Returns the level count (<=0: the reference loop would not terminate). */
+static int orc_levels_c(int w, int h, float scale, int min_size, int max_size,
+                        orc_level *lv, int cap, long long *total) {
+  if (min_size < 24) min_size = 24;
+  if (max_size <= 0) max_size = w < h ? w : h;
+  if (max_size > w) max_size = w;
+  if (max_size > h) max_size = h;
+  int win = 24, n = 0;
+  long long tot = 0;
+  if ((int)(24 * scale) <= 24) return -1;
+  while (win < min_size) win = (int)(win * scale);
+  for (; win <= max_size; win = (int)(win * scale)) {
+    if (n >= cap) return -2;
+    lv[n].win = win;
+    lv[n].step = (int)(win * 0.1f);
+    lv[n].nx = (w - win) / lv[n].step + 1;
+    lv[n].ny = (h - win) / lv[n].step + 1;
+    lv[n].base = tot;
+    tot += (long long)lv[n].nx * lv[n].ny;
+    n++;
+  }
+  *total = tot;
+  return n;
+}
+
+long long orc_count_windows_c(int w, int h, float scale, int min_size, int max_size, int *n_levels) {
+  orc_level lv[256];
+  long long tot = 0;
+  int n = orc_levels_c(w, h, scale, min_size, max_size, lv, 256, &tot);
+  if (n_levels) *n_levels = n;
+  return n < 0 ? -1 : tot;
+}
+
+/* ------------------------------------------------------- dialect C window */
+
+#define FNV_SEED 2166136261u
+#define FNV_STEP(h, v) (((h) ^ (unsigned)(v)) * 16777619u)
+
+typedef struct {
+  const unsigned char *data; /* top-left of the image this scale reads */
+  int w, h;                  /* image bounds (for the guarded read)    */
+  int ox, oy;                /* window origin inside that image        */
+} orc_view;
+
+/* One window through the cascade, reference c/jda.c:357-414.
+ * shape: in = unused, out = shape after the last completed stage.
+ * Returns carts evaluated (rejecting cart included); *alive tells whether
+ * every cart was passed.  The final threshold is NOT applied here. */
+static int orc_walk_c(const orc_model *m, const orc_view *views, int win,
+                      float *shape, int *lbf, float *score_out, unsigned *hash_out, int *alive) {
+  const int dim = m->dim, node_n = m->node_n, leaf_n = m->leaf_n;
+  float score = 0.f;
+  unsigned hash = FNV_SEED;
+  int evaluated = 0;
+  *alive = 1;
+  memcpy(shape, m->mean_shape_f, sizeof(float) * dim);
+  for (int t = 0; t < m->T && *alive; t++) {
+    for (int k = 0; k < m->K; k++) {
+      const long long c = (long long)t * m->K + k;
+      int at = 0;
+      for (int d = 0; d < m->D - 1; d++) {
+        const orc_node *nd = &m->nodes[c * node_n + at];
+        const float *of = &m->off_f[4 * (c * node_n + at)];
+        const orc_view *v = &views[nd->scale];
+        /* landmark + offset, scaled by the window side, truncated toward 0,
+         * clamped into the window (c/jda.c:373-389; note every scale uses
+         * the full window side, c/jda.c:347-354) */
+        const float ax = shape[2 * nd->lm1] + of[0];
+        const float ay = shape[2 * nd->lm1 + 1] + of[1];
+        const float bx = shape[2 * nd->lm2] + of[2];
+        const float by = shape[2 * nd->lm2 + 1] + of[3];
+        int ix1 = (int)(ax * win), iy1 = (int)(ay * win);
+        int ix2 = (int)(bx * win), iy2 = (int)(by * win);
+        if (ix1 < 0) ix1 = 0; else if (ix1 >= win) ix1 = win - 1;
+        if (ix2 < 0) ix2 = 0; else if (ix2 >= win) ix2 = win - 1;
+        if (iy1 < 0) iy1 = 0; else if (iy1 >= win) iy1 = win - 1;
+        if (iy2 < 0) iy2 = 0; else if (iy2 >= win) iy2 = win - 1;
+        /* Guarded read: for scale!=0 the reference indexes the half/quarter
+         * image with full-window coordinates and can leave it (undefined
+         * behaviour, SURVEY.md header item 6).  Rows/columns are clamped to
+         * the image here; identical to the reference whenever it is in bounds. */
+        int gx1 = v->ox + ix1, gy1 = v->oy + iy1, gx2 = v->ox + ix2, gy2 = v->oy + iy2;
+        if (gx1 >= v->w) gx1 = v->w - 1;
+        if (gy1 >= v->h) gy1 = v->h - 1;
+        if (gx2 >= v->w) gx2 = v->w - 1;
+        if (gy2 >= v->h) gy2 = v->h - 1;
+        const int feat = (int)v->data[(size_t)gy1 * v->w + gx1] - (int)v->data[(size_t)gy2 * v->w + gx2];
+        at = 2 * at + (feat <= nd->th ? 1 : 2);             /* c/jda.c:392-393 */
+      }
+      const int leaf = at - node_n;
+      evaluated++;
+      hash = FNV_STEP(hash, leaf);
+      score += m->leaf_f[c * leaf_n + leaf];                 /* c/jda.c:396 */
+      score = (score - m->cmean_f[c]) / m->cstd_f[c];         /* c/jda.c:397 */
+      if (score < m->cth_f[c]) { *alive = 0; break; }         /* c/jda.c:399 */
+      lbf[k] = k * leaf_n + leaf;
+    }
+    if (!*alive) break;
+    /* stage regression: rows added in cart order, c/jda.c:404-411 */
+    const float *ws = &m->w_f[(size_t)t * m->K * leaf_n * dim];
+    for (int k = 0; k < m->K; k++) {
+      const float *row = ws + (size_t)lbf[k] * dim;
+      for (int i = 0; i < dim; i++) shape[i] += row[i];
+    }
+  }
+  *score_out = score;
+  *hash_out = hash;
+  return evaluated;
+}
+
+typedef struct {
+  unsigned char *half, *quarter;
+  int hw, hh, qw, qh;
+} orc_pyr;
+
+static void orc_pyr_build(const unsigned char *img, int w, int h, orc_pyr *p) {
+  orc_pyramid_dims(w, h, &p->hw, &p->hh, &p->qw, &p->qh);
+  p->half = (unsigned char *)malloc((size_t)(p->hw > 0 ? p->hw : 1) * (p->hh > 0 ? p->hh : 1));
+  p->quarter = (unsigned char *)malloc((size_t)(p->qw > 0 ? p->qw : 1) * (p->qh > 0 ? p->qh : 1));
+  if (p->hw > 0 && p->hh > 0) orc_resize(img, w, h, p->half, p->hw, p->hh);
+  if (p->qw > 0 && p->qh > 0) orc_resize(img, w, h, p->quarter, p->qw, p->qh);
+}
+
+static void orc_views(const unsigned char *img, int w, int h, const orc_pyr *p, int x, int y, orc_view *v) {
+  const float r = 1.f / sqrtf(2.f);
+  v[0].data = img; v[0].w = w; v[0].h = h; v[0].ox = x; v[0].oy = y;
+  v[1].data = p->half; v[1].w = p->hw; v[1].h = p->hh; v[1].ox = (int)(x * r); v[1].oy = (int)(y * r);
+  v[2].data = p->quarter; v[2].w = p->qw; v[2].h = p->qh; v[2].ox = x / 2; v[2].oy = y / 2;
+}
+
+/* Per-window trace in scan order. Any output may be NULL. Returns windows. */
+long long orc_trace_c(const orc_model *m, const unsigned char *img, int w, int h,
+                      float scale, int min_size, int max_size,
+                      int *carts_n, float *score, unsigned *path_hash, float *shapes) {
+  orc_level lv[256];
+  long long tot = 0;
+  const int nl = orc_levels_c(w, h, scale, min_size, max_size, lv, 256, &tot);
+  if (nl < 0) return -1;
+  orc_pyr pyr;
+  orc_pyr_build(img, w, h, &pyr);
+  float *shape = (float *)malloc(sizeof(float) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  long long id = 0;
+  for (int l = 0; l < nl; l++) {
+    for (int iy = 0; iy < lv[l].ny; iy++) {
+      for (int ix = 0; ix < lv[l].nx; ix++, id++) {
+        orc_view v[3];
+        orc_views(img, w, h, &pyr, ix * lv[l].step, iy * lv[l].step, v);
+        float s; unsigned hsh; int alive;
+        const int n = orc_walk_c(m, v, lv[l].win, shape, lbf, &s, &hsh, &alive);
+        if (carts_n) carts_n[id] = n;
+        if (score) score[id] = s;
+        if (path_hash) path_hash[id] = hsh;
+        if (shapes) memcpy(shapes + (size_t)id * m->dim, shape, sizeof(float) * m->dim);
+      }
+    }
+  }
+  free(shape); free(lbf); free(pyr.half); free(pyr.quarter);
+  return tot;
+}
+
+/* --------------------------------------------------------- dialect C NMS */
+
+/* Reference c/jda.c:237-316. keep[i] = 1 for survivors (scan order kept). */
+static void orc_nms_c(const int *bb, const float *sc, int n, float overlap, unsigned char *keep) {
+  int *ord = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) { ord[i] = i; keep[i] = 1; }
+  for (int i = 0; i + 1 < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (sc[ord[i]] < sc[ord[j]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  for (int i = 0; i + 1 < n; i++) {
+    const int a = ord[i];
+    if (!keep[a]) continue;
+    for (int j = i + 1; j < n; j++) {
+      const int b = ord[j];
+      if (!keep[b]) continue;
+      const int ax = bb[3 * a], ay = bb[3 * a + 1], as = bb[3 * a + 2];
+      const int bx = bb[3 * b], by = bb[3 * b + 1], bs = bb[3 * b + 2];
+      const int x1 = ax > bx ? ax : bx, y1 = ay > by ? ay : by;
+      const int x2 = (ax + as < bx + bs) ? ax + as : bx + bs;
+      const int y2 = (ay + as < by + bs) ? ay + as : by + bs;
+      const int iw = x2 - x1 > 0 ? x2 - x1 : 0, ih = y2 - y1 > 0 ? y2 - y1 : 0;
+      const float ov = (float)(iw * ih) / (float)(as * as + bs * bs - iw * ih);
+      if (ov > overlap) keep[b] = 0;
+    }
+  }
+  free(ord);
+}
+
+/* Whole dialect-C detect of one frame = reference jdaDetect (c/jda.c:443-480).
+ * Output arrays must hold one entry per window (see orc_count_windows_c).
+ * Returns detections written, or -1. */
+int orc_detect_c(const orc_model *m, const unsigned char *img, int w, int h,
+                 float scale, int min_size, int max_size, float th, int do_nms,
+                 int *bboxes, float *scores, float *shapes) {
+  orc_level lv[256];
+  long long tot = 0;
+  const int nl = orc_levels_c(w, h, scale, min_size, max_size, lv, 256, &tot);
+  if (nl < 0) return -1;
+  orc_pyr pyr;
+  orc_pyr_build(img, w, h, &pyr);
+  float *shape = (float *)malloc(sizeof(float) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  int n = 0;
+  for (int l = 0; l < nl; l++) {
+    for (int iy = 0; iy < lv[l].ny; iy++) {
+      for (int ix = 0; ix < lv[l].nx; ix++) {
+        orc_view v[3];
+        const int x = ix * lv[l].step, y = iy * lv[l].step;
+        orc_views(img, w, h, &pyr, x, y, v);
+        float s; unsigned hsh; int alive;
+        (void)orc_walk_c(m, v, lv[l].win, shape, lbf, &s, &hsh, &alive);
+        if (!alive) continue;
+        if (s < th) continue;                                /* c/jda.c:414 */
+        bboxes[3 * n] = x; bboxes[3 * n + 1] = y; bboxes[3 * n + 2] = lv[l].win;
+        scores[n] = s;
+        memcpy(shapes + (size_t)n * m->dim, shape, sizeof(float) * m->dim);
+        n++;
+      }
+    }
+  }
+  free(shape); free(lbf); free(pyr.half); free(pyr.quarter);
+  if (do_nms) {
+    unsigned char *keep = (unsigned char *)malloc(n > 0 ? n : 1);
+    orc_nms_c(bboxes, scores, n, 0.3f, keep);
+    int o = 0;
+    for (int i = 0; i < n; i++) {
+      if (!keep[i]) continue;
+      if (o != i) {
+        memmove(bboxes + 3 * o, bboxes + 3 * i, sizeof(int) * 3);
+        scores[o] = scores[i];
+        memmove(shapes + (size_t)o * m->dim, shapes + (size_t)i * m->dim, sizeof(float) * m->dim);
+      }
+      o++;
+    }
+    free(keep);
+    n = o;
+    /* relocation, c/jda.c:465-474: multiply, then add */
+    for (int i = 0; i < n; i++) {
+      const int x = bboxes[3 * i], y = bboxes[3 * i + 1], sz = bboxes[3 * i + 2];
+      float *sh = shapes + (size_t)i * m->dim;
+      for (int j = 0; j < m->L; j++) {
+        sh[2 * j] = sh[2 * j] * sz + x;
+        sh[2 * j + 1] = sh[2 * j + 1] * sz + y;
+      }
+    }
+  }
+  return n;
+}
+
+/* ---------------------------------------------------------- dialect CPP */
+
+/* Window sizes of detectMultiScale1, reference cascador.cpp:310-376. */
+static int orc_levels_cpp(int w, int h, int minimum_size, int step, double factor,
+                          orc_level *lv, int cap, long long *total) {
+  if (minimum_size < 1 || step < 1 || (int)(minimum_size * factor) <= minimum_size) return -1;
+  int win = minimum_size, n = 0;
+  long long tot = 0;
+  while (win <= w && win <= h) {
+    if (n >= cap) return -2;
+    lv[n].win = win; lv[n].step = step;
+    lv[n].nx = (w - win) / step + 1; lv[n].ny = (h - win) / step + 1;
+    lv[n].base = tot;
+    tot += (long long)lv[n].nx * lv[n].ny;
+    n++;
+    win = (int)(win * factor);
+  }
+  *total = tot;
+  return n;
+}
+
+long long orc_count_windows_cpp(int w, int h, int minimum_size, int step, double factor, int *n_levels) {
+  orc_level lv[256];
+  long long tot = 0;
+  int n = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
+  if (n_levels) *n_levels = n;
+  return n < 0 ? -1 : tot;
+}
+
+/* Validate (cascador.cpp:166-211) on the origin-scale patch only, with
+ * shift_size = 0 (test.cpp:17,75) and the identity STParameter
+ * (data.cpp:68-70).  Cart::Forward cart.cpp:392-404; feature data.cpp:18-58
+ * (round half away from zero, clamp common.hpp:227-232); delta shape summed
+ * from zero then added, btcart.cpp:407-424.  Apply() with the identity
+ * parameter is written out (1*(1*x+0*y)) because it is not a no-op for -0. */
+static int orc_walk_cpp(const orc_model *m, const unsigned char *img, int iw, int x, int y, int win,
+                        double *shape, double *delta, int *lbf, double *score_out, unsigned *hash_out, int *alive) {
+  const int dim = m->dim, node_n = m->node_n, leaf_n = m->leaf_n;
+  double score = 0.;
+  unsigned hash = FNV_SEED;
+  int n = 0;
+  *alive = 1;
+  for (int j = 0; j < m->L; j++) {            /* RandomShape with zero shift, data.cpp:225-236 */
+    shape[2 * j] = m->mean_shape[2 * j] + 0.;
+    shape[2 * j + 1] = m->mean_shape[2 * j + 1] + 0.;
+  }
+  for (int t = 0; t < m->T; t++) {
+    for (int k = 0; k < m->K; k++) {
+      const long long c = (long long)t * m->K + k;
+      int at = 0; /* 0-based position in the stored node array == reference idx-1 */
+      for (int d = 0; d < m->D - 1; d++) {
+        const orc_node *nd = &m->nodes[c * node_n + at];
+        const double o1x = 1. * (1. * nd->off[0] + 0. * nd->off[1]);
+        const double o1y = 1. * (0. * nd->off[0] + 1. * nd->off[1]);
+        const double o2x = 1. * (1. * nd->off[2] + 0. * nd->off[3]);
+        const double o2y = 1. * (0. * nd->off[2] + 1. * nd->off[3]);
+        const double x1 = (shape[2 * nd->lm1] + o1x) * win;
+        const double y1 = (shape[2 * nd->lm1 + 1] + o1y) * win;
+        const double x2 = (shape[2 * nd->lm2] + o2x) * win;
+        const double y2 = (shape[2 * nd->lm2 + 1] + o2y) * win;
+        int ix1 = (int)round(x1), iy1 = (int)round(y1), ix2 = (int)round(x2), iy2 = (int)round(y2);
+        if (ix1 < 0) ix1 = 0;
+        if (iy1 < 0) iy1 = 0;
+        if (ix1 >= win) ix1 = win - 1;
+        if (iy1 >= win) iy1 = win - 1;
+        if (ix2 < 0) ix2 = 0;
+        if (iy2 < 0) iy2 = 0;
+        if (ix2 >= win) ix2 = win - 1;
+        if (iy2 >= win) iy2 = win - 1;
+        const int val = (int)img[(size_t)(y + iy1) * iw + x + ix1] - (int)img[(size_t)(y + iy2) * iw + x + ix2];
+        /* reference is 1-based: left child 2i, right 2i+1; 0-based: 2i+1 / 2i+2 */
+        at = 2 * at + (val <= nd->th ? 1 : 2);
+      }
+      const int leaf = at - node_n;
+      hash = FNV_STEP(hash, leaf);
+      score += m->leaf[c * leaf_n + leaf];
+      score = (score - m->cmean[c]) / m->cstd[c];
+      n++;
+      if (score < m->cth[c]) { *alive = 0; *score_out = score; *hash_out = hash; return n; }
+      lbf[k] = k * leaf_n + leaf;
+    }
+    const double *ws = &m->w[(size_t)t * m->K * leaf_n * dim];
+    for (int i = 0; i < dim; i++) delta[i] = 0.;
+    for (int k = 0; k < m->K; k++) {
+      const double *row = ws + (size_t)lbf[k] * dim;
+      for (int i = 0; i < dim; i++) delta[i] += row[i];
+    }
+    for (int j = 0; j < m->L; j++) {           /* stp_mc.Apply(delta, delta) with identity */
+      const double dx = delta[2 * j], dy = delta[2 * j + 1];
+      delta[2 * j] = 1. * (1. * dx + 0. * dy);
+      delta[2 * j + 1] = 1. * (0. * dx + 1. * dy);
+    }
+    for (int i = 0; i < dim; i++) shape[i] += delta[i];
+  }
+  *score_out = score;
+  *hash_out = hash;
+  return n;
+}
+
+static int orc_has_multiscale(const orc_model *m) {
+  for (long long i = 0; i < (long long)m->T * m->K * m->node_n; i++)
+    if (m->nodes[i].scale != 0) return 1;
+  return 0;
+}
+
+long long orc_trace_cpp(const orc_model *m, const unsigned char *img, int w, int h,
+                        int minimum_size, int step, double factor,
+                        int *carts_n, double *score, unsigned *path_hash, double *shapes) {
+  orc_level lv[256];
+  long long tot = 0;
+  const int nl = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
+  if (nl < 0 || orc_has_multiscale(m)) return -1;
+  double *shape = (double *)malloc(sizeof(double) * m->dim);
+  double *delta = (double *)malloc(sizeof(double) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  long long id = 0;
+  for (int l = 0; l < nl; l++)
+    for (int iy = 0; iy < lv[l].ny; iy++)
+      for (int ix = 0; ix < lv[l].nx; ix++, id++) {
+        double s; unsigned hsh; int alive;
+        const int n = orc_walk_cpp(m, img, w, ix * lv[l].step, iy * lv[l].step, lv[l].win,
+                                   shape, delta, lbf, &s, &hsh, &alive);
+        if (carts_n) carts_n[id] = n;
+        if (score) score[id] = s;
+        if (path_hash) path_hash[id] = hsh;
+        if (shapes) memcpy(shapes + (size_t)id * m->dim, shape, sizeof(double) * m->dim);
+      }
+  free(shape); free(delta); free(lbf);
+  return tot;
+}
+
+/* nms of cascador.cpp:387-429: ascending multimap (equal keys in insertion
+ * order), pick the last, erase everything whose IoU with it exceeds overlap. */
+static int orc_nms_cpp(const int *r, const double *sc, int n, double overlap, int *picked) {
+  int *asc = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+  unsigned char *alive = (unsigned char *)malloc(n > 0 ? n : 1);
+  for (int i = 0; i < n; i++) { asc[i] = i; alive[i] = 1; }
+  for (int i = 1; i < n; i++) { /* stable insertion sort, ascending */
+    int v = asc[i], j = i - 1;
+    while (j >= 0 && sc[asc[j]] > sc[v]) { asc[j + 1] = asc[j]; j--; }
+    asc[j + 1] = v;
+  }
+  int np = 0, hi = n - 1;
+  for (;;) {
+    while (hi >= 0 && !alive[hi]) hi--;
+    if (hi < 0) break;
+    const int last = asc[hi];
+    picked[np++] = last;
+    const double la = r[4 * last + 2] * r[4 * last + 3];
+    for (int p = 0; p <= hi; p++) {
+      if (!alive[p]) continue;
+      const int idx = asc[p];
+      const double x1 = r[4 * idx] > r[4 * last] ? r[4 * idx] : r[4 * last];
+      const double y1 = r[4 * idx + 1] > r[4 * last + 1] ? r[4 * idx + 1] : r[4 * last + 1];
+      const int ex = r[4 * idx] + r[4 * idx + 2], lx = r[4 * last] + r[4 * last + 2];
+      const int ey = r[4 * idx + 1] + r[4 * idx + 3], ly = r[4 * last + 1] + r[4 * last + 3];
+      const double x2 = ex < lx ? ex : lx, y2 = ey < ly ? ey : ly;
+      const double ww = x2 - x1 > 0. ? x2 - x1 : 0., hh = y2 - y1 > 0. ? y2 - y1 : 0.;
+      const double ia = r[4 * idx + 2] * r[4 * idx + 3];
+      const double ov = ww * hh / (ia + la - ww * hh);
+      if (ov > overlap) alive[p] = 0;
+    }
+    alive[hi] = 0; /* guards the reference's endless loop when overlap >= 1 */
+  }
+  free(asc); free(alive);
+  return np;
+}
+
+/* JoinCascador::Detect with method 1 (cascador.cpp:431-477). Outputs sized per
+ * window count. rects are (x,y,w,h). Returns detections. */
+int orc_detect_cpp(const orc_model *m, const unsigned char *img, int w, int h,
+                   int minimum_size, int step, double factor, double overlap, int do_nms,
+                   int *rects, double *scores, double *shapes) {
+  orc_level lv[256];
+  long long tot = 0;
+  const int nl = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
+  if (nl < 0 || orc_has_multiscale(m)) return -1;
+  double *shape = (double *)malloc(sizeof(double) * m->dim);
+  double *delta = (double *)malloc(sizeof(double) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  int *r0 = (int *)malloc(sizeof(int) * 4 * (tot > 0 ? tot : 1));
+  double *s0 = (double *)malloc(sizeof(double) * (tot > 0 ? tot : 1));
+  double *h0 = (double *)malloc(sizeof(double) * m->dim * (tot > 0 ? tot : 1));
+  int n = 0;
+  for (int l = 0; l < nl; l++)
+    for (int iy = 0; iy < lv[l].ny; iy++)
+      for (int ix = 0; ix < lv[l].nx; ix++) {
+        double s; unsigned hsh; int alive;
+        const int x = ix * lv[l].step, y = iy * lv[l].step;
+        (void)orc_walk_cpp(m, img, w, x, y, lv[l].win, shape, delta, lbf, &s, &hsh, &alive);
+        if (!alive) continue;
+        r0[4 * n] = x; r0[4 * n + 1] = y; r0[4 * n + 2] = lv[l].win; r0[4 * n + 3] = lv[l].win;
+        s0[n] = s;
+        memcpy(h0 + (size_t)n * m->dim, shape, sizeof(double) * m->dim);
+        n++;
+      }
+  int *picked = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+  int np;
+  if (do_nms) np = orc_nms_cpp(r0, s0, n, overlap, picked);
+  else { np = n; for (int i = 0; i < n; i++) picked[i] = i; }
+  for (int i = 0; i < np; i++) {
+    const int p = picked[i];
+    memcpy(rects + 4 * i, r0 + 4 * p, sizeof(int) * 4);
+    scores[i] = s0[p];
+    const double *src = h0 + (size_t)p * m->dim;
+    double *dst = shapes + (size_t)i * m->dim;
+    for (int j = 0; j < m->L; j++) {           /* cascador.cpp:468-471 */
+      dst[2 * j] = r0[4 * p] + src[2 * j] * r0[4 * p + 2];
+      dst[2 * j + 1] = r0[4 * p + 1] + src[2 * j + 1] * r0[4 * p + 3];
+    }
+  }
+  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(picked);
+  return np;
+}
