@@ -212,6 +212,13 @@ JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames
                               double factor, double overlap, int nms,
                               jdaStats *stats, jdaResultD *out);
 
+/* Per-window trace of the dialect-CPP cascade, like jdaTraceBatch but with the
+ * fp64 state of reference Validate (src/jda/cascador.cpp:166-211): carts_n is
+ * Validate's `n`. */
+JDA_API int jdaTraceBatchCpp(void *cascador, const unsigned char *const *frames, int n,
+                             int width, int height, int minimum_size, int step, double factor,
+                             int *carts_n, double *score, unsigned int *path_hash, double *shapes);
+
 #ifdef __cplusplus
 }
 #endif

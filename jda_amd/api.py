@@ -1,0 +1,323 @@
+"""ctypes binding of libjda.so -- the host-side mirror of the reference's C API.
+
+The function names, argument order and ownership rules are the reference's
+(reference c/jda.h:31-68): jdaCascadorCreateDouble / jdaCascadorCreateFloat /
+jdaCascadorSerializeTo / jdaCascadorRelease / jdaDetect / jdaResultRelease.
+On top of that sit thin numpy-friendly wrappers for the additive batch and
+trace entry points of include/jda.h.
+
+There is no fallback: if libjda.so is missing this module raises at import
+time, and if no HIP device is usable every detect call raises JdaError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjda.so")
+
+JDA_DIALECT_C = 0
+JDA_DIALECT_CPP = 1
+
+
+class JdaError(RuntimeError):
+    pass
+
+
+class jdaResult(C.Structure):
+    _fields_ = [("n", C.c_int), ("landmark_n", C.c_int), ("bboxes", C.POINTER(C.c_int)),
+                ("shapes", C.POINTER(C.c_float)), ("scores", C.POINTER(C.c_float))]
+
+
+class jdaResultD(C.Structure):
+    _fields_ = [("n", C.c_int), ("landmark_n", C.c_int), ("rects", C.POINTER(C.c_int)),
+                ("shapes", C.POINTER(C.c_double)), ("scores", C.POINTER(C.c_double))]
+
+
+class jdaModelInfo(C.Structure):
+    _fields_ = [("T", C.c_int), ("K", C.c_int), ("landmark_n", C.c_int), ("tree_depth", C.c_int),
+                ("multi_scale", C.c_int), ("source_real_bytes", C.c_int)]
+
+
+class jdaStats(C.Structure):
+    _fields_ = [("patch_n", C.c_longlong), ("face_patch_n", C.c_longlong), ("nonface_patch_n", C.c_longlong),
+                ("cart_gothrough_n", C.c_longlong), ("stage_done_n", C.c_longlong * 16),
+                ("average_cart_n", C.c_double), ("gpu_ms", C.c_double), ("scan_ms", C.c_double),
+                ("host_ms", C.c_double)]
+
+    def asdict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_done_n"}
+        d["stage_done_n"] = list(self.stage_done_n)
+        return d
+
+
+class jdaDetectOptions(C.Structure):
+    _fields_ = [("dialect", C.c_int), ("nms", C.c_int), ("nms_overlap", C.c_float), ("cpp_step", C.c_int),
+                ("hip_stream", C.c_void_p), ("stats", C.POINTER(jdaStats))]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("jda_amd: %s is missing -- build it with `python -m jda_amd.build` "
+                          "(there is no pure-Python or CPU fallback)" % LIB_PATH)
+    # If torch is going to share device pointers with us it must be the one to
+    # load the HIP runtime first (both resolve to the same libamdhip64.so.7).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    u8p = C.POINTER(C.c_ubyte)
+    lib.jdaCascadorCreateDouble.restype = C.c_void_p
+    lib.jdaCascadorCreateDouble.argtypes = [C.c_char_p]
+    lib.jdaCascadorCreateFloat.restype = C.c_void_p
+    lib.jdaCascadorCreateFloat.argtypes = [C.c_char_p]
+    lib.jdaCascadorCreate.restype = C.c_void_p
+    lib.jdaCascadorCreate.argtypes = [C.c_char_p]
+    lib.jdaCascadorSerializeTo.restype = None
+    lib.jdaCascadorSerializeTo.argtypes = [C.c_void_p, C.c_char_p]
+    lib.jdaCascadorRelease.restype = None
+    lib.jdaCascadorRelease.argtypes = [C.c_void_p]
+    lib.jdaDetect.restype = jdaResult
+    lib.jdaDetect.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float]
+    lib.jdaResultRelease.restype = None
+    lib.jdaResultRelease.argtypes = [jdaResult]
+    lib.jdaGetLastError.restype = C.c_char_p
+    lib.jdaCascadorInfo.argtypes = [C.c_void_p, C.POINTER(jdaModelInfo)]
+    lib.jdaSetDevice.argtypes = [C.c_void_p, C.c_int]
+    lib.jdaCountWindows.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                    C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+    lib.jdaDetectOptionsInit.restype = None
+    lib.jdaDetectOptionsInit.argtypes = [C.POINTER(jdaDetectOptions)]
+    lib.jdaDetectBatch.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions), C.POINTER(jdaResult)]
+    lib.jdaDetectBatchDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
+                                         C.POINTER(jdaResult)]
+    lib.jdaTraceBatch.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint), C.POINTER(C.c_float)]
+    lib.jdaBuildPyramid.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    u8p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.jdaResultDRelease.restype = None
+    lib.jdaResultDRelease.argtypes = [jdaResultD]
+    lib.jdaDetectBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    if hasattr(lib, "jdaTraceBatchCpp"):
+        lib.jdaTraceBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_uint), C.POINTER(C.c_double)]
+    return lib
+
+
+lib = _load()
+
+# reference-named entry points, callable exactly like the C functions
+jdaCascadorCreateDouble = lib.jdaCascadorCreateDouble
+jdaCascadorCreateFloat = lib.jdaCascadorCreateFloat
+jdaCascadorSerializeTo = lib.jdaCascadorSerializeTo
+jdaCascadorRelease = lib.jdaCascadorRelease
+jdaDetect = lib.jdaDetect
+jdaResultRelease = lib.jdaResultRelease
+
+
+def last_error():
+    return (lib.jdaGetLastError() or b"").decode()
+
+
+def count_windows(width, height, scale=1.25, min_size=40, max_size=-1):
+    n, nl = C.c_longlong(), C.c_int()
+    if lib.jdaCountWindows(width, height, scale, min_size, max_size, C.byref(n), C.byref(nl)) != 0:
+        raise JdaError(last_error())
+    return n.value, nl.value
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+
+def _take(r):
+    """jdaResult -> dict of numpy copies, then release the C arrays."""
+    n, dim = r.n, 2 * r.landmark_n
+    out = dict(
+        bboxes=np.ctypeslib.as_array(r.bboxes, (n, 3)).copy() if n else np.zeros((0, 3), np.int32),
+        scores=np.ctypeslib.as_array(r.scores, (n,)).copy() if n else np.zeros(0, np.float32),
+        shapes=np.ctypeslib.as_array(r.shapes, (n, dim)).copy() if n else np.zeros((0, dim), np.float32))
+    lib.jdaResultRelease(r)
+    return out
+
+
+def _take_d(r):
+    n, dim = r.n, 2 * r.landmark_n
+    out = dict(
+        rects=np.ctypeslib.as_array(r.rects, (n, 4)).copy() if n else np.zeros((0, 4), np.int32),
+        scores=np.ctypeslib.as_array(r.scores, (n,)).copy() if n else np.zeros(0, np.float64),
+        shapes=np.ctypeslib.as_array(r.shapes, (n, dim)).copy() if n else np.zeros((0, dim), np.float64))
+    lib.jdaResultDRelease(r)
+    return out
+
+
+class Cascador:
+    """Owning handle around the opaque void* of the C API."""
+
+    def __init__(self, model_path, real="auto", device=None):
+        p = os.fsencode(model_path)
+        if real == "double":
+            self.h = lib.jdaCascadorCreateDouble(p)
+        elif real == "float":
+            self.h = lib.jdaCascadorCreateFloat(p)
+        else:
+            self.h = lib.jdaCascadorCreate(p)
+        if not self.h:
+            raise JdaError("cannot load model %s: %s" % (model_path, last_error()))
+        info = jdaModelInfo()
+        lib.jdaCascadorInfo(self.h, C.byref(info))
+        self.T, self.K, self.L, self.D = info.T, info.K, info.landmark_n, info.tree_depth
+        self.multi_scale = bool(info.multi_scale)
+        self.source_real_bytes = info.source_real_bytes
+        self.dim = 2 * self.L
+        if device is not None and lib.jdaSetDevice(self.h, int(device)) != 0:
+            raise JdaError(last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.jdaCascadorRelease(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def serialize(self, path):
+        lib.jdaCascadorSerializeTo(self.h, os.fsencode(path))
+
+    # -- single frame, exactly the reference call -----------------------------
+    def detect(self, img, scale=1.25, step=0.1, min_size=40, max_size=-1, th=-0.5):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        r = lib.jdaDetect(self.h, _u8(img), w, h, scale, step, min_size, max_size, th)
+        err = last_error()
+        if r.n == 0 and err:
+            lib.jdaResultRelease(r)
+            raise JdaError(err)
+        return _take(r)
+
+    def _opts(self, nms, stats):
+        o = jdaDetectOptions()
+        lib.jdaDetectOptionsInit(C.byref(o))
+        o.nms = 1 if nms else 0
+        st = jdaStats() if stats else None
+        if st is not None:
+            o.stats = C.pointer(st)
+        return o, st
+
+    # -- batch of host frames ---------------------------------------------------
+    def detect_batch(self, frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True, stats=False):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        res = (jdaResult * max(n, 1))()
+        o, st = self._opts(nms, stats)
+        rc = lib.jdaDetectBatch(self.h, ptrs, n, w, h, scale, 0.1, min_size, max_size, th, C.byref(o), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = [_take(res[i]) for i in range(n)]
+        return (out, st.asdict()) if stats else out
+
+    # -- batch resident in device memory (torch uint8 CUDA tensor [n,h,w]) ------------
+    def detect_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True,
+                            stats=False, keep_results=True):
+        assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
+        n, h, w = d_frames.shape
+        res = (jdaResult * max(n, 1))()
+        o, st = self._opts(nms, stats)
+        rc = lib.jdaDetectBatchDevice(self.h, C.c_void_p(d_frames.data_ptr()), h * w, n, w, h, scale, 0.1,
+                                      min_size, max_size, th, C.byref(o), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        if keep_results:
+            out = [_take(res[i]) for i in range(n)]
+        else:
+            out = [res[i].n for i in range(n)]
+            for i in range(n):
+                lib.jdaResultRelease(res[i])
+        return (out, st.asdict()) if stats else out
+
+    # -- parity instrumentation ---------------------------------------------------
+    def trace(self, frames, scale=1.25, min_size=40, max_size=-1):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, h, w = frames.shape
+        wpf, _ = count_windows(w, h, scale, min_size, max_size)
+        tot = n * wpf
+        carts = np.zeros(tot, np.int32)
+        score = np.zeros(tot, np.float32)
+        hsh = np.zeros(tot, np.uint32)
+        shapes = np.zeros((tot, self.dim), np.float32)
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        rc = lib.jdaTraceBatch(self.h, ptrs, n, w, h, scale, min_size, max_size,
+                               carts.ctypes.data_as(C.POINTER(C.c_int)), score.ctypes.data_as(C.POINTER(C.c_float)),
+                               hsh.ctypes.data_as(C.POINTER(C.c_uint)), shapes.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != 0:
+            raise JdaError(last_error())
+        return dict(carts_n=carts, score=score, path_hash=hsh, shapes=shapes)
+
+    def build_pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        d = [C.c_int() for _ in range(4)]
+        if lib.jdaBuildPyramid(self.h, _u8(img), w, h, None, C.byref(d[0]), C.byref(d[1]), None,
+                               C.byref(d[2]), C.byref(d[3])) != 0:
+            raise JdaError(last_error())
+        hw, hh, qw, qh = [x.value for x in d]
+        half = np.zeros((max(hh, 0), max(hw, 0)), np.uint8)
+        quarter = np.zeros((max(qh, 0), max(qw, 0)), np.uint8)
+        if lib.jdaBuildPyramid(self.h, _u8(img), w, h, _u8(half), C.byref(d[0]), C.byref(d[1]), _u8(quarter),
+                               C.byref(d[2]), C.byref(d[3])) != 0:
+            raise JdaError(last_error())
+        return half, quarter
+
+    # -- dialect CPP ----------------------------------------------------------------
+    def detect_batch_cpp(self, frames, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True, stats=False):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, h, w = frames.shape
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        res = (jdaResultD * max(n, 1))()
+        st = jdaStats()
+        rc = lib.jdaDetectBatchCpp(self.h, ptrs, n, w, h, minimum_size, step, factor, overlap, 1 if nms else 0,
+                                   C.byref(st), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = [_take_d(res[i]) for i in range(n)]
+        return (out, st.asdict()) if stats else out
+
+    def trace_cpp(self, frames, minimum_size=20, step=5, factor=1.2):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, h, w = frames.shape
+        from . import synth
+        wpf = synth.count_windows_cpp(w, h, minimum_size, step, factor)
+        tot = n * wpf
+        carts = np.zeros(tot, np.int32)
+        score = np.zeros(tot, np.float64)
+        hsh = np.zeros(tot, np.uint32)
+        shapes = np.zeros((tot, self.dim), np.float64)
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        rc = lib.jdaTraceBatchCpp(self.h, ptrs, n, w, h, minimum_size, step, factor,
+                                  carts.ctypes.data_as(C.POINTER(C.c_int)), score.ctypes.data_as(C.POINTER(C.c_double)),
+                                  hsh.ctypes.data_as(C.POINTER(C.c_uint)), shapes.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc != 0:
+            raise JdaError(last_error())
+        return dict(carts_n=carts, score=score, path_hash=hsh, shapes=shapes)

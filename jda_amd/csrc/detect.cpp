@@ -1,0 +1,898 @@
+// libjda.so: the C ABI of include/jda.h on top of the HIP kernels.
+//
+// Boundary of the device work: the host enumerates pyramid
+// levels and does NMS + relocation; the device does resize, cascade walk,
+// stage regression and compaction.  There is no CPU fallback for the cascade:
+// without a usable HIP device every detect entry fails loudly.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/jda.h"
+#include "kernels.h"
+#include "model.h"
+#include "plan.h"
+#include "post.h"
+
+namespace jda {
+
+// ---------------------------------------------------------------- error channel
+
+static thread_local std::string g_err;
+
+static void fail(const std::string& msg) {
+  g_err = msg;
+  std::fprintf(stderr, "libjda: %s\n", msg.c_str());
+}
+
+#define JDA_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      fail(std::string(#expr) + " failed: " + hipGetErrorString(e_));                   \
+      return false;                                                                     \
+    }                                                                                   \
+  } while (0)
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+static long long env_ll(const char* name, long long dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoll(v) : dflt;
+}
+
+// ---------------------------------------------------------------- device buffers
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool reserve(size_t n) {
+    if (n <= bytes) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    JDA_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return true;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// carve typed arrays out of one allocation
+struct Carver {
+  unsigned char* base; size_t off = 0;
+  explicit Carver(void* b) : base((unsigned char*)b) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* r = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return r;
+  }
+};
+
+template <typename Real>
+struct ModelOnDevice {
+  DevModelT<Real> m{};
+  DevBuf buf;
+  bool ready = false;
+};
+
+struct PlanKey {
+  int w, h, dialect, a, b, c;
+  unsigned long long f;
+  bool operator<(const PlanKey& o) const {
+    return std::tie(w, h, dialect, a, b, c, f) < std::tie(o.w, o.h, o.dialect, o.a, o.b, o.c, o.f);
+  }
+};
+
+struct PlanEntry {
+  ScanPlan sp;
+  DevPlan hp{};
+  DevPlan* dp = nullptr;
+  S0Node* table = nullptr;
+  bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
+  bool any_untiled = false;
+};
+
+template <typename Real>
+struct Workspace {
+  DevBuf buf;
+  DevBuf frames;     // staging for host-frame entry points
+  DevBuf pyr;        // half + quarter images (multi-scale models)
+  WorkT<Real> w{};
+  size_t cap = 0;
+  bool trace = false;
+  int dim = 0;
+};
+
+struct Cascador {
+  HostModel hm;
+  std::mutex mu;
+  int device = -1;
+  bool dev_init = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  ModelOnDevice<float> mf;
+  ModelOnDevice<double> md;
+  std::map<PlanKey, PlanEntry> plans;
+  Workspace<float> wf;
+  Workspace<double> wd;
+  unsigned long long* h_counters = nullptr;  // pinned
+};
+
+template <typename Real> struct Sel;
+template <> struct Sel<float> {
+  static ModelOnDevice<float>& model(Cascador* c) { return c->mf; }
+  static Workspace<float>& ws(Cascador* c) { return c->wf; }
+  static constexpr int dialect = JDA_DIALECT_C;
+};
+template <> struct Sel<double> {
+  static ModelOnDevice<double>& model(Cascador* c) { return c->md; }
+  static Workspace<double>& ws(Cascador* c) { return c->wd; }
+  static constexpr int dialect = JDA_DIALECT_CPP;
+};
+
+// ---------------------------------------------------------------- device init
+
+static bool ensure_device(Cascador* c) {
+  if (c->dev_init) {
+    JDA_HIP(hipSetDevice(c->device));
+    return true;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    fail("no usable HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) +
+         "); libjda has no CPU fallback for the cascade");
+    return false;
+  }
+  if (c->device < 0) {
+    int cur = 0;
+    JDA_HIP(hipGetDevice(&cur));
+    c->device = cur;
+  }
+  if (c->device >= n) { fail("device ordinal out of range"); return false; }
+  JDA_HIP(hipSetDevice(c->device));
+  JDA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& ev : c->ev) JDA_HIP(hipEventCreate(&ev));
+  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntTotal, hipHostMallocDefault));
+  c->dev_init = true;
+  return true;
+}
+
+template <typename Real>
+static bool upload_model(Cascador* c) {
+  ModelOnDevice<Real>& mo = Sel<Real>::model(c);
+  if (mo.ready) return true;
+  const HostModel& h = c->hm;
+  using Node = typename std::conditional<sizeof(Real) == 4, NodeF, NodeD>::type;
+  const size_t carts = (size_t)h.carts();
+  const int node_n = h.node_n(), leaf_n = h.leaf_n(), dim = h.dim();
+  std::vector<Node> nodes(carts * node_n);
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const SplitNode& s = h.nodes[i];
+    Node& d = nodes[i];
+    d.scale = s.scale; d.lm1x2 = s.lm1 * 2; d.lm2x2 = s.lm2 * 2; d.th = s.th;
+    if (sizeof(Real) == 4) {
+      // plain narrowing casts, reference c/jda.c:525-532
+      d.o1x = (Real)s.off[0]; d.o1y = (Real)s.off[1]; d.o2x = (Real)s.off[2]; d.o2y = (Real)s.off[3];
+    } else {
+      // identity STParameter::Apply on each offset pair (data.hpp:42-45, data.cpp:33-34)
+      const volatile double one = 1., zero = 0.;
+      d.o1x = (Real)(one * (one * s.off[0] + zero * s.off[1]));
+      d.o1y = (Real)(one * (zero * s.off[0] + one * s.off[1]));
+      d.o2x = (Real)(one * (one * s.off[2] + zero * s.off[3]));
+      d.o2y = (Real)(one * (zero * s.off[2] + one * s.off[3]));
+    }
+  }
+  auto cast = [](const std::vector<double>& v) {
+    std::vector<Real> o(v.size());
+    for (size_t i = 0; i < v.size(); i++) o[i] = (Real)v[i];
+    return o;
+  };
+  std::vector<Real> leaf = cast(h.leaf_score), cth = cast(h.cart_th), cmean = cast(h.cart_mean),
+                    cstd = cast(h.cart_std), w = cast(h.w), ms = cast(h.mean_shape);
+  if (sizeof(Real) == 8) {
+    const volatile double zero = 0.;
+    for (auto& v : ms) v = (Real)((double)v + zero);   // RandomShape with zero shift, data.cpp:225-236
+  }
+  std::vector<uint8_t> cnorm(carts);
+  for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
+
+  Carver sz(nullptr);
+  sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
+  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim);
+  if (!mo.buf.reserve(sz.off + 256)) return false;
+  Carver cv(mo.buf.p);
+  Node* d_nodes = cv.take<Node>(nodes.size());
+  Real* d_leaf = cv.take<Real>(leaf.size());
+  Real* d_cth = cv.take<Real>(carts);
+  Real* d_cmean = cv.take<Real>(carts);
+  Real* d_cstd = cv.take<Real>(carts);
+  uint8_t* d_cnorm = cv.take<uint8_t>(carts);
+  Real* d_w = cv.take<Real>(w.size());
+  Real* d_ms = cv.take<Real>(dim);
+  JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cmean, cmean.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cstd, cstd.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cnorm, cnorm.data(), carts, hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_w, w.data(), w.size() * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
+  DevModelT<Real>& m = mo.m;
+  m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
+  m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
+  m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms;
+  mo.ready = true;
+  return true;
+}
+
+// ---------------------------------------------------------------- tiling of levels
+
+// Chooses, per level, how many windows share one LDS pixel tile.  See DESIGN.md
+// "LDS tiles": 256-thread workgroups share a tile of up to 512 windows while
+// the tile stays small enough for several workgroups per CU; one-wave
+// workgroups take the mid-size windows; the largest windows go to the generic
+// walker, which reads pixels through L1/L2.
+static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan, PlanEntry* pe) {
+  static const int wide_opts[][2] = {{32, 16}, {16, 16}};
+  static const int narrow_opts[][2] = {{8, 8}, {8, 4}, {4, 4}};
+  const int wide_budget = (int)env_ll("JDA_PIX_WIDE", 48 * 1024);
+  const int wide_pref = (int)env_ll("JDA_PIX_WIDE_PREF", 24 * 1024);
+  const int narrow_budget = (int)env_ll("JDA_PIX_NARROW", 56 * 1024);
+  DevPlan& hp = pe->hp;
+  hp.n_levels = (int)sp.levels.size();
+  hp.width = sp.width; hp.height = sp.height; hp.windows = (int)sp.windows;
+  int table = 0;
+  pe->any_untiled = false;
+  for (int i = 0; i < hp.n_levels; i++) {
+    const Level& s = sp.levels[i];
+    DevLevel& d = hp.lv[i];
+    d.win = s.win; d.step = s.step; d.nx = s.nx; d.ny = s.ny; d.base = (int)s.base;
+    d.tile_class = kTileNone; d.tw = d.th = 1; d.tiles_x = d.tiles_y = 0; d.pitch = 0; d.s0_table = 0;
+    auto try_tile = [&](int tw, int th, int budget, int cls) {
+      if (d.tile_class != kTileNone) return;
+      const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
+      int pitch = (pw + 3 + 3) & ~3;
+      if ((pitch & 127) == 0) pitch += 4;     // keep tile rows off a 32-bank multiple
+      const long long bytes = (long long)pitch * ph;
+      if (bytes > budget || bytes > 65535) return;
+      d.tile_class = cls; d.tw = tw; d.th = th; d.pitch = pitch;
+    };
+    if (fast_scan) {
+      const long long cnt = (long long)s.nx * s.ny;
+      if (cnt >= 256) {
+        for (auto& o : wide_opts) try_tile(o[0], o[1], wide_pref, kTileWide);
+        try_tile(16, 16, wide_budget, kTileWide);
+      }
+      for (auto& o : narrow_opts) try_tile(o[0], o[1], narrow_budget, kTileNarrow);
+    }
+    if (d.tile_class == kTileNone) { pe->any_untiled = true; continue; }
+    d.tiles_x = (s.nx + d.tw - 1) / d.tw;
+    d.tiles_y = (s.ny + d.th - 1) / d.th;
+    d.s0_table = table;
+    table += hm.K * hm.node_n();
+  }
+}
+
+static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out) {
+  auto it = c->plans.find(key);
+  if (it != c->plans.end()) { *out = &it->second; return true; }
+  if ((int)sp.levels.size() > kMaxLevels) { fail("too many pyramid levels"); return false; }
+  if (sp.windows * 1LL > 0x7fffffffLL) { fail("frame has too many windows"); return false; }
+  PlanEntry pe;
+  pe.sp = sp;
+  // LDS-tiled stage-0 scan needs every stage-0 node to read the origin image
+  bool s0_plain = true;
+  const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
+  for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
+  pe.fast_scan = s0_plain && env_ll("JDA_NO_FAST_SCAN", 0) == 0;
+  assign_tiles(sp, c->hm, pe.fast_scan, &pe);
+  JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
+  JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
+  size_t entries = 0;
+  for (int i = 0; i < pe.hp.n_levels; i++)
+    if (pe.hp.lv[i].tile_class != kTileNone) entries += n0;
+  if (entries) {
+    JDA_HIP(hipMalloc((void**)&pe.table, entries * sizeof(S0Node)));
+    const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
+    const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
+    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream));
+  }
+  auto ins = c->plans.emplace(key, std::move(pe));
+  *out = &ins.first->second;
+  return true;
+}
+
+// ---------------------------------------------------------------- workspace
+
+template <typename Real>
+static size_t bytes_per_window(int dim, bool trace) {
+  size_t b = 2 * (4 + sizeof(Real) + 4) + 2 * (size_t)dim * sizeof(Real) + 4 + 4;
+  if (trace) b += 2 * 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
+  return b;
+}
+
+template <typename Real>
+static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
+  Workspace<Real>& ws = Sel<Real>::ws(c);
+  const int dim = c->hm.dim();
+  if (ws.cap >= cap && (ws.trace || !trace) && ws.dim == dim) return true;
+  auto carve = [&](Carver& cv) {
+    WorkT<Real>& w = ws.w;
+    for (int p = 0; p < 2; p++) {
+      w.q_gid[p] = cv.take<uint32_t>(cap);
+      w.q_score[p] = cv.take<Real>(cap);
+      w.q_src[p] = cv.take<uint32_t>(cap);
+      w.q_hash[p] = trace ? cv.take<uint32_t>(cap) : nullptr;
+      w.shape[p] = cv.take<Real>(cap * dim);
+    }
+    w.qg_gid = cv.take<uint32_t>(cap);
+    w.out_slot = cv.take<uint32_t>(cap);
+    w.counters = cv.take<unsigned long long>(kCntTotal);
+    if (trace) {
+      w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
+      w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
+    } else {
+      w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
+    }
+  };
+  Carver sz(nullptr);
+  carve(sz);
+  if (!ws.buf.reserve(sz.off + 256)) return false;
+  Carver cv(ws.buf.p);
+  carve(cv);
+  ws.w.cap = (unsigned)cap;
+  ws.cap = cap; ws.trace = trace; ws.dim = dim;
+  return true;
+}
+
+// ---------------------------------------------------------------- the pipeline
+
+template <typename Real>
+struct RawDets {               // survivors of a batch, sorted by gid (= frame, then scan order)
+  std::vector<uint32_t> gid;
+  std::vector<Real> score;
+  std::vector<Real> shape;     // [n][dim]
+};
+
+template <typename Real>
+struct TraceOut {              // host arrays, may be null
+  int* carts_n; Real* score; unsigned* path_hash; Real* shapes;
+};
+
+struct RunStats {
+  long long carts = 0, out = 0;
+  long long stage_done[kMaxStages] = {0};
+  double gpu_ms = 0, scan_ms = 0;
+};
+
+// Runs the device pipeline over n frames resident in device memory.
+template <typename Real>
+static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+                       bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
+                       const TraceOut<Real>* trace, RunStats* rs) {
+  constexpr int dialect = Sel<Real>::dialect;
+  const HostModel& hm = c->hm;
+  const DevModelT<Real>& m = Sel<Real>::model(c).m;
+  const int dim = hm.dim(), T = hm.T;
+  const long long wpf = pe->sp.windows;
+  const bool want_trace = trace != nullptr;
+  const bool multi = hm.multi_scale();
+  if (multi && dialect == JDA_DIALECT_CPP) {
+    fail("dialect CPP supports only scale==0 split nodes (cv::resize is not reproduced; SURVEY.md 8c)");
+    return false;
+  }
+  hipStream_t st = user_stream ? user_stream : c->stream;
+  if (wpf == 0 || n == 0) return true;
+
+  // frames per pass, bounded by the workspace budget
+  const size_t bpw = bytes_per_window<Real>(dim, want_trace);
+  const long long budget = env_ll("JDA_WORKSPACE_MB", 24 * 1024) << 20;
+  long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
+  fpp = std::min<long long>(fpp, n);
+  fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
+  if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
+  const size_t cap = (size_t)fpp * (size_t)wpf;
+  if (!ensure_workspace<Real>(c, cap, want_trace)) return false;
+  Workspace<Real>& ws = Sel<Real>::ws(c);
+
+  int hw = 0, hh = 0, qw = 0, qh = 0;
+  if (multi) {
+    const float r = 1.f / sqrtf(2.f);                       // c/jda.c:450-456
+    hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
+    qw = pe->sp.width / 2; qh = pe->sp.height / 2;
+    if (hw < 1 || hh < 1 || qw < 1 || qh < 1) { fail("frame too small for the half/quarter images"); return false; }
+    if (!ws.pyr.reserve(((size_t)hw * hh + (size_t)qw * qh + 512) * (size_t)fpp)) return false;
+  }
+
+  for (int f0 = 0; f0 < n; f0 += (int)fpp) {
+    const int nf = std::min<int>((int)fpp, n - f0);
+    WorkT<Real> w = ws.w;
+    w.frames = d_frames + (size_t)f0 * stride; w.frame_stride = stride; w.n_frames = nf;
+    w.half = nullptr; w.quarter = nullptr; w.half_stride = w.quarter_stride = 0;
+    w.hw = hw; w.hh = hh; w.qw = qw; w.qh = qh;
+    JDA_HIP(hipEventRecord(c->ev[0], st));
+    JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntTotal, st));
+    if (multi) {
+      uint8_t* hbuf = (uint8_t*)ws.pyr.p;
+      const size_t hs = ((size_t)hw * hh + 255) & ~(size_t)255, qs = ((size_t)qw * qh + 255) & ~(size_t)255;
+      uint8_t* qbuf = hbuf + hs * (size_t)fpp;
+      const int W = pe->sp.width, H = pe->sp.height;
+      JDA_HIP(launch_resize(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, (float)(W - 1) / hw, (float)(H - 1) / hh, st));
+      JDA_HIP(launch_resize(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, (float)(W - 1) / qw, (float)(H - 1) / qh, st));
+      w.half = hbuf; w.half_stride = hs; w.quarter = qbuf; w.quarter_stride = qs;
+    }
+    if (want_trace) {
+      JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
+      JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
+    }
+    // ---- stage 0 ----
+    JDA_HIP(hipEventRecord(c->ev[1], st));
+    if (pe->fast_scan) {
+      for (int l = 0; l < pe->hp.n_levels; l++)
+        JDA_HIP(launch_scan<Real>(l, want_trace, pe->dp, pe->hp, m, pe->table, w, st));
+    }
+    JDA_HIP(hipEventRecord(c->ev[2], st));
+    if (!pe->fast_scan || pe->any_untiled) {
+      JDA_HIP(launch_enqueue_generic<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
+      JDA_HIP(launch_walk<Real>(dialect, want_trace, 0, pe->dp, m, w, st));
+    }
+    // ---- regression + later stages ----
+    for (int t = 0; t < T; t++) {
+      if (t > 0) JDA_HIP(launch_walk<Real>(dialect, want_trace, t, pe->dp, m, w, st));
+      JDA_HIP(launch_update<Real>(dialect, want_trace, t, apply_th, th, pe->dp, m, w, st));
+    }
+    JDA_HIP(launch_pack<Real>(w, T, dim, st));
+    JDA_HIP(hipEventRecord(c->ev[3], st));
+    JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntTotal, hipMemcpyDeviceToHost, st));
+    JDA_HIP(hipStreamSynchronize(st));
+    float ms_all = 0, ms_scan = 0;
+    (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[3]);
+    (void)hipEventElapsedTime(&ms_scan, c->ev[1], c->ev[2]);
+    rs->gpu_ms += ms_all; rs->scan_ms += ms_scan;
+    rs->carts += (long long)c->h_counters[kCntCarts];
+    for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntQueue0 + t];
+    const size_t n_out = (size_t)c->h_counters[kCntOut];
+    rs->out += (long long)n_out;
+    if (n_out > cap) { fail("internal: more detections than windows"); return false; }
+    // ---- detections of this pass -> host, sorted back into scan order ----
+    if (n_out && dets) {
+      const int po = T & 1;
+      std::vector<uint32_t> g(n_out);
+      std::vector<Real> s(n_out), sh(n_out * dim);
+      JDA_HIP(hipMemcpyAsync(g.data(), w.q_gid[po], n_out * 4, hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(s.data(), w.q_score[po], n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(sh.data(), w.shape[po], n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipStreamSynchronize(st));
+      std::vector<uint32_t> ord(n_out);
+      std::iota(ord.begin(), ord.end(), 0u);
+      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return g[a] < g[b]; });
+      const size_t o0 = dets->gid.size();
+      dets->gid.resize(o0 + n_out); dets->score.resize(o0 + n_out); dets->shape.resize((o0 + n_out) * dim);
+      const uint32_t gid_off = (uint32_t)((size_t)f0 * wpf);
+      for (size_t i = 0; i < n_out; i++) {
+        const uint32_t j = ord[i];
+        dets->gid[o0 + i] = g[j] + gid_off;
+        dets->score[o0 + i] = s[j];
+        std::memcpy(&dets->shape[(o0 + i) * dim], &sh[(size_t)j * dim], dim * sizeof(Real));
+      }
+    }
+    if (want_trace) {
+      const size_t nw = (size_t)nf * wpf, o = (size_t)f0 * wpf;
+      if (trace->carts_n) JDA_HIP(hipMemcpy(trace->carts_n + o, w.tr_carts, nw * 4, hipMemcpyDeviceToHost));
+      if (trace->score) JDA_HIP(hipMemcpy(trace->score + o, w.tr_score, nw * sizeof(Real), hipMemcpyDeviceToHost));
+      if (trace->path_hash) JDA_HIP(hipMemcpy(trace->path_hash + o, w.tr_hash, nw * 4, hipMemcpyDeviceToHost));
+      if (trace->shapes) JDA_HIP(hipMemcpy(trace->shapes + o * dim, w.tr_shape, nw * dim * sizeof(Real), hipMemcpyDeviceToHost));
+    }
+  }
+  return true;
+}
+
+// window of a gid
+struct WinRef { int frame, x, y, win; };
+static WinRef locate(const ScanPlan& sp, uint32_t gid) {
+  WinRef r;
+  r.frame = (int)(gid / (uint32_t)sp.windows);
+  const long long wid = gid - (long long)r.frame * sp.windows;
+  size_t l = 0;
+  for (size_t i = 1; i < sp.levels.size(); i++)
+    if (wid >= sp.levels[i].base) l = i;
+  const Level& lv = sp.levels[l];
+  const long long rel = wid - lv.base;
+  r.y = (int)(rel / lv.nx) * lv.step;
+  r.x = (int)(rel % lv.nx) * lv.step;
+  r.win = lv.win;
+  return r;
+}
+
+static void parallel_for(int n, const std::function<void(int)>& fn) {
+  unsigned hwc = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hwc ? hwc : 4, 32);
+  nt = std::min(nt, n);
+  if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  std::vector<std::thread> th;
+  std::atomic<int> next{0};
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+  for (auto& t : th) t.join();
+}
+
+static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int T, double host_ms) {
+  if (!st) return;
+  std::memset(st, 0, sizeof(*st));
+  st->patch_n = patch_n;
+  st->face_patch_n = rs.out;
+  st->nonface_patch_n = patch_n - rs.out;
+  st->cart_gothrough_n = rs.carts;
+  for (int t = 0; t < T && t < 16; t++) st->stage_done_n[t] = rs.stage_done[t];
+  st->average_cart_n = st->nonface_patch_n > 0 ? (double)rs.carts / (double)st->nonface_patch_n : 0.0;
+  st->gpu_ms = rs.gpu_ms; st->scan_ms = rs.scan_ms; st->host_ms = host_ms;
+}
+
+static jdaResult empty_result(int landmark_n) {
+  jdaResult r;
+  r.n = 0; r.landmark_n = landmark_n;
+  r.bboxes = (int*)std::malloc(sizeof(int));
+  r.shapes = (float*)std::malloc(sizeof(float));
+  r.scores = (float*)std::malloc(sizeof(float));
+  return r;
+}
+
+// dialect C batch on device-resident frames -> per-frame jdaResult
+static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
+                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
+                           jdaResult* out) {
+  // caller holds c->mu
+  if (!c || !out || n < 0) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L, dim = c->hm.dim();
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  ScanPlan sp;
+  std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
+  if (stride < (size_t)width * height) { fail("frame_stride smaller than a frame"); return -1; }
+  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
+  PlanEntry* pe = nullptr;
+  if (!get_plan(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
+  RawDets<float> dets;
+  RunStats rs;
+  if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
+    return -1;
+
+  const double t0 = now_ms();
+  const bool do_nms = !opt || opt->nms;
+  const float overlap = opt ? opt->nms_overlap : 0.3f;
+  // split by frame (dets are sorted by gid)
+  std::vector<size_t> first(n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] / (uint32_t)sp.windows == (uint32_t)f) i++;
+    }
+    first[n] = i;
+  }
+  parallel_for(n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    std::vector<int> bb(cnt * 3);
+    for (size_t i = 0; i < cnt; i++) {
+      const WinRef wr = locate(sp, dets.gid[a + i]);
+      bb[3 * i] = wr.x; bb[3 * i + 1] = wr.y; bb[3 * i + 2] = wr.win;
+    }
+    std::vector<int> keep;
+    if (do_nms) keep = nms_dialect_c(bb.data(), &dets.score[a], (int)cnt, overlap);
+    else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
+    jdaResult& r = out[f];
+    r.n = (int)keep.size(); r.landmark_n = L;
+    r.bboxes = (int*)std::malloc(std::max<size_t>(1, keep.size() * 3) * sizeof(int));
+    r.scores = (float*)std::malloc(std::max<size_t>(1, keep.size()) * sizeof(float));
+    r.shapes = (float*)std::malloc(std::max<size_t>(1, keep.size() * dim) * sizeof(float));
+    for (size_t i = 0; i < keep.size(); i++) {
+      const int k = keep[i];
+      std::memcpy(r.bboxes + 3 * i, &bb[3 * k], 3 * sizeof(int));
+      r.scores[i] = dets.score[a + k];
+      float* sh = r.shapes + i * dim;
+      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
+      relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
+    }
+  });
+  fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, now_ms() - t0);
+  return 0;
+}
+
+template <typename Real>
+static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n, size_t fbytes, size_t* stride) {
+  Workspace<Real>& ws = Sel<Real>::ws(c);
+  *stride = (fbytes + 255) & ~(size_t)255;
+  if (!ws.frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
+  for (int i = 0; i < n; i++)
+    JDA_HIP(hipMemcpyAsync((uint8_t*)ws.frames.p + (size_t)i * *stride, frames[i], fbytes, hipMemcpyHostToDevice, c->stream));
+  JDA_HIP(hipStreamSynchronize(c->stream));
+  return true;
+}
+
+}  // namespace jda
+
+// =============================================================================
+// C ABI
+// =============================================================================
+
+using namespace jda;
+
+extern "C" {
+
+const char* jdaGetLastError(void) { return g_err.c_str(); }
+
+static void* create_impl(const char* path, int real_bytes) {
+  g_err.clear();
+  Cascador* c = new (std::nothrow) Cascador();
+  if (!c) return nullptr;
+  std::string err;
+  if (!load_model(path, real_bytes, &c->hm, &err)) {
+    g_err = err;   // reference returns NULL silently (c/jda.c:487-488); keep the reason retrievable
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void* jdaCascadorCreateDouble(const char* model) { return create_impl(model, 8); }
+void* jdaCascadorCreateFloat(const char* model) { return create_impl(model, 4); }
+void* jdaCascadorCreate(const char* model) { return create_impl(model, 0); }
+
+void jdaCascadorSerializeTo(void* cascador, const char* model) {
+  if (!cascador) return;
+  (void)save_model_f32(((Cascador*)cascador)->hm, model);
+}
+
+void jdaCascadorRelease(void* cascador) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return;
+  if (c->dev_init) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
+    c->mf.buf.release(); c->md.buf.release();
+    c->wf.buf.release(); c->wf.frames.release(); c->wf.pyr.release();
+    c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+int jdaCascadorInfo(void* cascador, jdaModelInfo* info) {
+  if (!cascador || !info) return -1;
+  const HostModel& h = ((Cascador*)cascador)->hm;
+  info->T = h.T; info->K = h.K; info->landmark_n = h.L; info->tree_depth = h.D;
+  info->multi_scale = h.multi_scale() ? 1 : 0; info->source_real_bytes = h.real_bytes;
+  return 0;
+}
+
+int jdaSetDevice(void* cascador, int device) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->dev_init && c->device != device) { fail("jdaSetDevice after first use"); return -1; }
+  c->device = device;
+  return 0;
+}
+
+int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
+                    long long* n_windows, int* n_levels) {
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { g_err = err; return -1; }
+  if (n_windows) *n_windows = sp.windows;
+  if (n_levels) *n_levels = (int)sp.levels.size();
+  return 0;
+}
+
+void jdaDetectOptionsInit(jdaDetectOptions* opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof(*opt));
+  opt->dialect = JDA_DIALECT_C; opt->nms = 1; opt->nms_overlap = 0.3f; opt->cpp_step = 5;
+}
+
+int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
+                         int width, int height, float scale, float step, int min_size, int max_size,
+                         float th, const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;  // ignored like the reference (c/jda.c:333)
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchDevice runs dialect C; use jdaDetectBatchCpp"); return -1; }
+  if (!cascador) { fail("null cascador"); return -1; }
+  std::lock_guard<std::mutex> lock(((Cascador*)cascador)->mu);
+  return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                   float scale, float step, int min_size, int max_size, float th,
+                   const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
+  size_t stride = 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!ensure_device(c)) return -1;
+  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  return detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, n, width, height, scale, min_size, max_size, th, opt, out);
+}
+
+jdaResult jdaDetect(void* cascador, unsigned char* data, int width, int height,
+                    float scale, float step, int min_size, int max_size, float th) {
+  Cascador* c = (Cascador*)cascador;
+  jdaResult r;
+  r.n = 0; r.landmark_n = c ? c->hm.L : 0; r.bboxes = nullptr; r.shapes = nullptr; r.scores = nullptr;
+  if (!c || !data) { fail("jdaDetect: null cascador or image"); return empty_result(r.landmark_n); }
+  const unsigned char* frames[1] = {data};
+  if (jdaDetectBatch(cascador, frames, 1, width, height, scale, step, min_size, max_size, th, nullptr, &r) != 0) {
+    jdaResultRelease(r);
+    return empty_result(c->hm.L);
+  }
+  return r;
+}
+
+void jdaResultRelease(jdaResult result) {
+  std::free(result.bboxes);
+  std::free(result.shapes);
+  std::free(result.scores);
+}
+
+int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                  float scale, int min_size, int max_size, int* carts_n, float* score,
+                  unsigned int* path_hash, float* shapes) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
+  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  size_t stride = 0;
+  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
+  PlanEntry* pe = nullptr;
+  if (!get_plan(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
+  TraceOut<float> tr{carts_n, score, path_hash, shapes};
+  RunStats rs;
+  if (!run_device<float>(c, pe, (const uint8_t*)c->wf.frames.p, stride, n, false, 0.f, nullptr, nullptr, &tr, &rs)) return -1;
+  return 0;
+}
+
+int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int height,
+                    unsigned char* half, int* hw, int* hh, unsigned char* quarter, int* qw, int* qh) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !data || width <= 0 || height <= 0) { fail("bad arguments"); return -1; }
+  const float r = 1.f / sqrtf(2.f);
+  const int w1 = (int)((float)width * r), h1 = (int)((float)height * r), w2 = width / 2, h2 = height / 2;
+  if (hw) *hw = w1; if (hh) *hh = h1; if (qw) *qw = w2; if (qh) *qh = h2;
+  if (!half && !quarter) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!ensure_device(c)) return -1;
+  const unsigned char* frames[1] = {data};
+  size_t stride = 0;
+  if (!stage_frames<float>(c, frames, 1, (size_t)width * height, &stride)) return -1;
+  auto one = [&](unsigned char* dst, int dw, int dh) -> bool {
+    if (!dst || dw < 1 || dh < 1) return true;
+    if (!c->wf.pyr.reserve((size_t)dw * dh + 256)) return false;
+    JDA_HIP(launch_resize((const uint8_t*)c->wf.frames.p, stride, 1, width, height, (uint8_t*)c->wf.pyr.p,
+                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, c->stream));
+    JDA_HIP(hipMemcpyAsync(dst, c->wf.pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, c->stream));
+    JDA_HIP(hipStreamSynchronize(c->stream));
+    return true;
+  };
+  if (!one(half, w1, h1) || !one(quarter, w2, h2)) return -1;
+  return 0;
+}
+
+int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                     int minimum_size, int step, double factor, int* carts_n, double* score,
+                     unsigned int* path_hash, double* shapes) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
+  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
+  size_t stride = 0;
+  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  unsigned long long fb; std::memcpy(&fb, &factor, 8);
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, 0, fb};
+  PlanEntry* pe = nullptr;
+  if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  TraceOut<double> tr{carts_n, score, path_hash, shapes};
+  RunStats rs;
+  if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs)) return -1;
+  return 0;
+}
+
+void jdaResultDRelease(jdaResultD result) {
+  std::free(result.rects);
+  std::free(result.shapes);
+  std::free(result.scores);
+}
+
+int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                      int minimum_size, int step, double factor, double overlap, int nms,
+                      jdaStats* stats, jdaResultD* out) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  const int L = c->hm.L, dim = c->hm.dim();
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
+  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
+  size_t stride = 0;
+  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  unsigned long long fb; std::memcpy(&fb, &factor, 8);
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, 0, fb};
+  PlanEntry* pe = nullptr;
+  if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  RawDets<double> dets;
+  RunStats rs;
+  if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return -1;
+  const double t0 = now_ms();
+  std::vector<size_t> first(n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] / (uint32_t)sp.windows == (uint32_t)f) i++;
+    }
+    first[n] = i;
+  }
+  parallel_for(n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    std::vector<int> rc(cnt * 4);
+    for (size_t i = 0; i < cnt; i++) {
+      const WinRef wr = locate(sp, dets.gid[a + i]);
+      rc[4 * i] = wr.x; rc[4 * i + 1] = wr.y; rc[4 * i + 2] = wr.win; rc[4 * i + 3] = wr.win;
+    }
+    std::vector<int> pick;
+    if (nms) pick = nms_dialect_cpp(rc.data(), &dets.score[a], (int)cnt, overlap);
+    else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
+    jdaResultD& r = out[f];
+    r.n = (int)pick.size(); r.landmark_n = L;
+    r.rects = (int*)std::malloc(std::max<size_t>(1, pick.size() * 4) * sizeof(int));
+    r.scores = (double*)std::malloc(std::max<size_t>(1, pick.size()) * sizeof(double));
+    r.shapes = (double*)std::malloc(std::max<size_t>(1, pick.size() * dim) * sizeof(double));
+    for (size_t i = 0; i < pick.size(); i++) {
+      const int k = pick[i];
+      std::memcpy(r.rects + 4 * i, &rc[4 * k], 4 * sizeof(int));
+      r.scores[i] = dets.score[a + k];
+      double* sh = r.shapes + i * dim;
+      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(double));
+      relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
+    }
+  });
+  fill_stats(stats, rs, sp.windows * n, c->hm.T, now_ms() - t0);
+  return 0;
+}
+
+}  // extern "C"

@@ -181,6 +181,23 @@ def levels_c(width, height, scale=1.25, min_size=40, max_size=-1):
     return out, base
 
 
+def levels_cpp(width, height, minimum_size=20, step=5, factor=1.2):
+    """detectMultiScale1's window sizes (reference src/jda/cascador.cpp:310-376)."""
+    if minimum_size < 1 or step < 1 or int(minimum_size * factor) <= minimum_size:
+        raise ValueError("bad scan parameters")
+    win, out, base = minimum_size, [], 0
+    while win <= width and win <= height:
+        nx, ny = (width - win) // step + 1, (height - win) // step + 1
+        out.append(dict(win=win, step=step, nx=nx, ny=ny, base=base))
+        base += nx * ny
+        win = int(win * factor)
+    return out, base
+
+
+def count_windows_cpp(width, height, minimum_size=20, step=5, factor=1.2):
+    return levels_cpp(width, height, minimum_size, step, factor)[1]
+
+
 def window_table(width, height, scale=1.25, min_size=40, max_size=-1):
     """(x, y, win) int32 arrays of every window of a frame in scan order."""
     lv, tot = levels_c(width, height, scale, min_size, max_size)
@@ -231,8 +248,6 @@ def calibrate_thresholds(m, frames, tau=27.0, p_final=1e-3, sample=60000, seed=7
     target_prev = 1.0
     for t in range(m.T):
         lbf = np.zeros((len(alive), m.K), np.int64)
-        row_of = {int(a): i for i, a in enumerate(alive)} if False else None
-        stage_ids = alive.copy()      # windows that entered the stage
         pos = np.arange(len(alive))   # position of each alive window inside stage_ids
         for k in range(m.K):
             c = t * m.K + k
