@@ -141,6 +141,9 @@ typedef struct {
   double gpu_ms;              /* device time of the call (HIP events)         */
   double scan_ms;             /* device time of the stage-0 scan kernel alone */
   double host_ms;             /* host post-processing (sort, NMS, relocation) */
+  long long scan_cart_n;      /* part of cart_gothrough_n done by the stage-0 scan kernel */
+  long long scan_patch_n;     /* windows the stage-0 scan kernel covered      */
+  int scan_launches;          /* launches of the stage-0 scan kernel (one per tiled level) */
 } jdaStats;
 
 typedef struct {
@@ -211,6 +214,16 @@ JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames
                               int width, int height, int minimum_size, int step,
                               double factor, double overlap, int nms,
                               jdaStats *stats, jdaResultD *out);
+
+/* Host-only helpers (no GPU needed): the two NMS variants and the model-stream
+ * size, exported so that they can be unit-tested and reused.
+ * jdaNmsC   : reference c/jda.c:237-316; bboxes are (x,y,size) triples; keep[i]
+ *             is set to 1/0; returns the number kept (scan order is preserved).
+ * jdaNmsCpp : reference src/jda/cascador.cpp:387-429; rects are (x,y,w,h);
+ *             picked[] receives indices in descending-score order; returns count. */
+JDA_API int jdaNmsC(const int *bboxes, const float *scores, int n, float overlap, unsigned char *keep);
+JDA_API int jdaNmsCpp(const int *rects, const double *scores, int n, double overlap, int *picked);
+JDA_API long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes);
 
 /* Per-window trace of the dialect-CPP cascade, like jdaTraceBatch but with the
  * fp64 state of reference Validate (src/jda/cascador.cpp:166-211): carts_n is

@@ -44,7 +44,8 @@ class jdaStats(C.Structure):
     _fields_ = [("patch_n", C.c_longlong), ("face_patch_n", C.c_longlong), ("nonface_patch_n", C.c_longlong),
                 ("cart_gothrough_n", C.c_longlong), ("stage_done_n", C.c_longlong * 16),
                 ("average_cart_n", C.c_double), ("gpu_ms", C.c_double), ("scan_ms", C.c_double),
-                ("host_ms", C.c_double)]
+                ("host_ms", C.c_double), ("scan_cart_n", C.c_longlong), ("scan_patch_n", C.c_longlong),
+                ("scan_launches", C.c_int)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_done_n"}
@@ -103,6 +104,10 @@ def _load():
     lib.jdaResultDRelease.argtypes = [jdaResultD]
     lib.jdaDetectBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
+    lib.jdaNmsCpp.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int)]
+    lib.jdaModelStreamBytes.restype = C.c_longlong
+    lib.jdaModelStreamBytes.argtypes = [C.c_int] * 5
     if hasattr(lib, "jdaTraceBatchCpp"):
         lib.jdaTraceBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double),
@@ -115,6 +120,7 @@ lib = _load()
 # reference-named entry points, callable exactly like the C functions
 jdaCascadorCreateDouble = lib.jdaCascadorCreateDouble
 jdaCascadorCreateFloat = lib.jdaCascadorCreateFloat
+jdaCascadorCreate = lib.jdaCascadorCreate
 jdaCascadorSerializeTo = lib.jdaCascadorSerializeTo
 jdaCascadorRelease = lib.jdaCascadorRelease
 jdaDetect = lib.jdaDetect
@@ -130,6 +136,29 @@ def count_windows(width, height, scale=1.25, min_size=40, max_size=-1):
     if lib.jdaCountWindows(width, height, scale, min_size, max_size, C.byref(n), C.byref(nl)) != 0:
         raise JdaError(last_error())
     return n.value, nl.value
+
+
+def nms_c(bboxes, scores, overlap=0.3):
+    """Host NMS of dialect C (reference c/jda.c:237-316): boolean keep mask in scan order."""
+    bboxes = np.ascontiguousarray(bboxes, np.int32).reshape(-1, 3)
+    scores = np.ascontiguousarray(scores, np.float32)
+    keep = np.zeros(len(scores), np.uint8)
+    if lib.jdaNmsC(bboxes.ctypes.data_as(C.POINTER(C.c_int)), scores.ctypes.data_as(C.POINTER(C.c_float)),
+                   len(scores), overlap, keep.ctypes.data_as(C.POINTER(C.c_ubyte))) < 0:
+        raise JdaError("jdaNmsC failed")
+    return keep.astype(bool)
+
+
+def nms_cpp(rects, scores, overlap=0.3):
+    """Host NMS of dialect CPP (reference cascador.cpp:387-429): picked indices, best first."""
+    rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+    scores = np.ascontiguousarray(scores, np.float64)
+    picked = np.zeros(max(len(scores), 1), np.int32)
+    n = lib.jdaNmsCpp(rects.ctypes.data_as(C.POINTER(C.c_int)), scores.ctypes.data_as(C.POINTER(C.c_double)),
+                      len(scores), overlap, picked.ctypes.data_as(C.POINTER(C.c_int)))
+    if n < 0:
+        raise JdaError("jdaNmsCpp failed")
+    return picked[:n].copy()
 
 
 def _u8(a):

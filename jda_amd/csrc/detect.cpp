@@ -379,9 +379,10 @@ struct TraceOut {              // host arrays, may be null
 };
 
 struct RunStats {
-  long long carts = 0, out = 0;
+  long long carts = 0, out = 0, carts_scan = 0, win_scan = 0;
   long long stage_done[kMaxStages] = {0};
   double gpu_ms = 0, scan_ms = 0;
+  int scan_launches = 0;
 };
 
 // Runs the device pipeline over n frames resident in device memory.
@@ -447,8 +448,10 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     // ---- stage 0 ----
     JDA_HIP(hipEventRecord(c->ev[1], st));
     if (pe->fast_scan) {
-      for (int l = 0; l < pe->hp.n_levels; l++)
+      for (int l = 0; l < pe->hp.n_levels; l++) {
         JDA_HIP(launch_scan<Real>(l, want_trace, pe->dp, pe->hp, m, pe->table, w, st));
+        if (pe->hp.lv[l].tile_class != kTileNone) rs->scan_launches++;
+      }
     }
     JDA_HIP(hipEventRecord(c->ev[2], st));
     if (!pe->fast_scan || pe->any_untiled) {
@@ -469,6 +472,8 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     (void)hipEventElapsedTime(&ms_scan, c->ev[1], c->ev[2]);
     rs->gpu_ms += ms_all; rs->scan_ms += ms_scan;
     rs->carts += (long long)c->h_counters[kCntCarts];
+    rs->carts_scan += (long long)c->h_counters[kCntCartsScan];
+    rs->win_scan += (long long)c->h_counters[kCntWinScan];
     for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntQueue0 + t];
     const size_t n_out = (size_t)c->h_counters[kCntOut];
     rs->out += (long long)n_out;
@@ -545,6 +550,7 @@ static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int 
   for (int t = 0; t < T && t < 16; t++) st->stage_done_n[t] = rs.stage_done[t];
   st->average_cart_n = st->nonface_patch_n > 0 ? (double)rs.carts / (double)st->nonface_patch_n : 0.0;
   st->gpu_ms = rs.gpu_ms; st->scan_ms = rs.scan_ms; st->host_ms = host_ms;
+  st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
 }
 
 static jdaResult empty_result(int landmark_n) {
@@ -828,6 +834,25 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   RunStats rs;
   if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs)) return -1;
   return 0;
+}
+
+int jdaNmsC(const int* bboxes, const float* scores, int n, float overlap, unsigned char* keep) {
+  if (n < 0 || (n > 0 && (!bboxes || !scores || !keep))) return -1;
+  std::vector<int> k = nms_dialect_c(bboxes, scores, n, overlap);
+  std::memset(keep, 0, (size_t)n);
+  for (int i : k) keep[i] = 1;
+  return (int)k.size();
+}
+
+int jdaNmsCpp(const int* rects, const double* scores, int n, double overlap, int* picked) {
+  if (n < 0 || (n > 0 && (!rects || !scores || !picked))) return -1;
+  std::vector<int> k = nms_dialect_cpp(rects, scores, n, overlap);
+  std::copy(k.begin(), k.end(), picked);
+  return (int)k.size();
+}
+
+long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
+  return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
 }
 
 void jdaResultDRelease(jdaResultD result) {

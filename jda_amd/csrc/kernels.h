@@ -101,8 +101,9 @@ enum Counter : int {
   kCntGeneric = kMaxStages,        // windows queued for the generic stage-0 walker
   kCntOut = kMaxStages + 1,        // final detections
   kCntCarts = kMaxStages + 2,      // carts evaluated (reference counting)
-  kCntOverflow = kMaxStages + 3,   // set if any queue overflowed
-  kCntTotal = kMaxStages + 4
+  kCntCartsScan = kMaxStages + 3,  // the part of kCntCarts evaluated by the LDS-tiled stage-0 scan
+  kCntWinScan = kMaxStages + 4,    // windows the stage-0 scan covered
+  kCntTotal = kMaxStages + 5
 };
 
 // ---- launchers (kernels.hip) ------------------------------------------------

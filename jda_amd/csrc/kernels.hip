@@ -408,7 +408,11 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
   unsigned v = my_carts;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0 && v) atomicAdd(&w.counters[kCntCarts], (unsigned long long)v);
+  if (lane == 0 && v) {
+    atomicAdd(&w.counters[kCntCarts], (unsigned long long)v);
+    atomicAdd(&w.counters[kCntCartsScan], (unsigned long long)v);
+  }
+  if (tid == 0) atomicAdd(&w.counters[kCntWinScan], (unsigned long long)(twe * the));
 }
 
 template <typename Real, int BLOCK, bool TRACE>

@@ -1,0 +1,83 @@
+"""Multi-GPU sharding of a batch of frames and the gather of detections.
+
+Frames (and windows) are independent, the model is read-only and small, so the
+path shards by frame with NO data-path collective.  The only
+exchange is at the end: every rank sends its (bbox, score, landmarks) tuples
+to rank 0 -- one all_gather of counts and one gather of padded rows.  On GPUs
+the process group's backend is "nccl", which is RCCL over xGMI on ROCm; the
+same code runs on "gloo" for the CPU tests.
+
+The reference has no distributed layer at all (its only parallelism is an
+OpenMP loop over FDDB folds, reference src/test.cpp:100); nothing here is a
+translation of reference code.
+"""
+import numpy as np
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of items owned by `rank` (floor(i*G/N) partition)."""
+    lo = (n_items * rank) // world
+    hi = (n_items * (rank + 1)) // world
+    return lo, hi
+
+
+def pack_detections(results, landmark_n, frame_offset=0):
+    """Per-frame result dicts -> one float32 matrix, a row per detection:
+    [frame, x, y, size, score, shape(2L)].  Integers up to 2^24 are exact in
+    float32; frames/coordinates beyond that would need the int path."""
+    dim = 2 * landmark_n
+    rows = []
+    for i, r in enumerate(results):
+        n = len(r["scores"])
+        if n == 0:
+            continue
+        m = np.empty((n, 5 + dim), np.float32)
+        m[:, 0] = frame_offset + i
+        m[:, 1:4] = r["bboxes"]
+        m[:, 4] = r["scores"]
+        m[:, 5:] = r["shapes"]
+        rows.append(m)
+    return np.concatenate(rows) if rows else np.zeros((0, 5 + dim), np.float32)
+
+
+def unpack_detections(mat, landmark_n):
+    """Inverse of pack_detections: {frame: result dict}."""
+    out = {}
+    if len(mat) == 0:
+        return out
+    frames = mat[:, 0].astype(np.int64)
+    for f in np.unique(frames):
+        sel = mat[frames == f]
+        out[int(f)] = dict(bboxes=sel[:, 1:4].astype(np.int32), scores=sel[:, 4].copy(), shapes=sel[:, 5:].copy())
+    return out
+
+
+def gather_detections(mat, device=None, group=None):
+    """Gather every rank's detection rows on rank 0 (None on the other ranks).
+
+    One all_gather of row counts, then one gather of rows padded to the maximum
+    count.  Payloads are KBs, so this is latency-bound; no reduction is needed
+    anywhere on this path.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mat
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    width = mat.shape[1]
+    cnt = torch.tensor([mat.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx, width), dtype=torch.float32, device=dev)
+    if mat.shape[0]:
+        pad[: mat.shape[0]] = torch.from_numpy(np.ascontiguousarray(mat)).to(dev)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    parts = [bufs[r][: counts[r]].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts) if parts else np.zeros((0, width), np.float32)

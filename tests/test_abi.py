@@ -1,0 +1,89 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol that
+include/jda.h declares, the header is valid C, and a plain C program can link it."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "jda.h")
+
+REFERENCE_SYMBOLS = ["jdaCascadorCreateDouble", "jdaCascadorCreateFloat", "jdaCascadorSerializeTo",
+                     "jdaCascadorRelease", "jdaDetect", "jdaResultRelease"]    # reference c/jda.h:31-68
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"JDA_API\s+[^;(]*?\b(jda\w+)\s*\(", src)
+
+
+def test_every_declared_symbol_is_exported(built):
+    from jda_amd import api
+    names = declared_symbols()
+    assert set(REFERENCE_SYMBOLS) <= set(names)
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(api.lib, n), n
+
+
+def test_header_is_plain_c_and_links(built, tmp_path):
+    """What a maintainer of the reference would do: compile a C caller against
+    include/jda.h and link libjda.so (no torch, no C++)."""
+    from jda_amd import api
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "jda.h"
+int main(void) {
+  void *c = jdaCascadorCreateDouble("/nonexistent.model");
+  if (c != NULL) return 1;                      /* NULL on a missing file, c/jda.c:487-488 */
+  long long n = 0; int levels = 0;
+  if (jdaCountWindows(640, 480, 1.25f, 40, -1, &n, &levels) != 0) return 2;
+  printf("%lld %d\n", n, levels);
+  jdaResult r = {0, 0, NULL, NULL, NULL};
+  jdaResultRelease(r);                          /* free(NULL) is fine */
+  jdaCascadorRelease(NULL);
+  return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(api.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-l:libjda.so", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["38245", "11"]
+
+
+def test_detect_without_gpu_fails_loudly(built, model_file):
+    """No CPU fallback: on a box without a HIP device the detect entry must raise, not
+    quietly compute elsewhere."""
+    import numpy as np
+    import torch
+    from jda_amd import api
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    p, _ = model_file((2, 8, 5, 3), 8)
+    c = api.Cascador(p)
+    with pytest.raises(api.JdaError, match="no usable HIP device"):
+        c.detect(np.zeros((64, 64), np.uint8))
+    with pytest.raises(api.JdaError):
+        c.detect_batch(np.zeros((2, 64, 64), np.uint8))
+    with pytest.raises(api.JdaError):
+        c.trace(np.zeros((64, 64), np.uint8))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under jda_amd/ may import or load it."""
+    pkg = os.path.join(ROOT, "jda_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "pyoracle" not in txt and "libjda_oracle" not in txt and "oracle/_ref" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+    deps = subprocess.run(["readelf", "-d", os.path.join(pkg, "libjda.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
