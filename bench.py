@@ -144,13 +144,16 @@ def main():
         casc = api.Cascador(mp, device=local_rank)
 
         def step(want_stats=False):
+            # N=1: the C call has materialised every jdaResult; they are counted and released.
+            # N>1: the tuples are also copied out, packed and gathered on rank 0 over RCCL.
             out = casc.detect_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th,
-                                           nms=True, stats=want_stats)
+                                           nms=True, stats=want_stats, keep_results=world > 1)
             res, st = out if want_stats else (out, None)
             if world > 1:
                 mat = jdist.pack_detections(res, L, frame_offset=rank * B)
                 jdist.gather_detections(mat, device=dev)
-            return res, st
+                return sum(len(r["scores"]) for r in res), st
+            return sum(res), st
 
         for _ in range(warmup):
             step()
@@ -159,9 +162,8 @@ def main():
         stats = []
         n_det = 0
         for _ in range(steps):
-            res, st = step(True)
+            n_det, st = step(True)
             stats.append(st)
-            n_det = sum(len(r["scores"]) for r in res)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:

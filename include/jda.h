@@ -144,6 +144,7 @@ typedef struct {
   long long scan_cart_n;      /* part of cart_gothrough_n done by the stage-0 scan kernel */
   long long scan_patch_n;     /* windows the stage-0 scan kernel covered      */
   int scan_launches;          /* launches of the stage-0 scan kernel (one per tiled level) */
+  long long handoff_n;        /* windows handed from the scan to the finishing kernel (incl. untiled levels) */
 } jdaStats;
 
 typedef struct {

@@ -171,7 +171,7 @@ static bool ensure_device(Cascador* c) {
   JDA_HIP(hipSetDevice(c->device));
   JDA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& ev : c->ev) JDA_HIP(hipEventCreate(&ev));
-  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntTotal, hipHostMallocDefault));
+  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipHostMallocDefault));
   c->dev_init = true;
   return true;
 }
@@ -246,17 +246,15 @@ static bool upload_model(Cascador* c) {
 
 // ---------------------------------------------------------------- tiling of levels
 
-// Chooses, per level, how many windows share one LDS pixel tile.  See DESIGN.md
-// "LDS tiles": 256-thread workgroups share a tile of up to 512 windows while
-// the tile stays small enough for several workgroups per CU; one-wave
-// workgroups take the mid-size windows; the largest windows go to the generic
-// walker, which reads pixels through L1/L2.
+// Chooses, per level, whether k_scan covers it and how many windows share one
+// LDS pixel tile (DESIGN.md "LDS tiles").  A 256-thread workgroup shares a tile
+// of up to 512 windows; levels whose tile would not leave room for several
+// workgroups per CU (large windows, few of them) skip the scan and enter
+// k_finish at cart 0.
 static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan, PlanEntry* pe) {
-  static const int wide_opts[][2] = {{32, 16}, {16, 16}};
-  static const int narrow_opts[][2] = {{8, 8}, {8, 4}, {4, 4}};
-  const int wide_budget = (int)env_ll("JDA_PIX_WIDE", 48 * 1024);
-  const int wide_pref = (int)env_ll("JDA_PIX_WIDE_PREF", 24 * 1024);
-  const int narrow_budget = (int)env_ll("JDA_PIX_NARROW", 56 * 1024);
+  static const int opts[][2] = {{32, 16}, {16, 16}};
+  const int budget = (int)env_ll("JDA_PIX_MAX", 48 * 1024);     // hard cap of a pixel tile
+  const int pref = (int)env_ll("JDA_PIX_PREF", 24 * 1024);      // prefer the biggest tile under this
   DevPlan& hp = pe->hp;
   hp.n_levels = (int)sp.levels.size();
   hp.width = sp.width; hp.height = sp.height; hp.windows = (int)sp.windows;
@@ -266,25 +264,26 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
     const Level& s = sp.levels[i];
     DevLevel& d = hp.lv[i];
     d.win = s.win; d.step = s.step; d.nx = s.nx; d.ny = s.ny; d.base = (int)s.base;
-    d.tile_class = kTileNone; d.tw = d.th = 1; d.tiles_x = d.tiles_y = 0; d.pitch = 0; d.s0_table = 0;
-    auto try_tile = [&](int tw, int th, int budget, int cls) {
-      if (d.tile_class != kTileNone) return;
+    d.tiled = 0; d.tw = d.th = 1; d.tiles_x = d.tiles_y = 0; d.pitch = 0; d.s0_table = 0;
+    auto try_tile = [&](int tw, int th, int limit) {
+      if (d.tiled) return;
       const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
       int pitch = (pw + 3 + 3) & ~3;
       if ((pitch & 127) == 0) pitch += 4;     // keep tile rows off a 32-bank multiple
       const long long bytes = (long long)pitch * ph;
-      if (bytes > budget || bytes > 65535) return;
-      d.tile_class = cls; d.tw = tw; d.th = th; d.pitch = pitch;
+      if (bytes > limit || bytes > 65535) return;   // S0Node offsets are 16-bit
+      d.tiled = 1; d.tw = tw; d.th = th; d.pitch = pitch;
     };
-    if (fast_scan) {
-      const long long cnt = (long long)s.nx * s.ny;
-      if (cnt >= 256) {
-        for (auto& o : wide_opts) try_tile(o[0], o[1], wide_pref, kTileWide);
-        try_tile(16, 16, wide_budget, kTileWide);
-      }
-      for (auto& o : narrow_opts) try_tile(o[0], o[1], narrow_budget, kTileNarrow);
+    if (fast_scan && (long long)s.nx * s.ny >= 128) {
+      for (auto& o : opts) try_tile(o[0], o[1], pref);
+      try_tile(16, 16, budget);
     }
-    if (d.tile_class == kTileNone) { pe->any_untiled = true; continue; }
+    // no LDS tile: k_scan reads the frame through L1/L2 if its offsets fit the packed node
+    if (fast_scan && !d.tiled && env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
+        (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits)) {
+      d.tiled = 2; d.tw = 32; d.th = 16; d.pitch = sp.width;
+    }
+    if (!d.tiled) { pe->any_untiled = true; continue; }
     d.tiles_x = (s.nx + d.tw - 1) / d.tw;
     d.tiles_y = (s.ny + d.th - 1) / d.th;
     d.s0_table = table;
@@ -309,7 +308,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
   size_t entries = 0;
   for (int i = 0; i < pe.hp.n_levels; i++)
-    if (pe.hp.lv[i].tile_class != kTileNone) entries += n0;
+    if (pe.hp.lv[i].tiled) entries += n0;
   if (entries) {
     JDA_HIP(hipMalloc((void**)&pe.table, entries * sizeof(S0Node)));
     const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
@@ -325,8 +324,8 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
 
 template <typename Real>
 static size_t bytes_per_window(int dim, bool trace) {
-  size_t b = 2 * (4 + sizeof(Real) + 4) + 2 * (size_t)dim * sizeof(Real) + 4 + 4;
-  if (trace) b += 2 * 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
+  size_t b = (4 + sizeof(Real) + 4) + (4 + sizeof(Real) + (size_t)dim * sizeof(Real));
+  if (trace) b += 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
   return b;
 }
 
@@ -337,16 +336,14 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
   if (ws.cap >= cap && (ws.trace || !trace) && ws.dim == dim) return true;
   auto carve = [&](Carver& cv) {
     WorkT<Real>& w = ws.w;
-    for (int p = 0; p < 2; p++) {
-      w.q_gid[p] = cv.take<uint32_t>(cap);
-      w.q_score[p] = cv.take<Real>(cap);
-      w.q_src[p] = cv.take<uint32_t>(cap);
-      w.q_hash[p] = trace ? cv.take<uint32_t>(cap) : nullptr;
-      w.shape[p] = cv.take<Real>(cap * dim);
-    }
-    w.qg_gid = cv.take<uint32_t>(cap);
-    w.out_slot = cv.take<uint32_t>(cap);
-    w.counters = cv.take<unsigned long long>(kCntTotal);
+    w.q_gid = cv.take<uint32_t>(cap);
+    w.q_score = cv.take<Real>(cap);
+    w.q_kstart = cv.take<uint32_t>(cap);
+    w.q_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
+    w.out_gid = cv.take<uint32_t>(cap);
+    w.out_score = cv.take<Real>(cap);
+    w.out_shape = cv.take<Real>(cap * dim);
+    w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
     if (trace) {
       w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
       w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
@@ -379,7 +376,7 @@ struct TraceOut {              // host arrays, may be null
 };
 
 struct RunStats {
-  long long carts = 0, out = 0, carts_scan = 0, win_scan = 0;
+  long long carts = 0, out = 0, carts_scan = 0, win_scan = 0, tail = 0;
   long long stage_done[kMaxStages] = {0};
   double gpu_ms = 0, scan_ms = 0;
   int scan_launches = 0;
@@ -431,7 +428,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     w.half = nullptr; w.quarter = nullptr; w.half_stride = w.quarter_stride = 0;
     w.hw = hw; w.hh = hh; w.qw = qw; w.qh = qh;
     JDA_HIP(hipEventRecord(c->ev[0], st));
-    JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntTotal, st));
+    JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntShards * kCntStride, st));
     if (multi) {
       uint8_t* hbuf = (uint8_t*)ws.pyr.p;
       const size_t hs = ((size_t)hw * hh + 255) & ~(size_t)255, qs = ((size_t)qw * qh + 255) & ~(size_t)255;
@@ -445,28 +442,32 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
       JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
     }
-    // ---- stage 0 ----
+    // ---- windows k_scan does not cover enter the hand-off queue at cart 0 ----
+    if (!pe->fast_scan || pe->any_untiled) JDA_HIP(launch_enqueue<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
+    // ---- stage-0 scan: first `handoff` carts, one launch per tiled level ----
     JDA_HIP(hipEventRecord(c->ev[1], st));
     if (pe->fast_scan) {
+      const int handoff = (int)env_ll("JDA_HANDOFF", 128);
+      bool any_glb = false;
       for (int l = 0; l < pe->hp.n_levels; l++) {
-        JDA_HIP(launch_scan<Real>(l, want_trace, pe->dp, pe->hp, m, pe->table, w, st));
-        if (pe->hp.lv[l].tile_class != kTileNone) rs->scan_launches++;
+        if (pe->hp.lv[l].tiled == 2) any_glb = true;
+        if (pe->hp.lv[l].tiled != 1) continue;
+        JDA_HIP(launch_scan<Real>(l, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+        rs->scan_launches++;
+      }
+      if (any_glb) {
+        JDA_HIP(launch_scan<Real>(-1, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+        rs->scan_launches++;
       }
     }
     JDA_HIP(hipEventRecord(c->ev[2], st));
-    if (!pe->fast_scan || pe->any_untiled) {
-      JDA_HIP(launch_enqueue_generic<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
-      JDA_HIP(launch_walk<Real>(dialect, want_trace, 0, pe->dp, m, w, st));
-    }
-    // ---- regression + later stages ----
-    for (int t = 0; t < T; t++) {
-      if (t > 0) JDA_HIP(launch_walk<Real>(dialect, want_trace, t, pe->dp, m, w, st));
-      JDA_HIP(launch_update<Real>(dialect, want_trace, t, apply_th, th, pe->dp, m, w, st));
-    }
-    JDA_HIP(launch_pack<Real>(w, T, dim, st));
+    // ---- every survivor: remaining carts, regressions, later stages, final cut ----
+    JDA_HIP(launch_finish<Real>(want_trace, apply_th, th, pe->dp, m, w, st));
     JDA_HIP(hipEventRecord(c->ev[3], st));
-    JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntTotal, hipMemcpyDeviceToHost, st));
+    JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
     JDA_HIP(hipStreamSynchronize(st));
+    for (int sh = 1; sh < kCntShards; sh++)     // fold the counter shards into shard 0
+      for (int i = 0; i < kCntTotal; i++) c->h_counters[i] += c->h_counters[sh * kCntStride + i];
     float ms_all = 0, ms_scan = 0;
     (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[3]);
     (void)hipEventElapsedTime(&ms_scan, c->ev[1], c->ev[2]);
@@ -474,18 +475,18 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     rs->carts += (long long)c->h_counters[kCntCarts];
     rs->carts_scan += (long long)c->h_counters[kCntCartsScan];
     rs->win_scan += (long long)c->h_counters[kCntWinScan];
-    for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntQueue0 + t];
+    for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntStage0 + t];
+    rs->tail += (long long)c->h_counters[kCntTail];
     const size_t n_out = (size_t)c->h_counters[kCntOut];
     rs->out += (long long)n_out;
     if (n_out > cap) { fail("internal: more detections than windows"); return false; }
     // ---- detections of this pass -> host, sorted back into scan order ----
     if (n_out && dets) {
-      const int po = T & 1;
       std::vector<uint32_t> g(n_out);
       std::vector<Real> s(n_out), sh(n_out * dim);
-      JDA_HIP(hipMemcpyAsync(g.data(), w.q_gid[po], n_out * 4, hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipMemcpyAsync(s.data(), w.q_score[po], n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipMemcpyAsync(sh.data(), w.shape[po], n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(g.data(), w.out_gid, n_out * 4, hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(s.data(), w.out_score, n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(sh.data(), w.out_shape, n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
       JDA_HIP(hipStreamSynchronize(st));
       std::vector<uint32_t> ord(n_out);
       std::iota(ord.begin(), ord.end(), 0u);
@@ -528,7 +529,8 @@ static WinRef locate(const ScanPlan& sp, uint32_t gid) {
   return r;
 }
 
-static void parallel_for(int n, const std::function<void(int)>& fn) {
+static void parallel_for(int n, const std::function<void(int)>& fn, bool small_job = false) {
+  if (small_job) { for (int i = 0; i < n; i++) fn(i); return; }   // thread start-up would cost more than the work
   unsigned hwc = std::thread::hardware_concurrency();
   int nt = (int)std::min<unsigned>(hwc ? hwc : 4, 32);
   nt = std::min(nt, n);
@@ -551,6 +553,7 @@ static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int 
   st->average_cart_n = st->nonface_patch_n > 0 ? (double)rs.carts / (double)st->nonface_patch_n : 0.0;
   st->gpu_ms = rs.gpu_ms; st->scan_ms = rs.scan_ms; st->host_ms = host_ms;
   st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
+  st->handoff_n = rs.tail;
 }
 
 static jdaResult empty_result(int landmark_n) {
@@ -620,7 +623,7 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
-  });
+  }, dets.gid.size() < 20000);
   fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, now_ms() - t0);
   return 0;
 }
@@ -915,7 +918,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(double));
       relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
     }
-  });
+  }, dets.gid.size() < 20000);
   fill_stats(stats, rs, sp.windows * n, c->hm.T, now_ms() - t0);
   return 0;
 }

@@ -4,6 +4,13 @@
 // a *cart* is one depth-D tree of the cascade; a *stage* is K carts followed
 // by one global shape regression.  A window's *gid* is
 // frame*windows_per_frame + its scan-order index inside the frame.
+//
+// Two kernels carry the cascade (DESIGN.md "pipeline"):
+//   k_scan    lane = window, LDS pixel tile, the first `handoff` carts of
+//             stage 0, survivors compacted by ballot/prefix-sum
+//   k_finish  wave = window: lanes = carts for the tree walks of a stage,
+//             lanes = shape coordinates for the regression gather; runs a
+//             survivor through every remaining cart, stage and the final cut
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -15,17 +22,11 @@ namespace jda {
 constexpr int kMaxLevels = 64;
 constexpr int kMaxStages = 16;
 
-// How the stage-0 scan covers one pyramid level.
-enum TileClass : int {
-  kTileWide = 0,    // 256-thread workgroups, up to 512 windows share one LDS tile
-  kTileNarrow = 1,  // 64-thread workgroups (one wave), up to 64 windows per LDS tile
-  kTileNone = 2     // window too large for an LDS tile: generic walker reads HBM/L2
-};
-
 struct DevLevel {
   int win, step, nx, ny;
   int base;              // first window of the level inside a frame (scan order)
-  int tile_class;        // TileClass
+  int tiled;             // 1: k_scan with an LDS pixel tile; 2: k_scan reading pixels through L1/L2
+                         // (windows too large for a tile); 0: k_finish takes its windows from cart 0
   int tw, th;            // windows per tile in x / y
   int tiles_x, tiles_y;
   int pitch;             // LDS bytes per tile row
@@ -39,8 +40,8 @@ struct DevPlan {
   DevLevel lv[kMaxLevels];
 };
 
-// Split node as the generic walker reads it: 32 bytes, two 16-byte loads
-// (the reference's jdaNode is also 32 bytes, c/jda.c:114-127).
+// Split node as k_finish reads it: 32 bytes, two 16-byte loads (the
+// reference's jdaNode is also 32 bytes, c/jda.c:114-127).
 struct NodeF {
   int scale;
   int lm1x2, lm2x2;   // landmark index * 2, like c/jda.c:521-523
@@ -54,13 +55,17 @@ struct NodeD {         // dialect CPP: fp64 offsets (already passed through the 
   double o1x, o1y, o2x, o2y;
 };
 
-// Stage-0 node with its pixel offsets resolved for one level (see DESIGN.md
+// Stage-0 node with its pixel offsets resolved for one level (DESIGN.md
 // "stage-0 hoist"): in stage 0 every window holds the mean shape, so the
 // feature coordinates depend only on (node, window size).
+// Two packings of the same 8 bytes:
+//   tiled == 1 : lo = off1 | off2 << 16 (byte offsets inside the LDS tile), hi = th in [-256,255]
+//   tiled == 2 : off1 : 21 | off2 : 21 | th + 256 : 10 (byte offsets inside the frame, row pitch = width)
 struct S0Node {
-  uint32_t offs;   // off1 | off2 << 16, byte offsets from the window origin inside the LDS tile
-  int32_t th;      // feature threshold clamped to [-256, 255]
+  uint32_t lo;
+  uint32_t hi;
 };
+constexpr int kS0GlobalOffBits = 21;
 
 template <typename Real>
 struct DevModelT {
@@ -75,36 +80,38 @@ struct DevModelT {
   const Real* mean_shape;  // [dim]
 };
 
-// One pipeline's device buffers for a sub-batch of frames.
+// Device buffers of one pass over a sub-batch of frames.
 template <typename Real>
 struct WorkT {
-  // frames
   const uint8_t* frames; size_t frame_stride; int n_frames;
-  const uint8_t* half; size_t half_stride; int hw, hh;        // pyramid, only for multi-scale models
+  const uint8_t* half; size_t half_stride; int hw, hh;        // pyramid images, only for multi-scale models
   const uint8_t* quarter; size_t quarter_stride; int qw, qh;
-  // survivor queues, ping-pong by stage parity
-  uint32_t* q_gid[2]; Real* q_score[2]; uint32_t* q_src[2]; uint32_t* q_hash[2];
-  Real* shape[2];          // [cap][dim]
-  // queue of windows the stage-0 scan does not cover (generic walker, t = 0)
-  uint32_t* qg_gid;
-  // counters (device): see Counter enum
-  unsigned long long* counters;
-  // slots (in queue T-1) of the windows that pass the final threshold
-  uint32_t* out_slot;
-  // trace (optional, all NULL when off)
+  // hand-off queue k_scan -> k_finish (plus the windows k_scan does not cover)
+  uint32_t* q_gid; Real* q_score; uint32_t* q_hash; uint32_t* q_kstart;
+  unsigned long long* counters;                                // see Counter
+  // final detections: windows that passed every cart and the final threshold
+  uint32_t* out_gid; Real* out_score; Real* out_shape;
+  // per-window trace (all null when off), indexed by gid
   int* tr_carts; Real* tr_score; uint32_t* tr_hash; Real* tr_shape;
-  unsigned cap;            // queue capacity (windows)
+  unsigned cap;                                                // capacity of every per-window array
 };
 
+// Work counters live in kCntShards copies, one 256-byte line apart, so that the
+// workgroups of a launch do not serialise on one L2 atomic unit; the host sums
+// the shards.  kCntTail / kCntOut are queue allocators and exist once (shard 0).
+constexpr int kCntShards = 64;
+constexpr int kCntStride = 32;   // 64-bit words per shard
+
 enum Counter : int {
-  kCntQueue0 = 0,          // kCntQueue0 + t : windows that passed every cart of stage t
-  kCntGeneric = kMaxStages,        // windows queued for the generic stage-0 walker
+  kCntStage0 = 0,                  // kCntStage0 + t : windows that completed stage t
+  kCntTail = kMaxStages,           // length of the hand-off queue
   kCntOut = kMaxStages + 1,        // final detections
-  kCntCarts = kMaxStages + 2,      // carts evaluated (reference counting)
-  kCntCartsScan = kMaxStages + 3,  // the part of kCntCarts evaluated by the LDS-tiled stage-0 scan
-  kCntWinScan = kMaxStages + 4,    // windows the stage-0 scan covered
+  kCntCarts = kMaxStages + 2,      // carts evaluated, reference counting (Validate's n)
+  kCntCartsScan = kMaxStages + 3,  // carts evaluated inside k_scan
+  kCntWinScan = kMaxStages + 4,    // windows k_scan covered
   kCntTotal = kMaxStages + 5
 };
+static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
 // ---- launchers (kernels.hip) ------------------------------------------------
 
@@ -118,33 +125,25 @@ hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan&
                               const void* nodes, const void* mean_shape, int K, int node_n,
                               S0Node* table, hipStream_t stream);
 
-// Table/LDS sizing shared by host planner and kernels.
-int scan_chunk_max(int node_n, int leaf_n);       // carts per LDS table chunk
-size_t scan_lds_bytes(int pix_bytes, int node_n, int leaf_n, int real_bytes, bool trace, int tile_class);
+int scan_handoff_cap(int node_n, int leaf_n, int real_bytes);   // most carts k_scan can stage in LDS
+size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real_bytes, bool trace);
 
-// Stage-0 scan of ONE tiled level (h_plan.lv[level].tile_class is wide or narrow).
+// Windows of untiled levels (or of every level) -> head of the hand-off queue, k_start = 0.
 template <typename Real>
-hipError_t launch_scan(int level, bool trace, const DevPlan* d_plan, const DevPlan& h_plan,
+hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
+                          const WorkT<Real>& w, hipStream_t stream);
+
+// Stage-0 scan, carts [0, handoff) of stage 0: level >= 0 = that LDS-tiled level (tiled == 1);
+// level < 0 = every global-pixel level (tiled == 2) in one launch.
+template <typename Real>
+hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan, const DevPlan& h_plan,
                        const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,
                        hipStream_t stream);
 
+// Everything after the hand-off, for every queued window.
 template <typename Real>
-hipError_t launch_enqueue_generic(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
-                                  const WorkT<Real>& w, hipStream_t stream);
-
-// Generic walker for stage t: reads queue `in_counter`, appends survivors to queue kCntQueue0+t.
-template <typename Real>
-hipError_t launch_walk(int dialect, bool trace, int t, const DevPlan* d_plan, const DevModelT<Real>& m,
-                       const WorkT<Real>& w, hipStream_t stream);
-
-// Stage regression for the survivors of stage t (+ final threshold/emit when t == T-1).
-template <typename Real>
-hipError_t launch_update(int dialect, bool trace, int t, bool apply_final_th, Real final_th,
-                         const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
-                         hipStream_t stream);
-
-template <typename Real>
-hipError_t launch_pack(const WorkT<Real>& w, int T, int dim, hipStream_t stream);
+hipError_t launch_finish(bool trace, bool apply_final_th, Real final_th, const DevPlan* d_plan,
+                         const DevModelT<Real>& m, const WorkT<Real>& w, hipStream_t stream);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

@@ -6,16 +6,18 @@
 //
 //   k_resize        bilinear pyramid image        reference c/jda.c:203-230
 //   k_prep_stage0   stage-0 feature offsets per level (hoisted c/jda.c:370-389)
-//   k_scan          stage-0 cascade walk, LDS tile, lane = window, survivors
-//                   compacted by ballot/prefix-sum every chunk of carts
+//   k_scan          first `handoff` carts of stage 0: LDS pixel tile, lane = window,
+//                   survivors compacted by ballot/prefix-sum every chunk of carts
 //                                                  reference c/jda.c:357-402
-//   k_walk          generic walker (any stage; per-window shape; HBM/L2 pixels)
-//                                                  c/jda.c:364-402, cascador.cpp:166-192
-//   k_update        stage regression: W-row gather in cart order
-//                                                  c/jda.c:404-411, btcart.cpp:407-424
-//   k_pack          final detections -> contiguous rows
+//   k_finish        wave = window, for every survivor: lanes = carts for a stage's
+//                   tree walks (c/jda.c:366-400, cart.cpp:392-404), the score
+//                   recurrence replayed in cart order (c/jda.c:395-399), then
+//                   lanes = shape coordinates for the regression gather in cart
+//                   order (c/jda.c:404-411, btcart.cpp:407-424), final cut
+//                   (c/jda.c:414) and emit
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 
 #include "kernels.h"
@@ -67,6 +69,10 @@ __device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
   return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+__device__ __forceinline__ unsigned long long* shard_counter(unsigned long long* counters, int idx) {
+  return counters + (size_t)(blockIdx.x % kCntShards) * kCntStride + idx;
 }
 
 // level of a frame-local window index (uniform or per-lane; levels are few)
@@ -129,7 +135,7 @@ __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename D
                               S0Node* __restrict__ table) {
   const int l = blockIdx.y;
   const DevLevel lv = plan->lv[l];
-  if (lv.tile_class == kTileNone) return;
+  if (!lv.tiled) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K * node_n) return;
   const typename DL::Node nd = nodes[i];  // stage 0 occupies the first K*node_n nodes
@@ -138,10 +144,18 @@ __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename D
   int y1 = clamp_win(DL::coord(mean_shape[nd.lm1x2 + 1], nd.o1y, win), win);
   int x2 = clamp_win(DL::coord(mean_shape[nd.lm2x2], nd.o2x, win), win);
   int y2 = clamp_win(DL::coord(mean_shape[nd.lm2x2 + 1], nd.o2y, win), win);
-  S0Node o;
-  o.offs = (uint32_t)(y1 * lv.pitch + x1) | ((uint32_t)(y2 * lv.pitch + x2) << 16);
   // feature is a difference of two bytes: thresholds beyond [-256,255] behave like the ends
-  o.th = nd.th < -256 ? -256 : (nd.th > 255 ? 255 : nd.th);
+  const int th = nd.th < -256 ? -256 : (nd.th > 255 ? 255 : nd.th);
+  S0Node o;
+  if (lv.tiled == 1) {
+    o.lo = (uint32_t)(y1 * lv.pitch + x1) | ((uint32_t)(y2 * lv.pitch + x2) << 16);
+    o.hi = (uint32_t)th;
+  } else {
+    const unsigned long long v = (unsigned long long)(uint32_t)(y1 * lv.pitch + x1) |
+                                 ((unsigned long long)(uint32_t)(y2 * lv.pitch + x2) << kS0GlobalOffBits) |
+                                 ((unsigned long long)(uint32_t)(th + 256) << (2 * kS0GlobalOffBits));
+    o.lo = (uint32_t)v; o.hi = (uint32_t)(v >> 32);
+  }
   table[lv.s0_table + i] = o;
 }
 
@@ -162,25 +176,34 @@ hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan&
 // stage-0 scan
 // =============================================================================
 
-int scan_chunk_max(int node_n, int leaf_n) {
-  // LDS table chunk: at most 8 KiB of S0Node + leaf scores (sized for f64)
-  int c = 8192 / (node_n * (int)sizeof(S0Node) + leaf_n * 8);
-  if (c > 64) c = 64;
-  if (c < 2) c = 2;
-  return c & ~1;
+// Carts of stage 0 that k_scan evaluates before handing survivors to k_finish:
+// the tables of all of them (nodes, leaf scores, cart parameters) are staged in
+// LDS once per workgroup, so the count is capped by a 16 KiB table budget.
+int scan_handoff_cap(int node_n, int leaf_n, int real_bytes) {
+  const int per_cart = node_n * (int)sizeof(S0Node) + leaf_n * real_bytes + 4 * real_bytes;
+  int c = (16 * 1024) / per_cart;
+  if (c < 8) c = 8;
+  return c & ~7;
 }
 
 namespace {
 
+template <typename Real>
+struct CartPar {          // per-cart parameters as k_scan reads them from LDS
+  Real th, mean, std;
+  Real norm;              // != 0 where (mean,std) != (0,1)
+};
+
 template <typename Real, bool TRACE>
 struct ScanLds {
   // byte offsets inside dynamic LDS
-  int pix, nodes, leaf, q_widx, q_score, q_hash, misc, total;
-  __host__ __device__ ScanLds(int pix_budget, int chunk_max, int node_n, int leaf_n, int m_max) {
+  int pix, nodes, leaf, par, q_widx, q_score, q_hash, misc, total;
+  __host__ __device__ ScanLds(int pix_bytes, int carts, int node_n, int leaf_n, int m_max) {
     int o = 0;
-    pix = o; o += (pix_budget + 15) & ~15;
-    nodes = o; o += chunk_max * node_n * (int)sizeof(S0Node); o = (o + 15) & ~15;
-    leaf = o; o += chunk_max * leaf_n * (int)sizeof(Real); o = (o + 15) & ~15;
+    pix = o; o += (pix_bytes + 15) & ~15;
+    nodes = o; o += carts * node_n * (int)sizeof(S0Node); o = (o + 15) & ~15;
+    leaf = o; o += carts * leaf_n * (int)sizeof(Real); o = (o + 15) & ~15;
+    par = o; o += carts * (int)sizeof(CartPar<Real>);
     q_score = o; o += 2 * m_max * (int)sizeof(Real);
     q_widx = o; o += 2 * m_max * 2; o = (o + 15) & ~15;
     q_hash = o; if (TRACE) o += 2 * m_max * 4;
@@ -191,17 +214,17 @@ struct ScanLds {
 
 }  // namespace
 
-size_t scan_lds_bytes(int pix_bytes, int node_n, int leaf_n, int real_bytes, bool trace, int tile_class) {
-  const int cm = scan_chunk_max(node_n, leaf_n);
-  const int mm = tile_class == kTileWide ? 512 : 64;
-  if (real_bytes == 4) return trace ? ScanLds<float, true>(pix_bytes, cm, node_n, leaf_n, mm).total
-                                    : ScanLds<float, false>(pix_bytes, cm, node_n, leaf_n, mm).total;
-  return trace ? ScanLds<double, true>(pix_bytes, cm, node_n, leaf_n, mm).total
-               : ScanLds<double, false>(pix_bytes, cm, node_n, leaf_n, mm).total;
+size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real_bytes, bool trace) {
+  if (real_bytes == 4) return trace ? ScanLds<float, true>(pix_bytes, carts, node_n, leaf_n, 512).total
+                                    : ScanLds<float, false>(pix_bytes, carts, node_n, leaf_n, 512).total;
+  return trace ? ScanLds<double, true>(pix_bytes, carts, node_n, leaf_n, 512).total
+               : ScanLds<double, false>(pix_bytes, carts, node_n, leaf_n, 512).total;
 }
 
-// One cart of stage 0 for one window: D-1 dependent (node, 2 pixels) LDS reads.
-template <int DEPTH>
+// One cart of stage 0 for one window: D-1 dependent (node, 2 pixels) reads.  The
+// node table is in LDS; pixels come from the LDS tile (GLB = false) or from the
+// frame through L1/L2 (GLB = true).
+template <int DEPTH, bool GLB>
 __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const uint8_t* __restrict__ pix,
                                          int base, int depth_rt) {
   int node = 0;
@@ -209,24 +232,54 @@ __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const u
 #pragma unroll
   for (int d = 0; d < levels; d++) {
     const S0Node r = tbl[node];
-    const int a = pix[base + (int)(r.offs & 0xffffu)];
-    const int b = pix[base + (int)(r.offs >> 16)];
-    node = 2 * node + ((a - b <= r.th) ? 1 : 2);     // c/jda.c:391-393
+    if (!GLB) {
+      const int a = pix[base + (int)(r.lo & 0xffffu)];
+      const int b = pix[base + (int)(r.lo >> 16)];
+      node = 2 * node + ((a - b <= (int)r.hi) ? 1 : 2);     // c/jda.c:391-393
+    } else {
+      const uint32_t o1 = r.lo & 0x1fffffu;
+      const uint32_t o2 = __builtin_amdgcn_alignbit(r.hi, r.lo, 21) & 0x1fffffu;
+      const int a = pix[base + (int)o1];
+      const int b = pix[base + (int)o2];
+      node = 2 * node + ((a - b + 256 <= (int)(r.hi >> 10)) ? 1 : 2);
+    }
   }
   return node;
 }
 
-template <typename Real, int BLOCK, int DEPTH, bool TRACE>
-__global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
-                                                const S0Node* __restrict__ table, WorkT<Real> w,
-                                                int level, int pix_budget, int chunk_max) {
+// global -> LDS copy of n elements by the whole workgroup with all loads of a
+// thread in flight before its first store (one memory latency, not one per element)
+template <typename T, int BLOCK, int UNROLL>
+__device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __restrict__ src, int n, int tid) {
+  for (int i0 = 0; i0 < n; i0 += BLOCK * UNROLL) {
+    T v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i = i0 + u * BLOCK + tid;
+      if (i < n) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i = i0 + u * BLOCK + tid;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
+template <typename Real, int DEPTH, bool TRACE, bool GLB>
+__global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
+                                              const S0Node* __restrict__ table, WorkT<Real> w,
+                                              int level, int tiles_total, int pix_bytes, int handoff) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int M_MAX = BLOCK == 256 ? 512 : 64;
-  const int node_n = m.node_n, leaf_n = m.leaf_n, K = m.K;
-  const ScanLds<Real, TRACE> L(pix_budget, chunk_max, node_n, leaf_n, M_MAX);
-  uint8_t* pix = lds + L.pix;
+  constexpr int BLOCK = 256;
+  constexpr int M_MAX = 512;
+  const int node_n = m.node_n, leaf_n = m.leaf_n;
+  const int K = min(m.K, handoff);     // this kernel stops here and hands survivors to k_finish
+  const ScanLds<Real, TRACE> L(pix_bytes, K, node_n, leaf_n, M_MAX);
+  const uint8_t* pix = lds + L.pix;
   S0Node* t_nodes = (S0Node*)(lds + L.nodes);
   Real* t_leaf = (Real*)(lds + L.leaf);
+  CartPar<Real>* t_par = (CartPar<Real>*)(lds + L.par);
   Real* q_score = (Real*)(lds + L.q_score);
   uint16_t* q_widx = (uint16_t*)(lds + L.q_widx);
   unsigned* q_hash = (unsigned*)(lds + L.q_hash);
@@ -234,18 +287,32 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  const int wv = tid >> 6;
 
   // XCD-aware block -> (frame, tile): blocks b, b+8, b+16.. land on one XCD
   // (MI355X dispatches block b to XCD b % 8), so the 8 frames of a group each
   // stay inside one XCD's L2.
-  const DevLevel lv = plan->lv[level];
-  const int tiles_per_frame = lv.tiles_x * lv.tiles_y;
+  // level < 0: one launch covers every level of this pixel mode (GLB levels all
+  // need the same LDS); tiles_total = their tiles per frame.
+  int tiles_per_frame = tiles_total;
+  if (level >= 0) tiles_per_frame = plan->lv[level].tiles_x * plan->lv[level].tiles_y;
   const int b = blockIdx.x;
   const int group = b / (8 * tiles_per_frame);
   const int r = b - group * (8 * tiles_per_frame);
   const int frame = group * 8 + (r & 7);
-  const int trel = r >> 3;
+  int trel = r >> 3;
   if (frame >= w.n_frames) return;
+  if (level < 0) {
+    level = 0;
+    for (int i = 0; i < plan->n_levels; i++) {
+      const DevLevel* c = &plan->lv[i];
+      if (c->tiled != (GLB ? 2 : 1)) continue;
+      const int cnt = c->tiles_x * c->tiles_y;
+      if (trel < cnt) { level = i; break; }
+      trel -= cnt;
+    }
+  }
+  const DevLevel lv = plan->lv[level];
   const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
   const int wx0 = tx * lv.tw, wy0 = ty * lv.th;                 // first window of the tile
   const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
@@ -253,29 +320,53 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
   const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
   const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
 
-  // ---- stage the pixel tile: coalesced dword rows when alignment allows ----
+  // ---- stage the pixel tile: coalesced dword rows, 8 rows in flight per wave ----
   const int W = plan->width;
   const bool al4 = ((W & 3) == 0) && ((w.frame_stride & 3) == 0) && ((((uintptr_t)w.frames) & 3) == 0);
-  const int x0a = al4 ? (x0 & ~3) : x0;
+  const int x0a = (al4 && !GLB) ? (x0 & ~3) : x0;
   const int xshift = x0 - x0a;
-  {
-    constexpr int NW = BLOCK / 64;
-    const int wv = tid >> 6;
-    if (al4) {
-      const int ndw = (xshift + pw + 3) >> 2;
-      for (int rr = wv; rr < ph; rr += NW) {
-        const uint32_t* g = (const uint32_t*)(img + (size_t)(y0 + rr) * W + x0a);
-        uint32_t* d = (uint32_t*)(pix + rr * lv.pitch);
-        for (int c = lane; c < ndw; c += 64) d[c] = g[c];
+  if (GLB) {
+    pix = img + (size_t)y0 * W + x0;          // window origins are offsets from the tile origin in the frame
+  } else if (al4) {
+    const int ndw = (xshift + pw + 3) >> 2;
+    const int w4 = W >> 2, p4 = lv.pitch >> 2;
+    const uint32_t* g = (const uint32_t*)(img + (size_t)y0 * W + x0a);
+    uint32_t* d = (uint32_t*)(lds + L.pix);
+    for (int c0 = 0; c0 < ndw; c0 += 64) {
+      const int c = c0 + lane;
+      const bool cok = c < ndw;
+      for (int r0 = wv * 8; r0 < ph; r0 += 32) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * w4 + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) d[(r0 + u) * p4 + c] = v[u];
       }
-    } else {
-      for (int rr = wv; rr < ph; rr += NW) {
-        const uint8_t* g = img + (size_t)(y0 + rr) * W + x0;
-        uint8_t* d = pix + rr * lv.pitch;
-        for (int c = lane; c < pw; c += 64) d[c] = g[c];
+    }
+  } else {
+    const uint8_t* g = img + (size_t)y0 * W + x0;
+    for (int c0 = 0; c0 < pw; c0 += 64) {
+      const int c = c0 + lane;
+      const bool cok = c < pw;
+      for (int r0 = wv * 8; r0 < ph; r0 += 32) {
+        uint8_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * W + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) (lds + L.pix)[(r0 + u) * lv.pitch + c] = v[u];
       }
     }
   }
+  // ---- stage the tables of carts [0, K): resolved nodes, leaf scores, cart parameters ----
+  stage_to_lds<S0Node, BLOCK, 4>(t_nodes, table + lv.s0_table, K * node_n, tid);
+  stage_to_lds<Real, BLOCK, 4>(t_leaf, m.leaf, K * leaf_n, tid);
+  for (int k = tid; k < K; k += BLOCK) {
+    CartPar<Real> p;
+    p.th = m.cth[k]; p.mean = m.cmean[k]; p.std = m.cstd[k]; p.norm = m.cnorm[k] ? (Real)1 : (Real)0;
+    t_par[k] = p;
+  }
+  if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+  __syncthreads();
 
   const int n_tile = lv.tw * lv.th;      // phase 0 enumerates the full tile; edge windows are filtered
   int n_items = n_tile;
@@ -283,19 +374,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
   unsigned my_carts = 0;
   const int gid0 = frame * plan->windows + lv.base;
 
+  // Phases: carts [0,8) [8,16) [16,32) [32,64) [64,128) ...; after each phase the
+  // survivors are compacted so that later phases run on full waves.
   for (int c0 = 0; c0 < K;) {
-    int len = c0 < 8 ? 8 : c0;
-    if (len > chunk_max) len = chunk_max;
-    const int c1 = min(K, c0 + len);
-    // ---- stage this chunk's tables ----
-    {
-      const S0Node* src = table + lv.s0_table + c0 * node_n;
-      for (int i = tid; i < (c1 - c0) * node_n; i += BLOCK) t_nodes[i] = src[i];
-      const Real* ls = m.leaf + c0 * leaf_n;
-      for (int i = tid; i < (c1 - c0) * leaf_n; i += BLOCK) t_leaf[i] = ls[i];
-      if (tid == 0) misc[cur ^ 1] = 0;
-    }
-    __syncthreads();
+    const int c1 = min(K, c0 + (c0 < 8 ? 8 : c0));
 
     for (int i0 = 0; i0 < n_items; i0 += BLOCK) {
       const int i = i0 + tid;
@@ -320,20 +402,21 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
       for (; k + 1 < c1; k += 2) {
         if (__ballot(alive) == 0ull) break;
         if (alive) {
-          const S0Node* tn = t_nodes + (k - c0) * node_n;
-          const int na = scan_tree<DEPTH>(tn, pix, base, m.D);
-          const int nb = scan_tree<DEPTH>(tn + node_n, pix, base, m.D);
+          const S0Node* tn = t_nodes + k * node_n;
+          const int na = scan_tree<DEPTH, GLB>(tn, pix, base, m.D);
+          const int nb = scan_tree<DEPTH, GLB>(tn + node_n, pix, base, m.D);
           const int la = na - node_n, lb = nb - node_n;
-          Real s = score + t_leaf[(k - c0) * leaf_n + la];                // c/jda.c:396
-          if (m.cnorm[k]) s = (s - m.cmean[k]) / m.cstd[k];               // c/jda.c:397
+          const CartPar<Real> pa = t_par[k], pb = t_par[k + 1];
+          Real s = score + t_leaf[k * leaf_n + la];                       // c/jda.c:396
+          if (pa.norm != (Real)0) s = (s - pa.mean) / pa.std;             // c/jda.c:397
           if (TRACE) hash = fnv_step(hash, la);
-          bool dead = s < m.cth[k];                                       // c/jda.c:399
+          bool dead = s < pa.th;                                          // c/jda.c:399
           int kd = k;
           if (!dead) {
-            s = s + t_leaf[(k + 1 - c0) * leaf_n + lb];
-            if (m.cnorm[k + 1]) s = (s - m.cmean[k + 1]) / m.cstd[k + 1];
+            s = s + t_leaf[(k + 1) * leaf_n + lb];
+            if (pb.norm != (Real)0) s = (s - pb.mean) / pb.std;
             if (TRACE) hash = fnv_step(hash, lb);
-            dead = s < m.cth[k + 1];
+            dead = s < pb.th;
             kd = k + 1;
           }
           score = s;
@@ -349,13 +432,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
       }
       if (k < c1 && k + 1 >= c1) {   // odd tail cart
         if (alive) {
-          const int na = scan_tree<DEPTH>(t_nodes + (k - c0) * node_n, pix, base, m.D);
+          const int na = scan_tree<DEPTH, GLB>(t_nodes + k * node_n, pix, base, m.D);
           const int la = na - node_n;
-          Real s = score + t_leaf[(k - c0) * leaf_n + la];
-          if (m.cnorm[k]) s = (s - m.cmean[k]) / m.cstd[k];
+          const CartPar<Real> pa = t_par[k];
+          Real s = score + t_leaf[k * leaf_n + la];
+          if (pa.norm != (Real)0) s = (s - pa.mean) / pa.std;
           if (TRACE) hash = fnv_step(hash, la);
           score = s;
-          if (s < m.cth[k]) {
+          if (s < pa.th) {
             alive = false;
             my_carts += k + 1;
             if (TRACE) {
@@ -384,11 +468,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
     n_items = misc[cur];
     c0 = c1;
     if (n_items == 0) break;
+    if (tid == 0) misc[cur ^ 1] = 0;     // next phase's output counter; readers of it are past the barrier
+    __syncthreads();
   }
 
-  // ---- survivors of all K carts of stage 0 -> global queue 0 ----
+  // ---- windows still alive after cart K-1 -> hand-off queue (k_finish continues at cart K) ----
+  unsigned handed = 0;
   if (n_items > 0) {
-    if (tid == 0) misc[2] = (int)atomicAdd(&w.counters[kCntQueue0], (unsigned long long)n_items);
+    if (tid == 0) misc[2] = (int)atomicAdd(&w.counters[kCntTail], (unsigned long long)n_items);
     __syncthreads();
     const unsigned gbase = (unsigned)misc[2];
     for (int i = tid; i < n_items; i += BLOCK) {
@@ -396,104 +483,128 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const unsigned slot = gbase + i;
       if (slot < w.cap) {
-        w.q_gid[0][slot] = (uint32_t)(gid0 + (wy0 + wy) * lv.nx + wx0 + wx);
-        w.q_score[0][slot] = q_score[cur * M_MAX + i];
-        w.q_src[0][slot] = 0;
-        if (TRACE) w.q_hash[0][slot] = q_hash[cur * M_MAX + i];
+        w.q_gid[slot] = (uint32_t)(gid0 + (wy0 + wy) * lv.nx + wx0 + wx);
+        w.q_score[slot] = q_score[cur * M_MAX + i];
+        w.q_kstart[slot] = (uint32_t)K;
+        if (TRACE) w.q_hash[slot] = q_hash[cur * M_MAX + i];
       }
-      my_carts += K;
+      handed += K;
     }
   }
-  // ---- carts-evaluated counter (DetectionStatisic.cart_gothrough_n) ----
-  unsigned v = my_carts;
+  // ---- counters: rejected windows are final (DetectionStatisic.cart_gothrough_n);
+  //      handed-off windows are counted by k_finish when they terminate.  One
+  //      atomic set per workgroup, on this workgroup's counter shard. ----
+  unsigned v = my_carts, hv = handed;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0 && v) {
-    atomicAdd(&w.counters[kCntCarts], (unsigned long long)v);
-    atomicAdd(&w.counters[kCntCartsScan], (unsigned long long)v);
+  for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); hv += __shfl_xor(hv, o); }
+  __syncthreads();
+  if (lane == 0) { misc[4 + wv] = (int)v; misc[8 + wv] = (int)hv; }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long sv = (unsigned)misc[4] + (unsigned)misc[5] + (unsigned)misc[6] + (unsigned)misc[7];
+    const unsigned long long sh = (unsigned)misc[8] + (unsigned)misc[9] + (unsigned)misc[10] + (unsigned)misc[11];
+    if (sv) atomicAdd(shard_counter(w.counters, kCntCarts), sv);
+    atomicAdd(shard_counter(w.counters, kCntCartsScan), sv + sh);
+    atomicAdd(shard_counter(w.counters, kCntWinScan), (unsigned long long)(twe * the));
   }
-  if (tid == 0) atomicAdd(&w.counters[kCntWinScan], (unsigned long long)(twe * the));
 }
 
-template <typename Real, int BLOCK, bool TRACE>
+template <typename Real, bool TRACE>
 static hipError_t launch_scan_depth(const DevPlan* d_plan, const DevPlan& h_plan, const DevModelT<Real>& m,
-                                    const S0Node* table, const WorkT<Real>& w, int level, hipStream_t stream) {
-  const DevLevel& lv = h_plan.lv[level];
-  const int cm = scan_chunk_max(m.node_n, m.leaf_n);
-  const int pix_bytes = lv.pitch * (lv.win + (lv.th - 1) * lv.step);
-  const ScanLds<Real, TRACE> L(pix_bytes, cm, m.node_n, m.leaf_n, BLOCK == 256 ? 512 : 64);
+                                    const S0Node* table, const WorkT<Real>& w, int level, int handoff,
+                                    hipStream_t stream) {
+  // level >= 0: that LDS-tiled level; level < 0: every global-pixel level in one launch
+  const bool glb = level < 0;
+  int tiles = 0, pix_bytes = 0;
+  if (glb) {
+    for (int i = 0; i < h_plan.n_levels; i++)
+      if (h_plan.lv[i].tiled == 2) tiles += h_plan.lv[i].tiles_x * h_plan.lv[i].tiles_y;
+  } else {
+    const DevLevel& lv = h_plan.lv[level];
+    tiles = lv.tiles_x * lv.tiles_y;
+    pix_bytes = lv.pitch * (lv.win + (lv.th - 1) * lv.step);
+  }
+  if (tiles == 0) return hipSuccess;
+  handoff = std::min(handoff, scan_handoff_cap(m.node_n, m.leaf_n, (int)sizeof(Real)));
+  const int carts = std::min(m.K, handoff);
+  const ScanLds<Real, TRACE> L(pix_bytes, carts, m.node_n, m.leaf_n, 512);
   const int groups = (w.n_frames + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * lv.tiles_x * lv.tiles_y)), block(BLOCK);
+  dim3 grid((unsigned)(groups * 8 * tiles)), block(256);
   auto go = [&](auto kern) {
     if (L.total > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level, pix_bytes, cm);
+    hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level, tiles, pix_bytes, handoff);
   };
-  if (m.D == 4) go(k_scan<Real, BLOCK, 4, TRACE>);
-  else if (m.D == 6) go(k_scan<Real, BLOCK, 6, TRACE>);
-  else go(k_scan<Real, BLOCK, 0, TRACE>);
+  if (glb) {
+    if (m.D == 4) go(k_scan<Real, 4, TRACE, true>);
+    else if (m.D == 6) go(k_scan<Real, 6, TRACE, true>);
+    else go(k_scan<Real, 0, TRACE, true>);
+  } else {
+    if (m.D == 4) go(k_scan<Real, 4, TRACE, false>);
+    else if (m.D == 6) go(k_scan<Real, 6, TRACE, false>);
+    else go(k_scan<Real, 0, TRACE, false>);
+  }
   return hipGetLastError();
 }
 
 template <typename Real>
-hipError_t launch_scan(int level, bool trace, const DevPlan* d_plan, const DevPlan& h_plan,
+hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan, const DevPlan& h_plan,
                        const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,
                        hipStream_t stream) {
-  const int tile_class = h_plan.lv[level].tile_class;
-  if (tile_class == kTileNone || w.n_frames == 0) return hipSuccess;
-  if (tile_class == kTileWide) {
-    return trace ? launch_scan_depth<Real, 256, true>(d_plan, h_plan, m, table, w, level, stream)
-                 : launch_scan_depth<Real, 256, false>(d_plan, h_plan, m, table, w, level, stream);
-  }
-  return trace ? launch_scan_depth<Real, 64, true>(d_plan, h_plan, m, table, w, level, stream)
-               : launch_scan_depth<Real, 64, false>(d_plan, h_plan, m, table, w, level, stream);
+  if (w.n_frames == 0) return hipSuccess;
+  if (level >= 0 && h_plan.lv[level].tiled != 1) return hipSuccess;
+  return trace ? launch_scan_depth<Real, true>(d_plan, h_plan, m, table, w, level, handoff, stream)
+               : launch_scan_depth<Real, false>(d_plan, h_plan, m, table, w, level, handoff, stream);
 }
 
-template hipError_t launch_scan<float>(int, bool, const DevPlan*, const DevPlan&, const DevModelT<float>&,
+template hipError_t launch_scan<float>(int, bool, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
                                        const S0Node*, const WorkT<float>&, hipStream_t);
-template hipError_t launch_scan<double>(int, bool, const DevPlan*, const DevPlan&, const DevModelT<double>&,
+template hipError_t launch_scan<double>(int, bool, int, const DevPlan*, const DevPlan&, const DevModelT<double>&,
                                         const S0Node*, const WorkT<double>&, hipStream_t);
 
 // =============================================================================
-// queue of windows the scan does not cover
+// windows k_scan does not cover -> head of the hand-off queue (k_start = 0)
 // =============================================================================
 
 template <typename Real>
-__global__ void k_enqueue_generic(const DevPlan* __restrict__ plan, WorkT<Real> w, int per_frame, int all_levels) {
+__global__ void k_enqueue(const DevPlan* __restrict__ plan, WorkT<Real> w, int per_frame, int all_levels) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)per_frame * w.n_frames;
-  if (idx == 0) w.counters[kCntGeneric] = (unsigned long long)total;
+  if (idx == 0) w.counters[kCntTail] = (unsigned long long)total;   // k_scan appends behind these
   if (idx >= total) return;
   const int frame = (int)(idx / per_frame);
   int r = (int)(idx - (long long)frame * per_frame);
   int wid = -1;
   for (int i = 0; i < plan->n_levels; i++) {
     const DevLevel* c = &plan->lv[i];
-    if (!all_levels && c->tile_class != kTileNone) continue;
+    if (!all_levels && c->tiled) continue;
     const int cnt = c->nx * c->ny;
     if (wid < 0 && r < cnt) wid = c->base + r;
     r -= cnt;
   }
-  w.qg_gid[idx] = (uint32_t)(frame * plan->windows + wid);
+  w.q_gid[idx] = (uint32_t)(frame * plan->windows + wid);
+  w.q_score[idx] = (Real)0;
+  w.q_kstart[idx] = 0u;
+  if (w.q_hash) w.q_hash[idx] = kFnvSeed;
 }
 
 template <typename Real>
-hipError_t launch_enqueue_generic(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
-                                  const WorkT<Real>& w, hipStream_t stream) {
+hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
+                          const WorkT<Real>& w, hipStream_t stream) {
   long long per_frame = 0;
   for (int i = 0; i < h_plan.n_levels; i++)
-    if (all_levels || h_plan.lv[i].tile_class == kTileNone) per_frame += (long long)h_plan.lv[i].nx * h_plan.lv[i].ny;
+    if (all_levels || !h_plan.lv[i].tiled) per_frame += (long long)h_plan.lv[i].nx * h_plan.lv[i].ny;
   const long long total = per_frame * w.n_frames;
   if (total == 0) return hipSuccess;
   dim3 block(256), grid((unsigned)((total + 255) / 256));
-  hipLaunchKernelGGL(k_enqueue_generic<Real>, grid, block, 0, stream, d_plan, w, (int)per_frame, all_levels ? 1 : 0);
+  hipLaunchKernelGGL(k_enqueue<Real>, grid, block, 0, stream, d_plan, w, (int)per_frame, all_levels ? 1 : 0);
   return hipGetLastError();
 }
-template hipError_t launch_enqueue_generic<float>(const DevPlan*, const DevPlan&, bool, const WorkT<float>&, hipStream_t);
-template hipError_t launch_enqueue_generic<double>(const DevPlan*, const DevPlan&, bool, const WorkT<double>&, hipStream_t);
+template hipError_t launch_enqueue<float>(const DevPlan*, const DevPlan&, bool, const WorkT<float>&, hipStream_t);
+template hipError_t launch_enqueue<double>(const DevPlan*, const DevPlan&, bool, const WorkT<double>&, hipStream_t);
 
 // =============================================================================
-// generic walker: one stage, lane = window, per-window shape in LDS
+// k_finish: one wave per surviving window
 // =============================================================================
 
 namespace {
@@ -503,13 +614,14 @@ struct View {
   const uint8_t* img; int w, h, ox, oy;
 };
 
+// Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
+// data.cpp:18-58).
 template <typename DL>
-__device__ __forceinline__ int node_feature(const typename DL::Node& nd, const typename DL::Real* sh, int sh_stride,
-                                            int sh_lane, int win, const View& v0, const View& v1, const View& v2,
-                                            bool multi) {
+__device__ __forceinline__ int node_feature(const typename DL::Node& nd, const typename DL::Real* sh, int win,
+                                            const View& v0, const View& v1, const View& v2, bool multi) {
   using Real = typename DL::Real;
-  const Real s1x = sh[nd.lm1x2 * sh_stride + sh_lane], s1y = sh[(nd.lm1x2 + 1) * sh_stride + sh_lane];
-  const Real s2x = sh[nd.lm2x2 * sh_stride + sh_lane], s2y = sh[(nd.lm2x2 + 1) * sh_stride + sh_lane];
+  const Real s1x = sh[nd.lm1x2], s1y = sh[nd.lm1x2 + 1];
+  const Real s2x = sh[nd.lm2x2], s2y = sh[nd.lm2x2 + 1];
   const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
   const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
   const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win);
@@ -549,193 +661,111 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   }
 }
 
+// value held by lane j, as a wave-uniform scalar
+__device__ __forceinline__ int rl(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float rl(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ double rl(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
 }  // namespace
 
 template <typename DL, bool TRACE>
-__global__ __launch_bounds__(64) void k_walk(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
-                                             WorkT<typename DL::Real> w, int t, int multi_i, float inv_sqrt2) {
-  using Real = typename DL::Real;
-  using Node = typename DL::Node;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  Real* sh = (Real*)lds;  // [dim][64]
-  const bool multi = multi_i != 0;
-  const int lane = threadIdx.x;
-  const int K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
-  const int pin = (t + 1) & 1, pout = t & 1;   // parity of queue t-1 / queue t
-  const unsigned n_in = (unsigned)(t == 0 ? w.counters[kCntGeneric] : w.counters[kCntQueue0 + t - 1]);
-  const uint32_t* in_gid = t == 0 ? w.qg_gid : w.q_gid[pin];
-  const Node* nodes = (const Node*)m.nodes + (size_t)t * K * node_n;
-  const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
-  const Real* cth = m.cth + (size_t)t * K;
-  const Real* cmean = m.cmean + (size_t)t * K;
-  const Real* cstd = m.cstd + (size_t)t * K;
-  const uint8_t* cnorm = m.cnorm + (size_t)t * K;
-  unsigned my_carts = 0;
-
-  for (unsigned s0 = blockIdx.x * 64u; s0 < n_in; s0 += gridDim.x * 64u) {
-    const unsigned slot = s0 + lane;
-    bool alive = slot < n_in;
-    uint32_t gid = 0;
-    Real score = 0;
-    unsigned hash = kFnvSeed;
-    int win = 24;
-    View v0{}, v1{}, v2{};
-    if (alive) {
-      gid = in_gid[slot];
-      if (t > 0) { score = w.q_score[pin][slot]; if (TRACE) hash = w.q_hash[pin][slot]; }
-      decode_window<Real>(plan, w, gid, inv_sqrt2, &win, &v0, &v1, &v2, multi);
-    }
-    __syncthreads();   // previous iteration's readers are done with sh
-    if (alive) {
-      if (t == 0) {
-        for (int d = 0; d < dim; d++) sh[d * 64 + lane] = m.mean_shape[d];
-      } else {
-        const Real* src = w.shape[pin] + (size_t)slot * dim;
-        for (int d = 0; d < dim; d++) sh[d * 64 + lane] = src[d];
-      }
-    }
-    __syncthreads();
-
-    for (int k = 0; k < K; k++) {
-      if (__ballot(alive) == 0ull) break;
-      if (alive) {
-        int node = 0;
-        for (int d = 0; d < m.D - 1; d++) {
-          const Node nd = nodes[(size_t)k * node_n + node];
-          const int feat = node_feature<DL>(nd, sh, 64, lane, win, v0, v1, v2, multi);
-          node = 2 * node + (feat <= nd.th ? 1 : 2);
-        }
-        const int lf = node - node_n;
-        Real s = score + leaf_tab[(size_t)k * leaf_n + lf];
-        if (cnorm[k]) s = (s - cmean[k]) / cstd[k];
-        score = s;
-        if (TRACE) hash = fnv_step(hash, lf);
-        if (s < cth[k]) {
-          alive = false;
-          my_carts += k + 1;
-          if (TRACE) {
-            w.tr_carts[gid] = t * K + k + 1; w.tr_score[gid] = s; w.tr_hash[gid] = hash;
-            if (t > 0)
-              for (int d = 0; d < dim; d++) w.tr_shape[(size_t)gid * dim + d] = sh[d * 64 + lane];
-          }
-        }
-      }
-    }
-    if (alive) my_carts += K;
-    // survivors -> queue t (one atomic per wave, order inside the wave kept)
-    const unsigned long long mask = __ballot(alive);
-    if (mask) {
-      unsigned long long wbase = 0;
-      if (lane == 0) wbase = atomicAdd(&w.counters[kCntQueue0 + t], (unsigned long long)__popcll(mask));
-      wbase = __shfl(wbase, 0);
-      if (alive) {
-        const unsigned o = (unsigned)wbase + __popcll(mask & lanes_below(lane));
-        if (o < w.cap) {
-          w.q_gid[pout][o] = gid; w.q_score[pout][o] = score; w.q_src[pout][o] = slot;
-          if (TRACE) w.q_hash[pout][o] = hash;
-        }
-      }
-    }
-  }
-  unsigned v = my_carts;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane == 0 && v) atomicAdd(&w.counters[kCntCarts], (unsigned long long)v);
-}
-
-template <typename Real>
-hipError_t launch_walk(int dialect, bool trace, int t, const DevPlan* d_plan, const DevModelT<Real>& m,
-                       const WorkT<Real>& w, hipStream_t stream);
-
-namespace {
-template <typename DL>
-hipError_t launch_walk_impl(bool trace, int t, const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
-                            const WorkT<typename DL::Real>& w, hipStream_t stream) {
-  const size_t lds = (size_t)m.dim * 64 * sizeof(typename DL::Real);
-  const int multi = (w.half != nullptr) ? 1 : 0;
-  const float r = 1.f / sqrtf(2.f);
-  unsigned blocks = (w.cap + 63) / 64;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  if (blocks == 0) blocks = 1;
-  auto go = [&](auto kern) {
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, t, multi, r);
-  };
-  if (trace) go(k_walk<DL, true>); else go(k_walk<DL, false>);
-  return hipGetLastError();
-}
-}  // namespace
-
-template <>
-hipError_t launch_walk<float>(int dialect, bool trace, int t, const DevPlan* d_plan, const DevModelT<float>& m,
-                              const WorkT<float>& w, hipStream_t stream) {
-  (void)dialect;
-  return launch_walk_impl<DialectC>(trace, t, d_plan, m, w, stream);
-}
-template <>
-hipError_t launch_walk<double>(int dialect, bool trace, int t, const DevPlan* d_plan, const DevModelT<double>& m,
-                               const WorkT<double>& w, hipStream_t stream) {
-  (void)dialect;
-  return launch_walk_impl<DialectCPP>(trace, t, d_plan, m, w, stream);
-}
-
-// =============================================================================
-// stage regression (+ final threshold)
-// =============================================================================
-
-template <typename DL, bool TRACE>
-__global__ __launch_bounds__(256) void k_update(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
-                                                WorkT<typename DL::Real> w, int t, int multi_i, float inv_sqrt2,
-                                                int is_last, int apply_th, typename DL::Real final_th,
-                                                uint32_t* __restrict__ out_slot) {
+__global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
+                                               WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
+                                               int apply_th, typename DL::Real final_th) {
   using Real = typename DL::Real;
   using Node = typename DL::Node;
   constexpr bool kCpp = sizeof(Real) == 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int T = m.T, K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
   const int dim_pad = (dim + 1) & ~1;
-  Real* sh = (Real*)lds + wv * dim_pad;                                     // [4][dim]
-  uint16_t* lbf = (uint16_t*)(lds + 4 * dim_pad * sizeof(Real)) + wv * ((K + 7) & ~7);  // [4][K]
+  Real* sh = (Real*)lds;                                     // current shape        [dim_pad]
+  Real* sh2 = sh + dim_pad;                                  // shape being built    [dim_pad]
+  uint16_t* lbf = (uint16_t*)(sh2 + dim_pad);                // leaf of every cart   [K]
+  int* stage_cnt = (int*)(lbf + ((K + 7) & ~7));             // per-block stage counters
   const bool multi = multi_i != 0;
-  const int pcur = t & 1, pprev = (t + 1) & 1;
-  const unsigned n = (unsigned)w.counters[kCntQueue0 + t];
-  const Node* nodes = (const Node*)m.nodes + (size_t)t * K * node_n;
-  const Real* wt = m.w + (size_t)t * K * leaf_n * dim;
+  const int lane = threadIdx.x;
+  if (lane < kMaxStages) stage_cnt[lane] = 0;
+  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  unsigned long long carts_acc = 0;
 
-  for (unsigned s0 = blockIdx.x * 4u; s0 < n; s0 += gridDim.x * 4u) {
-    const unsigned slot = s0 + wv;
-    const bool has = slot < n;     // wave-uniform
-    uint32_t gid = 0;
-    int win = 24;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t gid = w.q_gid[i];
+    Real score = w.q_score[i];
+    const int kstart = (int)w.q_kstart[i];
+    unsigned hash = TRACE ? w.q_hash[i] : kFnvSeed;
+    int win;
     View v0{}, v1{}, v2{};
+    decode_window<Real>(plan, w, gid, inv_sqrt2, &win, &v0, &v1, &v2, multi);
+    __syncthreads();                       // previous window's readers are done with sh
+    for (int d = lane; d < dim; d += 64) sh[d] = m.mean_shape[d];
     __syncthreads();
-    if (has) {
-      gid = w.q_gid[pcur][slot];
-      decode_window<Real>(plan, w, gid, inv_sqrt2, &win, &v0, &v1, &v2, multi);
-      const Real* src = t == 0 ? m.mean_shape : w.shape[pprev] + (size_t)w.q_src[pcur][slot] * dim;
-      for (int d = lane; d < dim; d += 64) sh[d] = src[d];
-    }
-    __syncthreads();
-    if (has) {
-      // leaves of this stage, one cart per lane (shape is fixed during a stage)
-      for (int k = lane; k < K; k += 64) {
+
+    bool alive = true;
+    int carts_n = 0;
+    for (int t = 0; t < T; t++) {
+      const Node* nodes = (const Node*)m.nodes + (size_t)t * K * node_n;
+      const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
+      const Real* cth = m.cth + (size_t)t * K;
+      const Real* cmean = m.cmean + (size_t)t * K;
+      const Real* cstd = m.cstd + (size_t)t * K;
+      const uint8_t* cnorm = m.cnorm + (size_t)t * K;
+      const int kbeg = t == 0 ? min(kstart, K) : 0;   // first cart whose score is still to be applied
+      const int k_first = kbeg & ~63;
+
+      // ---- tree walks, 64 carts at a time (the shape is fixed during a stage, so
+      //      the trees of a stage are independent); then the score recurrence of
+      //      c/jda.c:395-399 replayed strictly in cart order ----
+      for (int k0 = k_first; k0 < K && alive; k0 += 64) {
+        const int k = k0 + lane;
+        int lf = 0, norm_k = 0;
+        Real ls = 0, th_k = 0, mean_k = 0, std_k = 1;
+        if (k < K) {
+          int node = 0;
+          for (int d = 0; d < m.D - 1; d++) {
+            const Node nd = nodes[(size_t)k * node_n + node];
+            const int feat = node_feature<DL>(nd, sh, win, v0, v1, v2, multi);
+            node = 2 * node + (feat <= nd.th ? 1 : 2);       // c/jda.c:392-393
+          }
+          lf = node - node_n;
+          lbf[k] = (uint16_t)lf;
+          ls = leaf_tab[(size_t)k * leaf_n + lf];
+          th_k = cth[k];
+          norm_k = cnorm[k];
+          if (norm_k) { mean_k = cmean[k]; std_k = cstd[k]; }
+        }
+        const unsigned long long normmask = __ballot(norm_k != 0);
+        const int jend = min(64, K - k0);
+        for (int j = max(0, kbeg - k0); j < jend; j++) {
+          Real s = score + rl(ls, j);                                   // c/jda.c:396
+          if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);   // c/jda.c:397
+          score = s;
+          if (TRACE) hash = fnv_step(hash, rl(lf, j));
+          if (s < rl(th_k, j)) { alive = false; carts_n = t * K + k0 + j + 1; break; }   // c/jda.c:399
+        }
+      }
+      if (!alive) break;
+      // leaves of the carts k_scan already scored (needed only now that the stage is passed)
+      for (int k = lane; k < k_first; k += 64) {
         int node = 0;
         for (int d = 0; d < m.D - 1; d++) {
           const Node nd = nodes[(size_t)k * node_n + node];
-          const int feat = node_feature<DL>(nd, sh, 1, 0, win, v0, v1, v2, multi);
+          const int feat = node_feature<DL>(nd, sh, win, v0, v1, v2, multi);
           node = 2 * node + (feat <= nd.th ? 1 : 2);
         }
         lbf[k] = (uint16_t)(node - node_n);
       }
-    }
-    __syncthreads();
-    if (has) {
-      const Real score = w.q_score[pcur][slot];
-      const bool emit = is_last && !(apply_th && score < final_th);   // c/jda.c:414
+      __syncthreads();
+      // ---- stage regression: K weight rows added strictly in cart order
+      //      (c/jda.c:404-411); dialect CPP sums the delta from zero and adds it
+      //      once (btcart.cpp:407-424) ----
+      const Real* wt = m.w + (size_t)t * K * leaf_n * dim;
       for (int d = lane; d < dim; d += 64) {
-        // rows added strictly in cart order (c/jda.c:404-411). Dialect CPP sums
-        // the delta from zero and adds it once (btcart.cpp:407-424).
         Real acc = kCpp ? (Real)0 : sh[d];
         const Real* col = wt + d;
         int k = 0;
@@ -754,85 +784,66 @@ __global__ __launch_bounds__(256) void k_update(const DevPlan* __restrict__ plan
           acc = (d & 1) ? one * (zero * other + one * acc) : one * (one * acc + zero * other);
           acc = sh[d] + acc;
         }
-        w.shape[pcur][(size_t)slot * dim + d] = acc;
-        if (TRACE && is_last) w.tr_shape[(size_t)gid * dim + d] = acc;
+        sh2[d] = acc;
       }
-      if (lane == 0) {
-        if (TRACE && is_last) { w.tr_carts[gid] = m.T * K; w.tr_score[gid] = score; w.tr_hash[gid] = w.q_hash[pcur][slot]; }
-        if (emit) {
-          const unsigned o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
-          if (o < w.cap) out_slot[o] = slot;
-        }
+      __syncthreads();
+      { Real* tmp = sh; sh = sh2; sh2 = tmp; }
+      if (lane == 0) stage_cnt[t] += 1;
+    }
+    if (alive) carts_n = T * K;
+    carts_acc += (unsigned long long)carts_n;
+
+    if (TRACE) {
+      if (lane == 0) { w.tr_carts[gid] = carts_n; w.tr_score[gid] = score; w.tr_hash[gid] = hash; }
+      for (int d = lane; d < dim; d += 64) w.tr_shape[(size_t)gid * dim + d] = sh[d];
+    }
+    if (alive && !(apply_th && score < final_th)) {            // c/jda.c:414
+      unsigned o = 0;
+      if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
+      o = (unsigned)__shfl((int)o, 0);
+      if (o < w.cap) {
+        if (lane == 0) { w.out_gid[o] = gid; w.out_score[o] = score; }
+        for (int d = lane; d < dim; d += 64) w.out_shape[(size_t)o * dim + d] = sh[d];
       }
     }
   }
+  __syncthreads();
+  if (lane < T && stage_cnt[lane]) atomicAdd(shard_counter(w.counters, kCntStage0 + lane), (unsigned long long)stage_cnt[lane]);
+  if (lane == 0 && carts_acc) atomicAdd(shard_counter(w.counters, kCntCarts), carts_acc);
 }
 
 namespace {
 template <typename DL>
-hipError_t launch_update_impl(bool trace, int t, bool apply_th, typename DL::Real th, const DevPlan* d_plan,
+hipError_t launch_finish_impl(bool trace, bool apply_th, typename DL::Real th, const DevPlan* d_plan,
                               const DevModelT<typename DL::Real>& m, const WorkT<typename DL::Real>& w,
                               hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
-  const size_t lds = 4 * (size_t)dim_pad * sizeof(Real) + 4 * (size_t)((m.K + 7) & ~7) * 2;
+  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 7) & ~7) * 2 + kMaxStages * sizeof(int);
   const int multi = (w.half != nullptr) ? 1 : 0;
   const float r = 1.f / sqrtf(2.f);
-  unsigned blocks = (w.cap + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  unsigned blocks = w.cap;
+  if (blocks > 256u * 64u) blocks = 256u * 64u;
   if (blocks == 0) blocks = 1;
-  const int is_last = (t == m.T - 1) ? 1 : 0;
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, d_plan, m, w, t, multi, r, is_last,
-                       apply_th ? 1 : 0, th, w.out_slot);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, apply_th ? 1 : 0, th);
   };
-  if (trace) go(k_update<DL, true>); else go(k_update<DL, false>);
+  if (trace) go(k_finish<DL, true>); else go(k_finish<DL, false>);
   return hipGetLastError();
 }
 }  // namespace
 
 template <>
-hipError_t launch_update<float>(int dialect, bool trace, int t, bool apply_final_th, float final_th,
-                                const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
-                                hipStream_t stream) {
-  (void)dialect;
-  return launch_update_impl<DialectC>(trace, t, apply_final_th, final_th, d_plan, m, w, stream);
+hipError_t launch_finish<float>(bool trace, bool apply_final_th, float final_th, const DevPlan* d_plan,
+                                const DevModelT<float>& m, const WorkT<float>& w, hipStream_t stream) {
+  return launch_finish_impl<DialectC>(trace, apply_final_th, final_th, d_plan, m, w, stream);
 }
 template <>
-hipError_t launch_update<double>(int dialect, bool trace, int t, bool apply_final_th, double final_th,
-                                 const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
-                                 hipStream_t stream) {
-  (void)dialect;
-  return launch_update_impl<DialectCPP>(trace, t, apply_final_th, final_th, d_plan, m, w, stream);
+hipError_t launch_finish<double>(bool trace, bool apply_final_th, double final_th, const DevPlan* d_plan,
+                                 const DevModelT<double>& m, const WorkT<double>& w, hipStream_t stream) {
+  return launch_finish_impl<DialectCPP>(trace, apply_final_th, final_th, d_plan, m, w, stream);
 }
-
-// =============================================================================
-// final detections -> contiguous rows (into the buffers of the other parity)
-// =============================================================================
-
-template <typename Real>
-__global__ void k_pack(WorkT<Real> w, int T, int dim) {
-  const int pl = (T - 1) & 1, po = T & 1;
-  const unsigned n = (unsigned)w.counters[kCntOut];
-  const unsigned long long total = (unsigned long long)n * dim;
-  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (unsigned long long)gridDim.x * blockDim.x) {
-    const unsigned i = (unsigned)(idx / dim);
-    const int d = (int)(idx - (unsigned long long)i * dim);
-    const unsigned s = w.out_slot[i];  // slot in queue T-1
-    w.shape[po][idx] = w.shape[pl][(size_t)s * dim + d];
-    if (d == 0) { w.q_gid[po][i] = w.q_gid[pl][s]; w.q_score[po][i] = w.q_score[pl][s]; }
-  }
-}
-
-template <typename Real>
-hipError_t launch_pack(const WorkT<Real>& w, int T, int dim, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pack<Real>, dim3(1024), dim3(256), 0, stream, w, T, dim);
-  return hipGetLastError();
-}
-template hipError_t launch_pack<float>(const WorkT<float>&, int, int, hipStream_t);
-template hipError_t launch_pack<double>(const WorkT<double>&, int, int, hipStream_t);
 
 // =============================================================================
 // trace defaults: every window starts as "0 carts, mean shape"
