@@ -324,7 +324,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
 
 template <typename Real>
 static size_t bytes_per_window(int dim, bool trace) {
-  size_t b = (4 + sizeof(Real) + 4) + (4 + sizeof(Real) + (size_t)dim * sizeof(Real));
+  size_t b = (4 + sizeof(Real) + 4) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real));
   if (trace) b += 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
   return b;
 }
@@ -340,6 +340,10 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
     w.q_score = cv.take<Real>(cap);
     w.q_kstart = cv.take<uint32_t>(cap);
     w.q_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
+    w.m_gid = cv.take<uint32_t>(cap);
+    w.m_score = cv.take<Real>(cap);
+    w.m_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
+    w.m_shape = cv.take<Real>(cap * dim);
     w.out_gid = cv.take<uint32_t>(cap);
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
@@ -462,7 +466,14 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     }
     JDA_HIP(hipEventRecord(c->ev[2], st));
     // ---- every survivor: remaining carts, regressions, later stages, final cut ----
-    JDA_HIP(launch_finish<Real>(want_trace, apply_th, th, pe->dp, m, w, st));
+    // two launches so that the few windows that pass stage 0 (and then cost whole
+    // stages each) are spread over the machine again instead of trailing single waves
+    if (T > 1) {
+      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), st));
+      JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), st));
+    } else {
+      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), st));
+    }
     JDA_HIP(hipEventRecord(c->ev[3], st));
     JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
     JDA_HIP(hipStreamSynchronize(st));

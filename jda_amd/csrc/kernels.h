@@ -89,6 +89,8 @@ struct WorkT {
   // hand-off queue k_scan -> k_finish (plus the windows k_scan does not cover)
   uint32_t* q_gid; Real* q_score; uint32_t* q_hash; uint32_t* q_kstart;
   unsigned long long* counters;                                // see Counter
+  // mid queue: windows alive after stage 0, with their regressed shape (k_finish pass 1 -> pass 2)
+  uint32_t* m_gid; Real* m_score; uint32_t* m_hash; Real* m_shape;
   // final detections: windows that passed every cart and the final threshold
   uint32_t* out_gid; Real* out_score; Real* out_shape;
   // per-window trace (all null when off), indexed by gid
@@ -109,7 +111,8 @@ enum Counter : int {
   kCntCarts = kMaxStages + 2,      // carts evaluated, reference counting (Validate's n)
   kCntCartsScan = kMaxStages + 3,  // carts evaluated inside k_scan
   kCntWinScan = kMaxStages + 4,    // windows k_scan covered
-  kCntTotal = kMaxStages + 5
+  kCntMid = kMaxStages + 5,        // length of the mid queue (allocator, shard 0 only)
+  kCntTotal = kMaxStages + 6
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
@@ -140,10 +143,12 @@ hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan
                        const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,
                        hipStream_t stream);
 
-// Everything after the hand-off, for every queued window.
+// Stages [t_begin, t_end) for every queued window: t_begin == 0 reads the hand-off queue,
+// t_begin > 0 the mid queue; survivors go to the mid queue (t_end < T) or the detection list.
 template <typename Real>
-hipError_t launch_finish(bool trace, bool apply_final_th, Real final_th, const DevPlan* d_plan,
-                         const DevModelT<Real>& m, const WorkT<Real>& w, hipStream_t stream);
+hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
+                         const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
+                         int groups, hipStream_t stream);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

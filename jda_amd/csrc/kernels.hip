@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -197,7 +198,7 @@ struct CartPar {          // per-cart parameters as k_scan reads them from LDS
 template <typename Real, bool TRACE>
 struct ScanLds {
   // byte offsets inside dynamic LDS
-  int pix, nodes, leaf, par, q_widx, q_score, q_hash, misc, total;
+  int pix, nodes, leaf, par, q_widx, q_score, q_hash, lfbuf, misc, total;
   __host__ __device__ ScanLds(int pix_bytes, int carts, int node_n, int leaf_n, int m_max) {
     int o = 0;
     pix = o; o += (pix_bytes + 15) & ~15;
@@ -207,6 +208,7 @@ struct ScanLds {
     q_score = o; o += 2 * m_max * (int)sizeof(Real);
     q_widx = o; o += 2 * m_max * 2; o = (o + 15) & ~15;
     q_hash = o; if (TRACE) o += 2 * m_max * 4;
+    lfbuf = o; o += 32 * 64;            // leaf indices of 32 carts x 64 windows (cart-parallel phases)
     misc = o; o += 64;
     total = o;
   }
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   Real* q_score = (Real*)(lds + L.q_score);
   uint16_t* q_widx = (uint16_t*)(lds + L.q_widx);
   unsigned* q_hash = (unsigned*)(lds + L.q_hash);
-  int* misc = (int*)(lds + L.misc);   // [0],[1] queue counts; [2] global base
+  uint8_t* lfbuf = lds + L.lfbuf;
+  int* misc = (int*)(lds + L.misc);   // [0],[1] queue counts; [2] global base; [4..11] counter partials
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -377,89 +380,147 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   // Phases: carts [0,8) [8,16) [16,32) [32,64) [64,128) ...; after each phase the
   // survivors are compacted so that later phases run on full waves.
   for (int c0 = 0; c0 < K;) {
-    const int c1 = min(K, c0 + (c0 < 8 ? 8 : c0));
+    const int c1 = min(K, c0 + (c0 < 8 ? 8 : min(c0, 64)));
 
-    for (int i0 = 0; i0 < n_items; i0 += BLOCK) {
-      const int i = i0 + tid;
-      bool alive = i < n_items;
+    // Applies carts [k, k+CNT) to this lane's window: the CNT trees first (they do
+    // not depend on the score, so their LDS round trips overlap), then the scores
+    // strictly in cart order with the per-cart reject test.
+    auto apply = [&](auto cnt_tag, int k, const int* lf, bool& alive, Real& score, unsigned& hash, int gid) {
+      constexpr int CNT = decltype(cnt_tag)::value;
+      Real s = score;
+      bool dead = false;
+      int kd = k;
+#pragma unroll
+      for (int u = 0; u < CNT; u++) {
+        if (!dead) {
+          const CartPar<Real> p = t_par[k + u];
+          s = s + t_leaf[(k + u) * leaf_n + lf[u]];                        // c/jda.c:396
+          if (p.norm != (Real)0) s = (s - p.mean) / p.std;                 // c/jda.c:397
+          if (TRACE) hash = fnv_step(hash, lf[u]);
+          kd = k + u;
+          dead = s < p.th;                                                 // c/jda.c:399
+        }
+      }
+      score = s;
+      if (dead) {
+        alive = false;
+        my_carts += kd + 1;
+        if (TRACE) { w.tr_carts[gid] = kd + 1; w.tr_score[gid] = s; w.tr_hash[gid] = hash; }
+      }
+    };
+
+    const bool cart_parallel = n_items <= 64 && c1 - c0 >= 16 && leaf_n <= 256;
+    if (!cart_parallel) {
+      // ---- lane = window, every wave walks the whole chunk for its own windows ----
+      for (int i0 = 0; i0 < n_items; i0 += BLOCK) {
+        const int i = i0 + tid;
+        bool alive = i < n_items;
+        int widx = 0;
+        Real score = 0;
+        unsigned hash = kFnvSeed;
+        if (alive) {
+          if (c0 == 0) {
+            widx = i;
+          } else {
+            widx = q_widx[cur * M_MAX + i];
+            score = q_score[cur * M_MAX + i];
+            if (TRACE) hash = q_hash[cur * M_MAX + i];
+          }
+        }
+        const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
+        if (c0 == 0) alive = alive && wx < twe && wy < the;
+        const int base = (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
+        const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
+
+        int k = c0;
+        for (; k + 4 <= c1; k += 4) {
+          if (__ballot(alive) == 0ull) break;
+          if (alive) {
+            int lf[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) lf[u] = scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+            apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
+          }
+        }
+        for (; k < c1; k++) {
+          if (alive) {
+            int lf[1];
+            lf[0] = scan_tree<DEPTH, GLB>(t_nodes + k * node_n, pix, base, m.D) - node_n;
+            apply(std::integral_constant<int, 1>{}, k, lf, alive, score, hash, gid);
+          }
+        }
+        // ---- compact survivors into the next queue (ballot + prefix popcount) ----
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+          int wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&misc[cur ^ 1], __popcll(mask));
+          wbase = __shfl(wbase, 0);
+          if (alive) {
+            const int pos = wbase + __popcll(mask & lanes_below(lane));
+            q_widx[(cur ^ 1) * M_MAX + pos] = (uint16_t)widx;
+            q_score[(cur ^ 1) * M_MAX + pos] = score;
+            if (TRACE) q_hash[(cur ^ 1) * M_MAX + pos] = hash;
+          }
+        }
+      }
+    } else {
+      // ---- at most one wave of windows left: the four waves split the CARTS of the
+      //      chunk (trees only, 8 carts per wave and round), then wave 0 replays the
+      //      scores of the round in cart order from the leaf indices in LDS ----
+      bool alive = lane < n_items;
       int widx = 0;
       Real score = 0;
       unsigned hash = kFnvSeed;
       if (alive) {
-        if (c0 == 0) {
-          widx = i;
-        } else {
-          widx = q_widx[cur * M_MAX + i];
-          score = q_score[cur * M_MAX + i];
-          if (TRACE) hash = q_hash[cur * M_MAX + i];
-        }
+        widx = q_widx[cur * M_MAX + lane];
+        score = q_score[cur * M_MAX + lane];
+        if (TRACE) hash = q_hash[cur * M_MAX + lane];
       }
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
-      if (c0 == 0) alive = alive && wx < twe && wy < the;
       const int base = (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
-
-      int k = c0;
-      for (; k + 1 < c1; k += 2) {
-        if (__ballot(alive) == 0ull) break;
-        if (alive) {
-          const S0Node* tn = t_nodes + k * node_n;
-          const int na = scan_tree<DEPTH, GLB>(tn, pix, base, m.D);
-          const int nb = scan_tree<DEPTH, GLB>(tn + node_n, pix, base, m.D);
-          const int la = na - node_n, lb = nb - node_n;
-          const CartPar<Real> pa = t_par[k], pb = t_par[k + 1];
-          Real s = score + t_leaf[k * leaf_n + la];                       // c/jda.c:396
-          if (pa.norm != (Real)0) s = (s - pa.mean) / pa.std;             // c/jda.c:397
-          if (TRACE) hash = fnv_step(hash, la);
-          bool dead = s < pa.th;                                          // c/jda.c:399
-          int kd = k;
-          if (!dead) {
-            s = s + t_leaf[(k + 1) * leaf_n + lb];
-            if (pb.norm != (Real)0) s = (s - pb.mean) / pb.std;
-            if (TRACE) hash = fnv_step(hash, lb);
-            dead = s < pb.th;
-            kd = k + 1;
+      const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
+      for (int r0 = c0; r0 < c1; r0 += 32) {
+        const int r1 = min(c1, r0 + 32);
+        const int ka = r0 + wv * 8, kb = min(r1, ka + 8);
+        if (lane < n_items) {
+          for (int k = ka; k < kb; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              if (k + u < kb)
+                lfbuf[(k + u - r0) * 64 + lane] =
+                    (uint8_t)(scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n);
           }
-          score = s;
-          if (dead) {
-            alive = false;
-            my_carts += kd + 1;
-            if (TRACE) {
-              const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
-              w.tr_carts[gid] = kd + 1; w.tr_score[gid] = s; w.tr_hash[gid] = hash;
+        }
+        __syncthreads();
+        if (wv == 0) {
+          for (int k = r0; k < r1; k += 4) {
+            if (__ballot(alive) == 0ull) break;
+            if (alive) {
+              int lf[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) lf[u] = (k + u < r1) ? (int)lfbuf[(k + u - r0) * 64 + lane] : 0;
+              if (k + 4 <= r1) {
+                apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
+              } else {
+                for (int u = 0; k + u < r1 && alive; u++)
+                  apply(std::integral_constant<int, 1>{}, k + u, lf + u, alive, score, hash, gid);
+              }
             }
           }
         }
+        __syncthreads();
       }
-      if (k < c1 && k + 1 >= c1) {   // odd tail cart
-        if (alive) {
-          const int na = scan_tree<DEPTH, GLB>(t_nodes + k * node_n, pix, base, m.D);
-          const int la = na - node_n;
-          const CartPar<Real> pa = t_par[k];
-          Real s = score + t_leaf[k * leaf_n + la];
-          if (pa.norm != (Real)0) s = (s - pa.mean) / pa.std;
-          if (TRACE) hash = fnv_step(hash, la);
-          score = s;
-          if (s < pa.th) {
-            alive = false;
-            my_carts += k + 1;
-            if (TRACE) {
-              const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
-              w.tr_carts[gid] = k + 1; w.tr_score[gid] = s; w.tr_hash[gid] = hash;
-            }
+      if (wv == 0) {
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+          const int cnt = __popcll(mask);
+          if (lane == 0) misc[cur ^ 1] = cnt;
+          if (alive) {
+            const int pos = __popcll(mask & lanes_below(lane));
+            q_widx[(cur ^ 1) * M_MAX + pos] = (uint16_t)widx;
+            q_score[(cur ^ 1) * M_MAX + pos] = score;
+            if (TRACE) q_hash[(cur ^ 1) * M_MAX + pos] = hash;
           }
-        }
-      }
-      // ---- compact survivors into the next queue (ballot + prefix popcount) ----
-      const unsigned long long mask = __ballot(alive);
-      if (mask) {
-        int wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&misc[cur ^ 1], __popcll(mask));
-        wbase = __shfl(wbase, 0);
-        if (alive) {
-          const int pos = wbase + __popcll(mask & lanes_below(lane));
-          q_widx[(cur ^ 1) * M_MAX + pos] = (uint16_t)widx;
-          q_score[(cur ^ 1) * M_MAX + pos] = score;
-          if (TRACE) q_hash[(cur ^ 1) * M_MAX + pos] = hash;
         }
       }
     }
@@ -674,10 +735,82 @@ __device__ __forceinline__ double rl(double v, int j) {
 
 }  // namespace
 
-template <typename DL, bool TRACE>
+// Tree walks of G carts (k[0..G)) of one stage for the window whose shape is sh[],
+// in lockstep: per tree level the G node records are fetched together, then the
+// 2G pixels, so the memory round trips of the G walks overlap.  -> leaf indices.
+template <typename DL, int G>
+__device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__ stage_nodes, const int* k,
+                                           int depth, int node_n, const typename DL::Real* sh, int win,
+                                           const View& v0, const View& v1, const View& v2, bool multi, int* leaf) {
+  int node[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) node[g] = 0;
+  for (int d = 0; d < depth - 1; d++) {
+    typename DL::Node nd[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) nd[g] = stage_nodes[(size_t)k[g] * node_n + node[g]];
+    int feat[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) feat[g] = node_feature<DL>(nd[g], sh, win, v0, v1, v2, multi);
+#pragma unroll
+    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (feat[g] <= nd[g].th ? 1 : 2);   // c/jda.c:392-393
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
+}
+
+// Score recurrence of c/jda.c:395-399 over the carts held by lanes [jbeg, jend)
+// of one 64-cart group, replayed strictly in cart order.  ls/th_k/mean_k/std_k/lf
+// are per-lane values of cart (group base + lane).  Returns the lane of the
+// rejecting cart or -1; score/hash are left as they stood at that cart.
+template <typename Real, bool TRACE>
+__device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real ls, Real th_k, Real mean_k, Real std_k,
+                                             unsigned long long normmask, int lf, int jbeg, int jend) {
+  if (jbeg == 0 && jend == 64 && normmask == 0ull) {
+    // Common case, branch-free: the running score is wave-uniform; after every
+    // add ALL lanes compare it with their own cart's threshold and only bit j
+    // of that ballot is kept.  Same adds in the same order as the scalar loop.
+    Real s = score;
+    unsigned long long rej = 0ull;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      s = s + rl(ls, j);                                       // c/jda.c:396
+      rej |= __ballot(s < th_k) & (1ull << j);                 // c/jda.c:399
+    }
+    if (rej == 0ull) {
+      if (TRACE) {
+#pragma unroll 8
+        for (int j = 0; j < 64; j++) hash = fnv_step(hash, rl(lf, j));
+      }
+      score = s;
+      return -1;
+    }
+    const int jr = __ffsll((long long)rej) - 1;
+    Real s2 = score;
+    for (int j = 0; j <= jr; j++) {                            // the score as it stood at the rejecting cart
+      s2 = s2 + rl(ls, j);
+      if (TRACE) hash = fnv_step(hash, rl(lf, j));
+    }
+    score = s2;
+    return jr;
+  }
+  for (int j = jbeg; j < jend; j++) {
+    Real s = score + rl(ls, j);                                                     // c/jda.c:396
+    if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);             // c/jda.c:397
+    score = s;
+    if (TRACE) hash = fnv_step(hash, rl(lf, j));
+    if (s < rl(th_k, j)) return j;                                                  // c/jda.c:399
+  }
+  return -1;
+}
+
+// Stages [t_begin, t_end) for every window of the input queue.  Windows that are
+// still alive after stage t_end-1 go to the mid queue (t_end < T) or, after the
+// final threshold, to the detection list (t_end == T).
+template <typename DL, bool TRACE, int kG>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
-                                               int apply_th, typename DL::Real final_th) {
+                                               int t_begin, int t_end, int apply_th, typename DL::Real final_th) {
   using Real = typename DL::Real;
   using Node = typename DL::Node;
   constexpr bool kCpp = sizeof(Real) == 8;
@@ -691,24 +824,29 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   const bool multi = multi_i != 0;
   const int lane = threadIdx.x;
   if (lane < kMaxStages) stage_cnt[lane] = 0;
-  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  const bool from_scan = t_begin == 0;
+  const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)w.cap);
   unsigned long long carts_acc = 0;
 
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t gid = w.q_gid[i];
-    Real score = w.q_score[i];
-    const int kstart = (int)w.q_kstart[i];
-    unsigned hash = TRACE ? w.q_hash[i] : kFnvSeed;
+    const uint32_t gid = from_scan ? w.q_gid[i] : w.m_gid[i];
+    Real score = from_scan ? w.q_score[i] : w.m_score[i];
+    const int kstart = from_scan ? (int)w.q_kstart[i] : 0;
+    unsigned hash = kFnvSeed;
+    if (TRACE) hash = from_scan ? w.q_hash[i] : w.m_hash[i];
     int win;
     View v0{}, v1{}, v2{};
     decode_window<Real>(plan, w, gid, inv_sqrt2, &win, &v0, &v1, &v2, multi);
     __syncthreads();                       // previous window's readers are done with sh
-    for (int d = lane; d < dim; d += 64) sh[d] = m.mean_shape[d];
+    {
+      const Real* src = from_scan ? m.mean_shape : w.m_shape + (size_t)i * dim;
+      for (int d = lane; d < dim; d += 64) sh[d] = src[d];
+    }
     __syncthreads();
 
     bool alive = true;
     int carts_n = 0;
-    for (int t = 0; t < T; t++) {
+    for (int t = t_begin; t < t_end; t++) {
       const Node* nodes = (const Node*)m.nodes + (size_t)t * K * node_n;
       const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
       const Real* cth = m.cth + (size_t)t * K;
@@ -718,47 +856,45 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       const int kbeg = t == 0 ? min(kstart, K) : 0;   // first cart whose score is still to be applied
       const int k_first = kbeg & ~63;
 
-      // ---- tree walks, 64 carts at a time (the shape is fixed during a stage, so
-      //      the trees of a stage are independent); then the score recurrence of
-      //      c/jda.c:395-399 replayed strictly in cart order ----
-      for (int k0 = k_first; k0 < K && alive; k0 += 64) {
-        const int k = k0 + lane;
-        int lf = 0, norm_k = 0;
-        Real ls = 0, th_k = 0, mean_k = 0, std_k = 1;
-        if (k < K) {
-          int node = 0;
-          for (int d = 0; d < m.D - 1; d++) {
-            const Node nd = nodes[(size_t)k * node_n + node];
-            const int feat = node_feature<DL>(nd, sh, win, v0, v1, v2, multi);
-            node = 2 * node + (feat <= nd.th ? 1 : 2);       // c/jda.c:392-393
+      // ---- tree walks, kG groups of 64 carts per round (the shape is fixed during a
+      //      stage, so the trees of a stage are independent of each other and of the
+      //      score); then the score recurrence replayed in cart order ----
+      for (int k0 = k_first; k0 < K && alive; k0 += 64 * kG) {
+        int kk[kG], lf[kG], nrm[kG];
+        Real ls[kG], thk[kG], mk[kG], sk[kG];
+#pragma unroll
+        for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
+        walk_carts<DL, kG>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, multi, lf);
+#pragma unroll
+        for (int g = 0; g < kG; g++) {
+          const int k = k0 + g * 64 + lane;
+          ls[g] = 0; thk[g] = 0; mk[g] = 0; sk[g] = 1; nrm[g] = 0;
+          if (k < K) {
+            lbf[k] = (uint16_t)lf[g];
+            ls[g] = leaf_tab[(size_t)k * leaf_n + lf[g]];
+            thk[g] = cth[k];
+            nrm[g] = cnorm[k];
+            if (nrm[g]) { mk[g] = cmean[k]; sk[g] = cstd[k]; }
           }
-          lf = node - node_n;
-          lbf[k] = (uint16_t)lf;
-          ls = leaf_tab[(size_t)k * leaf_n + lf];
-          th_k = cth[k];
-          norm_k = cnorm[k];
-          if (norm_k) { mean_k = cmean[k]; std_k = cstd[k]; }
         }
-        const unsigned long long normmask = __ballot(norm_k != 0);
-        const int jend = min(64, K - k0);
-        for (int j = max(0, kbeg - k0); j < jend; j++) {
-          Real s = score + rl(ls, j);                                   // c/jda.c:396
-          if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);   // c/jda.c:397
-          score = s;
-          if (TRACE) hash = fnv_step(hash, rl(lf, j));
-          if (s < rl(th_k, j)) { alive = false; carts_n = t * K + k0 + j + 1; break; }   // c/jda.c:399
+#pragma unroll
+        for (int g = 0; g < kG; g++) {
+          const int kg = k0 + g * 64;
+          if (kg >= K || !alive) break;
+          const unsigned long long normmask = __ballot(nrm[g] != 0);
+          const int jr = replay_scores<Real, TRACE>(score, hash, ls[g], thk[g], mk[g], sk[g], normmask, lf[g],
+                                                    max(0, kbeg - kg), min(64, K - kg));
+          if (jr >= 0) { alive = false; carts_n = t * K + kg + jr + 1; }
         }
       }
       if (!alive) break;
       // leaves of the carts k_scan already scored (needed only now that the stage is passed)
-      for (int k = lane; k < k_first; k += 64) {
-        int node = 0;
-        for (int d = 0; d < m.D - 1; d++) {
-          const Node nd = nodes[(size_t)k * node_n + node];
-          const int feat = node_feature<DL>(nd, sh, win, v0, v1, v2, multi);
-          node = 2 * node + (feat <= nd.th ? 1 : 2);
-        }
-        lbf[k] = (uint16_t)(node - node_n);
+      for (int k0 = 0; k0 < k_first; k0 += 128) {
+        int kk[2], lf[2];
+        kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
+        walk_carts<DL, 2>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, multi, lf);
+        if (k0 + lane < k_first) lbf[k0 + lane] = (uint16_t)lf[0];
+        if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint16_t)lf[1];
       }
       __syncthreads();
       // ---- stage regression: K weight rows added strictly in cart order
@@ -769,12 +905,12 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real acc = kCpp ? (Real)0 : sh[d];
         const Real* col = wt + d;
         int k = 0;
-        for (; k + 8 <= K; k += 8) {
-          Real r[8];
+        for (; k + 32 <= K; k += 32) {          // 32 row loads in flight, then 32 ordered adds
+          Real r[32];
 #pragma unroll
-          for (int u = 0; u < 8; u++) r[u] = col[(size_t)((k + u) * leaf_n + lbf[k + u]) * dim];
+          for (int u = 0; u < 32; u++) r[u] = col[(size_t)((k + u) * leaf_n + lbf[k + u]) * dim];
 #pragma unroll
-          for (int u = 0; u < 8; u++) acc = acc + r[u];
+          for (int u = 0; u < 32; u++) acc = acc + r[u];
         }
         for (; k < K; k++) acc = acc + col[(size_t)(k * leaf_n + lbf[k]) * dim];
         if (kCpp) {
@@ -790,20 +926,32 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       { Real* tmp = sh; sh = sh2; sh2 = tmp; }
       if (lane == 0) stage_cnt[t] += 1;
     }
-    if (alive) carts_n = T * K;
-    carts_acc += (unsigned long long)carts_n;
 
-    if (TRACE) {
-      if (lane == 0) { w.tr_carts[gid] = carts_n; w.tr_score[gid] = score; w.tr_hash[gid] = hash; }
-      for (int d = lane; d < dim; d += 64) w.tr_shape[(size_t)gid * dim + d] = sh[d];
-    }
-    if (alive && !(apply_th && score < final_th)) {            // c/jda.c:414
+    if (!alive || t_end == T) {
+      // the window's walk is over: account for it (reference counting: Validate's n)
+      if (alive) carts_n = T * K;
+      carts_acc += (unsigned long long)carts_n;
+      if (TRACE) {
+        if (lane == 0) { w.tr_carts[gid] = carts_n; w.tr_score[gid] = score; w.tr_hash[gid] = hash; }
+        for (int d = lane; d < dim; d += 64) w.tr_shape[(size_t)gid * dim + d] = sh[d];
+      }
+      if (alive && !(apply_th && score < final_th)) {            // c/jda.c:414
+        unsigned o = 0;
+        if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
+        o = (unsigned)__shfl((int)o, 0);
+        if (o < w.cap) {
+          if (lane == 0) { w.out_gid[o] = gid; w.out_score[o] = score; }
+          for (int d = lane; d < dim; d += 64) w.out_shape[(size_t)o * dim + d] = sh[d];
+        }
+      }
+    } else {
+      // alive with stages left: park it in the mid queue for the next launch
       unsigned o = 0;
-      if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
+      if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
       o = (unsigned)__shfl((int)o, 0);
       if (o < w.cap) {
-        if (lane == 0) { w.out_gid[o] = gid; w.out_score[o] = score; }
-        for (int d = lane; d < dim; d += 64) w.out_shape[(size_t)o * dim + d] = sh[d];
+        if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; if (TRACE) w.m_hash[o] = hash; }
+        for (int d = lane; d < dim; d += 64) w.m_shape[(size_t)o * dim + d] = sh[d];
       }
     }
   }
@@ -814,9 +962,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
 
 namespace {
 template <typename DL>
-hipError_t launch_finish_impl(bool trace, bool apply_th, typename DL::Real th, const DevPlan* d_plan,
-                              const DevModelT<typename DL::Real>& m, const WorkT<typename DL::Real>& w,
-                              hipStream_t stream) {
+hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th, typename DL::Real th,
+                              const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
+                              const WorkT<typename DL::Real>& w, int groups, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
   const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 7) & ~7) * 2 + kMaxStages * sizeof(int);
@@ -827,22 +975,28 @@ hipError_t launch_finish_impl(bool trace, bool apply_th, typename DL::Real th, c
   if (blocks == 0) blocks = 1;
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, apply_th ? 1 : 0, th);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, t_begin, t_end,
+                       apply_th ? 1 : 0, th);
   };
-  if (trace) go(k_finish<DL, true>); else go(k_finish<DL, false>);
+  // groups = 64-cart groups walked speculatively per round: 1 where most windows are
+  // rejected within a few carts (throughput), 4 where most pass (latency)
+  if (trace) { if (groups >= 4) go(k_finish<DL, true, 4>); else if (groups >= 2) go(k_finish<DL, true, 2>); else go(k_finish<DL, true, 1>); }
+  else { if (groups >= 4) go(k_finish<DL, false, 4>); else if (groups >= 2) go(k_finish<DL, false, 2>); else go(k_finish<DL, false, 1>); }
   return hipGetLastError();
 }
 }  // namespace
 
 template <>
-hipError_t launch_finish<float>(bool trace, bool apply_final_th, float final_th, const DevPlan* d_plan,
-                                const DevModelT<float>& m, const WorkT<float>& w, hipStream_t stream) {
-  return launch_finish_impl<DialectC>(trace, apply_final_th, final_th, d_plan, m, w, stream);
+hipError_t launch_finish<float>(bool trace, int t_begin, int t_end, bool apply_final_th, float final_th,
+                                const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
+                                int groups, hipStream_t stream) {
+  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, stream);
 }
 template <>
-hipError_t launch_finish<double>(bool trace, bool apply_final_th, double final_th, const DevPlan* d_plan,
-                                 const DevModelT<double>& m, const WorkT<double>& w, hipStream_t stream) {
-  return launch_finish_impl<DialectCPP>(trace, apply_final_th, final_th, d_plan, m, w, stream);
+hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_final_th, double final_th,
+                                 const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
+                                 int groups, hipStream_t stream) {
+  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, stream);
 }
 
 // =============================================================================

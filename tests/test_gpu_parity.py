@@ -252,3 +252,73 @@ def test_concurrent_callers_share_one_cascador(built, gpu, model_file):
         got = list(ex.map(c.detect, list(frames) * 3))
     for i, g in enumerate(got):
         _compare_detect(g, want[i % 8])
+
+
+# ---------------------------------------------------------------- dialect CPP (src/jda, fp64)
+
+def _compare_trace_cpp(casc, orc, frames, **kw):
+    g = casc.trace_cpp(frames, **kw)
+    off = 0
+    for i in range(len(frames)):
+        r = orc.trace_cpp(frames[i], **kw)
+        n = len(r["carts_n"])
+        for k in ("carts_n", "score", "path_hash", "shapes"):
+            assert same(r[k], g[k][off:off + n]), (i, k, int((bits(r[k]) != bits(g[k][off:off + n])).sum()))
+        off += n
+    assert off == len(g["carts_n"])
+
+
+@pytest.mark.parametrize("dims", [(2, 8, 5, 3), (3, 20, 5, 4), (2, 6, 4, 6), (3, 70, 9, 5)])
+@pytest.mark.parametrize("th", [-3.0e38, -0.8])
+def test_dialect_cpp_vs_oracle(built, gpu, model_file, dims, th):
+    """fp64 / round() / fixed pixel step / delta-shape summed from zero / score-ordered NMS:
+    reference src/jda/cascador.cpp:166-211,310-477 as restated by the oracle (parity unpinned
+    against a compiled src/jda -- it needs OpenCV -- see DESIGN.md)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file(dims, 8, seed=21, cart_th=th, norm_every=5, f32_exact=False)
+    frames = synth.make_frames(2, 160, 120, seed=31)
+    c, o = api.Cascador(p, "double"), Oracle(p)
+    kw = dict(minimum_size=20, step=5, factor=1.2)
+    _compare_trace_cpp(c, o, frames, **kw)
+    for nms in (True, False):
+        dets, st = c.detect_batch_cpp(frames, overlap=0.3, nms=nms, stats=True, **kw)
+        assert st["patch_n"] == 2 * synth.count_windows_cpp(160, 120, 20, 5, 1.2)
+        for i in range(len(frames)):
+            want = o.detect_cpp(frames[i], overlap=0.3, nms=nms, **kw)
+            for k in ("rects", "scores", "shapes"):
+                assert same(dets[i][k], want[k]), (nms, i, k)
+
+
+def test_dialect_cpp_shipped_config(built, gpu, model_file):
+    """fddb parameters of the shipped config (model/config.json:41-45: min 20, step 5, x1.2)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 20, 5, 4), 8, seed=22, cart_th=-0.6)
+    frames = synth.make_frames(1, 640, 480, seed=32)
+    c, o = api.Cascador(p), Oracle(p)
+    dets, st = c.detect_batch_cpp(frames, 20, 5, 1.2, 0.3, True, stats=True)
+    assert st["patch_n"] == 140215                               # SURVEY.md a-16
+    want = o.detect_cpp(frames[0], 20, 5, 1.2, 0.3, True)
+    for k in want:
+        assert same(dets[0][k], want[k]), k
+
+
+def test_dialects_agree_where_they_must(built, gpu, model_file):
+    """Same model, same windows: wherever fp32/trunc and fp64/round pick the same pixels the
+    leaf paths coincide; with thresholds off both dialects evaluate every cart of every window."""
+    from jda_amd import api, synth
+    p, _ = model_file((2, 8, 5, 3), 8, seed=23)
+    frames = synth.make_frames(1, 100, 80, seed=33)
+    c = api.Cascador(p)
+    a = c.trace(frames, scale=1.25, min_size=24)
+    b = c.trace_cpp(frames, minimum_size=24, step=5, factor=1.25)
+    assert (a["carts_n"] == 16).all() and (b["carts_n"] == 16).all()
+
+
+def test_dialect_cpp_rejects_multiscale(built, gpu, model_file):
+    from jda_amd import api, synth
+    p, _ = model_file((2, 8, 5, 3), 8, seed=24, multi_scale=True)
+    c = api.Cascador(p)
+    with pytest.raises(api.JdaError, match="scale==0"):
+        c.detect_batch_cpp(synth.make_frames(1, 64, 64, seed=1))
