@@ -322,3 +322,21 @@ def test_dialect_cpp_rejects_multiscale(built, gpu, model_file):
     c = api.Cascador(p)
     with pytest.raises(api.JdaError, match="scale==0"):
         c.detect_batch_cpp(synth.make_frames(1, 64, 64, seed=1))
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[4] dimensions
+
+def test_deep_wide_model_config5_dims(built, gpu, tmp_path):
+    """T=7, K=2000, depth 6, 68 landmarks (259,560,576-byte float file, W = 243.7 MB): branchy
+    trees (generic-depth scan path, 31 nodes per cart) and the wide regression gather."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    m = synth.make_model(7, 2000, 68, 6, seed=2, cart_th=-2.0)
+    p = str(tmp_path / "x.model"); m.save(p, 4)
+    assert os.path.getsize(p) == 259560576                     # SURVEY.md 8a-8
+    c, o = api.Cascador(p, "float"), Oracle(p)
+    frames = synth.make_frames(1, 320, 240, seed=3)
+    _compare_trace(c, o, frames)
+    d = c.detect_batch(frames)[0]
+    _compare_detect(d, o.detect(frames[0]))
+    assert len(d["scores"]) > 0
