@@ -174,7 +174,7 @@ def main():
         scan_ms = float(np.mean([s["scan_ms"] for s in stats]))
         gpu_ms = float(np.mean([s["gpu_ms"] for s in stats]))
         host_ms = float(np.mean([s["host_ms"] for s in stats]))
-        step_bytes = algorithmic_bytes(dims, st["cart_gothrough_n"], st["stage_done_n"][:T], st["patch_n"], n_det)
+        step_bytes = algorithmic_bytes(dims, st["cart_total_n"], st["stage_done_n"][:T], st["patch_n"], n_det)
         scan_bytes = st["scan_cart_n"] * ((D - 1) * 34 + 16) + st["scan_patch_n"] * 2 * L * 4
         info = {
             "windows_per_s": windows_step * world * steps / el,

@@ -134,8 +134,9 @@ typedef struct {
   long long patch_n;          /* candidate windows scanned                    */
   long long face_patch_n;     /* windows that passed every cart (+ final th)  */
   long long nonface_patch_n;  /* patch_n - face_patch_n                       */
-  long long cart_gothrough_n; /* carts evaluated, counted as the reference    */
-                              /* counts `n` in Validate (cascador.cpp:187)    */
+  long long cart_gothrough_n; /* reject lengths (Validate's n, cascador.cpp:187) */
+                              /* summed over the NON-face windows only, like  */
+                              /* the reference (cascador.cpp:359-364)         */
   long long stage_done_n[16]; /* windows that completed stage t (shape update) */
   double average_cart_n;      /* cart_gothrough_n / nonface_patch_n           */
   double gpu_ms;              /* device time of the call (HIP events)         */
@@ -145,6 +146,7 @@ typedef struct {
   long long scan_patch_n;     /* windows the stage-0 scan kernel covered      */
   int scan_launches;          /* launches of the stage-0 scan kernel (one per tiled level) */
   long long handoff_n;        /* windows handed from the scan to the finishing kernel (incl. untiled levels) */
+  long long cart_total_n;     /* carts evaluated over ALL windows (roofline accounting) */
 } jdaStats;
 
 typedef struct {

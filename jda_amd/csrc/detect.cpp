@@ -553,15 +553,16 @@ static void parallel_for(int n, const std::function<void(int)>& fn, bool small_j
   for (auto& t : th) t.join();
 }
 
-static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int T, double host_ms) {
+static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int T, int K, double host_ms) {
   if (!st) return;
   std::memset(st, 0, sizeof(*st));
   st->patch_n = patch_n;
   st->face_patch_n = rs.out;
   st->nonface_patch_n = patch_n - rs.out;
-  st->cart_gothrough_n = rs.carts;
+  st->cart_total_n = rs.carts;
+  st->cart_gothrough_n = rs.carts - rs.out * (long long)T * K;   // faces walked all T*K carts
   for (int t = 0; t < T && t < 16; t++) st->stage_done_n[t] = rs.stage_done[t];
-  st->average_cart_n = st->nonface_patch_n > 0 ? (double)rs.carts / (double)st->nonface_patch_n : 0.0;
+  st->average_cart_n = st->nonface_patch_n > 0 ? (double)st->cart_gothrough_n / (double)st->nonface_patch_n : 0.0;
   st->gpu_ms = rs.gpu_ms; st->scan_ms = rs.scan_ms; st->host_ms = host_ms;
   st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
   st->handoff_n = rs.tail;
@@ -635,7 +636,7 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
   }, dets.gid.size() < 20000);
-  fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, now_ms() - t0);
+  fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
 }
 
@@ -930,7 +931,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
       relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
     }
   }, dets.gid.size() < 20000);
-  fill_stats(stats, rs, sp.windows * n, c->hm.T, now_ms() - t0);
+  fill_stats(stats, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
 }
 

@@ -195,7 +195,7 @@ def test_full_batch_properties(built, gpu, tmp_path):
     res1, st1 = c.detect_batch_device(d_frames, stats=True)
     res2, st2 = c.detect_batch_device(d_frames, stats=True)
     assert st1["patch_n"] == 256 * 38245 == 9790720
-    for k in ("cart_gothrough_n", "face_patch_n", "stage_done_n", "scan_cart_n", "scan_patch_n"):
+    for k in ("cart_gothrough_n", "cart_total_n", "face_patch_n", "stage_done_n", "scan_cart_n", "scan_patch_n"):
         assert st1[k] == st2[k], k                                        # deterministic work
     for a, b in zip(res1, res2):
         _compare_detect(a, b)                                             # deterministic results
@@ -215,8 +215,12 @@ def test_full_batch_properties(built, gpu, tmp_path):
     # counters: carts evaluated over 3 frames equal the oracle's per-window sum
     sub = [0, 100, 255]
     _, st = c.detect_batch(frames[sub], stats=True)
-    want = sum(int(o.trace(frames[i], want_shapes=False)["carts_n"].sum()) for i in sub)
-    assert st["cart_gothrough_n"] == want
+    trs = [o.trace(frames[i], want_shapes=False) for i in sub]
+    assert st["cart_total_n"] == sum(int(t["carts_n"].sum()) for t in trs)
+    # DetectionStatisic semantics: reject lengths of the non-face windows only
+    faces = sum(int(((t["carts_n"] == 2700) & ~(t["score"] < np.float32(-0.5))).sum()) for t in trs)
+    assert st["face_patch_n"] == faces and st["nonface_patch_n"] == st["patch_n"] - faces
+    assert st["cart_gothrough_n"] == st["cart_total_n"] - faces * 2700
     # NMS off returns a superset, in scan order
     raw = c.detect_batch(frames[:2], nms=False)
     for i in range(2):
