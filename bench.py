@@ -144,16 +144,15 @@ def main():
         casc = api.Cascador(mp, device=local_rank)
 
         def step(want_stats=False):
-            # N=1: the C call has materialised every jdaResult; they are counted and released.
-            # N>1: the tuples are also copied out, packed and gathered on rank 0 over RCCL.
+            # every rank: detect its batch, flatten the (bbox, score, landmarks) tuples with one C call;
+            # N>1: one RCCL all_gather of fixed-size blocks brings them to rank 0
             out = casc.detect_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th,
-                                           nms=True, stats=want_stats, keep_results=world > 1)
-            res, st = out if want_stats else (out, None)
+                                           nms=True, stats=want_stats, keep_results="packed",
+                                           frame_offset=rank * B)
+            rows, st = out if want_stats else (out, None)
             if world > 1:
-                mat = jdist.pack_detections(res, L, frame_offset=rank * B)
-                jdist.gather_detections(mat, device=dev)
-                return sum(len(r["scores"]) for r in res), st
-            return sum(res), st
+                jdist.gather_detections_fixed(rows, 4096, device=dev)
+            return len(rows), st
 
         for _ in range(warmup):
             step()

@@ -228,6 +228,13 @@ JDA_API int jdaNmsC(const int *bboxes, const float *scores, int n, float overlap
 JDA_API int jdaNmsCpp(const int *rects, const double *scores, int n, double overlap, int *picked);
 JDA_API long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes);
 
+/* Flattens n per-frame results into rows of (5 + 2*landmark_n) floats:
+ * [frame_offset + i, x, y, size, score, shape...] -- the (bbox, score, landmarks)
+ * tuple that is gathered across GPUs.  rows may be NULL to query the row count.
+ * Returns the number of rows, or -1 if capacity_rows is too small. */
+JDA_API int jdaResultsPack(const jdaResult *results, int n, int frame_offset,
+                           float *rows, int capacity_rows);
+
 /* Per-window trace of the dialect-CPP cascade, like jdaTraceBatch but with the
  * fp64 state of reference Validate (src/jda/cascador.cpp:166-211): carts_n is
  * Validate's `n`. */

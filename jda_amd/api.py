@@ -106,6 +106,7 @@ def _load():
                                       C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
     lib.jdaNmsCpp.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int)]
+    lib.jdaResultsPack.argtypes = [C.POINTER(jdaResult), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.jdaModelStreamBytes.restype = C.c_longlong
     lib.jdaModelStreamBytes.argtypes = [C.c_int] * 5
     if hasattr(lib, "jdaTraceBatchCpp"):
@@ -263,7 +264,7 @@ class Cascador:
 
     # -- batch resident in device memory (torch uint8 CUDA tensor [n,h,w]) ------------
     def detect_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True,
-                            stats=False, keep_results=True):
+                            stats=False, keep_results=True, frame_offset=0):
         assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
         n, h, w = d_frames.shape
         res = (jdaResult * max(n, 1))()
@@ -272,7 +273,15 @@ class Cascador:
                                       min_size, max_size, th, C.byref(o), res)
         if rc != 0:
             raise JdaError(last_error())
-        if keep_results:
+        if keep_results == "packed":
+            # one C call: rows [frame, x, y, size, score, shape...] of every detection of the batch
+            rows = lib.jdaResultsPack(res, n, frame_offset, None, 0)
+            out = np.empty((max(rows, 0), 5 + self.dim), np.float32)
+            if rows > 0:
+                lib.jdaResultsPack(res, n, frame_offset, out.ctypes.data_as(C.POINTER(C.c_float)), rows)
+            for i in range(n):
+                lib.jdaResultRelease(res[i])
+        elif keep_results:
             out = [_take(res[i]) for i in range(n)]
         else:
             out = [res[i].n for i in range(n)]

@@ -866,6 +866,27 @@ int jdaNmsCpp(const int* rects, const double* scores, int n, double overlap, int
   return (int)k.size();
 }
 
+int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* rows, int capacity_rows) {
+  if (!results || n < 0) return -1;
+  long long total = 0;
+  for (int i = 0; i < n; i++) total += results[i].n;
+  if (!rows) return (int)total;
+  if (total > capacity_rows) return -1;
+  float* o = rows;
+  for (int i = 0; i < n; i++) {
+    const jdaResult& r = results[i];
+    const int dim = 2 * r.landmark_n;
+    for (int j = 0; j < r.n; j++) {
+      o[0] = (float)(frame_offset + i);
+      o[1] = (float)r.bboxes[3 * j]; o[2] = (float)r.bboxes[3 * j + 1]; o[3] = (float)r.bboxes[3 * j + 2];
+      o[4] = r.scores[j];
+      std::memcpy(o + 5, r.shapes + (size_t)j * dim, dim * sizeof(float));
+      o += 5 + dim;
+    }
+  }
+  return (int)total;
+}
+
 long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
   return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
 }

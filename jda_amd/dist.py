@@ -81,3 +81,32 @@ def gather_detections(mat, device=None, group=None):
         return None
     parts = [bufs[r][: counts[r]].cpu().numpy() for r in range(world)]
     return np.concatenate(parts) if parts else np.zeros((0, width), np.float32)
+
+
+def gather_detections_fixed(mat, max_rows, device=None, group=None):
+    """Same result as gather_detections with ONE collective and no host sync in between: every
+    rank contributes a fixed (1 + max_rows)-row block whose first row carries its row count.
+    Falls back to the two-step gather when any rank holds more than max_rows rows (decided
+    collectively from the gathered counts, so every rank takes the same branch)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mat
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    width = mat.shape[1]
+    n = mat.shape[0]
+    block = torch.zeros((1 + max_rows, width), dtype=torch.float32, device=dev)
+    block[0, 0] = float(n)
+    if 0 < n <= max_rows:
+        block[1:1 + n] = torch.from_numpy(np.ascontiguousarray(mat)).to(dev)
+    allb = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(allb, block, group=group)
+    counts = [int(c) for c in torch.stack([b[0, 0] for b in allb]).tolist()]     # one device->host sync
+    if max(counts) > max_rows:
+        return gather_detections(mat, device=device, group=group)
+    if rank != 0:
+        return None
+    parts = [allb[r][1:1 + counts[r]].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts) if parts else np.zeros((0, width), np.float32)

@@ -89,3 +89,63 @@ def test_gather_over_gloo_world2():
         assert (r["bboxes"] == f).all() and (r["scores"] == f + 0.5).all() and (r["shapes"] == f + 0.25).all()
     # rows arrive grouped by rank, ranks hold contiguous frame blocks -> global frame order is preserved
     assert list(got[:, 0]) == sorted(got[:, 0])
+
+
+def _worker_fixed(rank, world, port, q, max_rows):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from jda_amd import dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 5 + 40 * rank                                     # rank 1 overflows max_rows=16 -> fallback path
+    mat = np.full((n, 9), rank + 1, np.float32)
+    mat[:, 0] = np.arange(n) + 1000 * rank
+    got = jd.gather_detections_fixed(mat, max_rows, device="cpu")
+    if rank == 0:
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("max_rows", [64, 16])
+def test_gather_fixed_block_and_fallback(max_rows):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fixed, args=(r, 2, port, q, max_rows)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got.shape == (5 + 45, 9)
+    assert list(got[:5, 0]) == [0, 1, 2, 3, 4] and list(got[5:, 0]) == list(1000 + np.arange(45))
+    assert (got[:5, 1:] == 1).all() and (got[5:, 1:] == 2).all()
+
+
+def test_results_pack_matches_python_packing():
+    """jdaResultsPack (C) == jda_amd.dist.pack_detections (numpy) on hand-made jdaResult structs."""
+    import ctypes as C
+    from jda_amd import api, dist as jd
+    rng = np.random.default_rng(3)
+    L = 4
+    res_py, keep = [], []
+    arr = (api.jdaResult * 3)()
+    for i, n in enumerate((2, 0, 3)):
+        bb = rng.integers(0, 500, (n, 3)).astype(np.int32)
+        sc = rng.normal(size=n).astype(np.float32)
+        sh = rng.normal(size=(n, 2 * L)).astype(np.float32)
+        keep += [bb, sc, sh]
+        arr[i].n = n; arr[i].landmark_n = L
+        arr[i].bboxes = bb.ctypes.data_as(C.POINTER(C.c_int))
+        arr[i].scores = sc.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].shapes = sh.ctypes.data_as(C.POINTER(C.c_float))
+        res_py.append(dict(bboxes=bb, scores=sc, shapes=sh))
+    rows = api.lib.jdaResultsPack(arr, 3, 7, None, 0)
+    assert rows == 5
+    out = np.zeros((rows, 5 + 2 * L), np.float32)
+    assert api.lib.jdaResultsPack(arr, 3, 7, out.ctypes.data_as(C.POINTER(C.c_float)), rows) == 5
+    assert np.array_equal(out, jd.pack_detections(res_py, L, frame_offset=7))
+    assert api.lib.jdaResultsPack(arr, 3, 7, out.ctypes.data_as(C.POINTER(C.c_float)), 4) == -1
