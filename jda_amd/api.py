@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjda.so")
+LIB_PATH = os.environ.get("JDA_LIB_PATH") or os.path.join(_HERE, "libjda.so")
 
 JDA_DIALECT_C = 0
 JDA_DIALECT_CPP = 1

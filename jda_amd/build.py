@@ -35,6 +35,13 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_timing():
+    """Investigation build with shader-clock stamps in k_scan (tools/scan_timing.py); never the product."""
+    out = os.path.join(HERE, "libjda_timing.so")
+    subprocess.check_call([hipcc()] + FLAGS + ["-DJDA_SCAN_TIMING", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -46,4 +53,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--timing" in sys.argv:
+        print(build_timing()); sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

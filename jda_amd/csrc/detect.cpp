@@ -348,6 +348,9 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
     w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
+#ifdef JDA_SCAN_TIMING
+    w.dbg = cv.take<unsigned long long>(65536 * 32);
+#endif
     if (trace) {
       w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
       w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
@@ -466,13 +469,24 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     }
     JDA_HIP(hipEventRecord(c->ev[2], st));
     // ---- every survivor: remaining carts, regressions, later stages, final cut ----
-    // two launches so that the few windows that pass stage 0 (and then cost whole
-    // stages each) are spread over the machine again instead of trailing single waves
+    // Two launches so that the few windows that pass stage 0 (and then cost whole stages
+    // each) are spread over the machine again.  The queue lengths are read back first
+    // (two small synchronisations) so that each launch gets one workgroup per window.
+    const bool sized = env_ll("JDA_FINISH_SIZED", 1) != 0;
+    auto queue_len = [&](int counter, long long* n) -> bool {
+      *n = -1;
+      if (!sized) return true;
+      JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters + counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipStreamSynchronize(st));
+      *n = (long long)std::min<unsigned long long>(c->h_counters[0], cap);
+      return true;
+    };
+    long long n_tail = -1, n_mid = -1;
+    if (!queue_len(kCntTail, &n_tail)) return false;
+    JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
     if (T > 1) {
-      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), st));
-      JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), st));
-    } else {
-      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), st));
+      if (!queue_len(kCntMid, &n_mid)) return false;
+      JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
     }
     JDA_HIP(hipEventRecord(c->ev[3], st));
     JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
@@ -890,6 +904,15 @@ int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* row
 long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
   return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
 }
+
+#ifdef JDA_SCAN_TIMING
+// timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
+__attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !c->wf.w.dbg) return -1;
+  return hipMemcpy(out, c->wf.w.dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 void jdaResultDRelease(jdaResultD result) {
   std::free(result.rects);

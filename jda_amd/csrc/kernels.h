@@ -96,6 +96,9 @@ struct WorkT {
   // per-window trace (all null when off), indexed by gid
   int* tr_carts; Real* tr_score; uint32_t* tr_hash; Real* tr_shape;
   unsigned cap;                                                // capacity of every per-window array
+#ifdef JDA_SCAN_TIMING
+  unsigned long long* dbg;                                     // [65536][16] shader-clock stamps of k_scan workgroups
+#endif
 };
 
 // Work counters live in kCntShards copies, one 256-byte line apart, so that the
@@ -148,7 +151,7 @@ hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan
 template <typename Real>
 hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
-                         int groups, hipStream_t stream);
+                         int groups, long long n_hint, hipStream_t stream);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

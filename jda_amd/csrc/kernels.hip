@@ -223,9 +223,28 @@ size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real
                : ScanLds<double, false>(pix_bytes, carts, node_n, leaf_n, 512).total;
 }
 
-// One cart of stage 0 for one window: D-1 dependent (node, 2 pixels) reads.  The
-// node table is in LDS; pixels come from the LDS tile (GLB = false) or from the
-// frame through L1/L2 (GLB = true).
+// Feature test of one resolved stage-0 node for the window at `base`: true = go left
+// (feature <= threshold, c/jda.c:391-393).
+template <bool GLB>
+__device__ __forceinline__ bool s0_left(const S0Node r, const uint8_t* __restrict__ pix, int base) {
+  if (!GLB) {
+    const int a = pix[base + (int)(r.lo & 0xffffu)];
+    const int b = pix[base + (int)(r.lo >> 16)];
+    return a - b <= (int)r.hi;
+  }
+  const uint32_t o1 = r.lo & 0x1fffffu;
+  const uint32_t o2 = __builtin_amdgcn_alignbit(r.hi, r.lo, 21) & 0x1fffffu;
+  const int a = pix[base + (int)o1];
+  const int b = pix[base + (int)o2];
+  return a - b + 256 <= (int)(r.hi >> 10);
+}
+
+// One cart of stage 0 for one window -> node index reached below the last split level:
+// D-1 dependent (node record, 2 pixels) reads.  The node table is in LDS; pixels come
+// from the LDS tile (GLB = false) or from the frame through L1/L2 (GLB = true).
+// (Testing the root and both children at once -- 2 dependent round trips instead of 3,
+// 8 pixel reads instead of 6 -- was measured 15 % SLOWER: the kernel is sensitive to LDS
+// instruction count, see DESIGN.md.)
 template <int DEPTH, bool GLB>
 __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const uint8_t* __restrict__ pix,
                                          int base, int depth_rt) {
@@ -234,17 +253,7 @@ __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const u
 #pragma unroll
   for (int d = 0; d < levels; d++) {
     const S0Node r = tbl[node];
-    if (!GLB) {
-      const int a = pix[base + (int)(r.lo & 0xffffu)];
-      const int b = pix[base + (int)(r.lo >> 16)];
-      node = 2 * node + ((a - b <= (int)r.hi) ? 1 : 2);     // c/jda.c:391-393
-    } else {
-      const uint32_t o1 = r.lo & 0x1fffffu;
-      const uint32_t o2 = __builtin_amdgcn_alignbit(r.hi, r.lo, 21) & 0x1fffffu;
-      const int a = pix[base + (int)o1];
-      const int b = pix[base + (int)o2];
-      node = 2 * node + ((a - b + 256 <= (int)(r.hi >> 10)) ? 1 : 2);
-    }
+    node = 2 * node + (s0_left<GLB>(r, pix, base) ? 1 : 2);
   }
   return node;
 }
@@ -291,6 +300,15 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
+#ifdef JDA_SCAN_TIMING
+  unsigned long long stamps[12];
+  int n_stamp = 0;
+  int items_at[12];
+#define JDA_STAMP(v) do { if (n_stamp < 12) { items_at[n_stamp] = (v); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define JDA_STAMP(v) do { } while (0)
+#endif
+  JDA_STAMP(0);
 
   // XCD-aware block -> (frame, tile): blocks b, b+8, b+16.. land on one XCD
   // (MI355X dispatches block b to XCD b % 8), so the 8 frames of a group each
@@ -370,6 +388,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   }
   if (tid == 0) { misc[0] = 0; misc[1] = 0; }
   __syncthreads();
+  JDA_STAMP(lv.tw * lv.th);
 
   const int n_tile = lv.tw * lv.th;      // phase 0 enumerates the full tile; edge windows are filtered
   int n_items = n_tile;
@@ -528,6 +547,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
     cur ^= 1;
     n_items = misc[cur];
     c0 = c1;
+    JDA_STAMP(n_items);
     if (n_items == 0) break;
     if (tid == 0) misc[cur ^ 1] = 0;     // next phase's output counter; readers of it are past the barrier
     __syncthreads();
@@ -568,6 +588,14 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
     atomicAdd(shard_counter(w.counters, kCntCartsScan), sv + sh);
     atomicAdd(shard_counter(w.counters, kCntWinScan), (unsigned long long)(twe * the));
   }
+#ifdef JDA_SCAN_TIMING
+  JDA_STAMP(-1);
+  if (tid == 0 && w.dbg && blockIdx.x < 65536) {
+    unsigned long long* o = w.dbg + (size_t)blockIdx.x * 32;
+    o[0] = (unsigned long long)n_stamp | ((unsigned long long)level << 32);
+    for (int i = 0; i < n_stamp; i++) { o[1 + i] = stamps[i]; o[16 + i] = (unsigned long long)(long long)items_at[i]; }
+  }
+#endif
 }
 
 template <typename Real, bool TRACE>
@@ -964,15 +992,19 @@ namespace {
 template <typename DL>
 hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th, typename DL::Real th,
                               const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
-                              const WorkT<typename DL::Real>& w, int groups, hipStream_t stream) {
+                              const WorkT<typename DL::Real>& w, int groups, long long n_hint, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
   const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 7) & ~7) * 2 + kMaxStages * sizeof(int);
   const int multi = (w.half != nullptr) ? 1 : 0;
   const float r = 1.f / sqrtf(2.f);
+  // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to
+  // 1M workgroups, grid-stride beyond), so the hardware dispatcher balances the very
+  // uneven per-window cost; n_hint < 0: fixed grid, windows dealt round-robin.
   unsigned blocks = w.cap;
   if (blocks > 256u * 64u) blocks = 256u * 64u;
-  if (blocks == 0) blocks = 1;
+  if (n_hint >= 0) blocks = (unsigned)std::min<long long>(n_hint, 1 << 20);
+  if (blocks == 0) return hipSuccess;
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, t_begin, t_end,
@@ -989,14 +1021,14 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
 template <>
 hipError_t launch_finish<float>(bool trace, int t_begin, int t_end, bool apply_final_th, float final_th,
                                 const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
-                                int groups, hipStream_t stream) {
-  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, stream);
+                                int groups, long long n_hint, hipStream_t stream) {
+  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, stream);
 }
 template <>
 hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_final_th, double final_th,
                                  const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
-                                 int groups, hipStream_t stream) {
-  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, stream);
+                                 int groups, long long n_hint, hipStream_t stream) {
+  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, stream);
 }
 
 // =============================================================================
