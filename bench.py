@@ -111,6 +111,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if not os.path.exists(os.path.join(ROOT, "jda_amd", "libjda.so")) and int(os.environ.get("RANK", "0")) == 0:
+        from jda_amd import build as lib_build      # fresh checkout: compile the library once
+        lib_build.build()
     from jda_amd import api, dist as jdist, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
