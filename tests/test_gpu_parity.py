@@ -344,3 +344,91 @@ def test_deep_wide_model_config5_dims(built, gpu, tmp_path):
     d = c.detect_batch(frames)[0]
     _compare_detect(d, o.detect(frames[0]))
     assert len(d["scores"]) > 0
+
+
+# ---------------------------------------------------------------- randomised sweep
+
+def test_random_configurations_vs_oracle(built, gpu, tmp_path):
+    """40 random (dims, frame size, call arguments, threshold) combinations, both dialects:
+    detections and per-window traces bit-exact against the oracle."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        T = int(rng.integers(1, 5)); K = int(rng.choice([1, 3, 17, 64, 65, 130, 200])); L = int(rng.integers(1, 12))
+        D = int(rng.integers(2, 7))
+        th = float(rng.choice([-3.0e38, -2.0, -0.9, -0.2]))
+        m = synth.make_model(T, K, L, D, seed=100 + case, cart_th=th, norm_every=int(rng.integers(2, 9)),
+                             multi_scale=bool(rng.random() < 0.2), f32_exact=bool(rng.random() < 0.5))
+        p = str(tmp_path / ("r%d.model" % case)); m.save(p, 8 if rng.random() < 0.5 else 4)
+        w, h = int(rng.integers(24, 330)), int(rng.integers(24, 260))
+        frames = synth.make_frames(int(rng.integers(1, 4)), w, h, seed=case)
+        kw = dict(scale=float(rng.choice([1.1, 1.25, 1.5, 2.0])), min_size=int(rng.integers(0, 60)),
+                  max_size=int(rng.choice([-1, 0, 50, 120])))
+        c, o = api.Cascador(p), Oracle(p)
+        _compare_trace(c, o, frames, **kw)
+        fin = float(rng.choice([-10.0, -0.5, 0.3]))
+        dets = c.detect_batch(frames, th=fin, **kw)
+        for i in range(len(frames)):
+            _compare_detect(dets[i], o.detect(frames[i], th=fin, **kw))
+        if not m.scale.any():
+            ckw = dict(minimum_size=int(rng.integers(12, 40)), step=int(rng.integers(2, 9)),
+                       factor=float(rng.choice([1.15, 1.2, 1.5])))
+            if min(w, h) >= ckw["minimum_size"]:
+                _compare_trace_cpp(c, o, frames, **ckw)
+                got = c.detect_batch_cpp(frames, overlap=0.3, nms=True, **ckw)
+                for i in range(len(frames)):
+                    want = o.detect_cpp(frames[i], overlap=0.3, nms=True, **ckw)
+                    for k in want:
+                        assert same(got[i][k], want[k]), (case, k)
+        c.close()
+
+
+# ---------------------------------------------------------------- sizes, strides, passes
+
+def test_4k_frame_and_odd_strides(built, gpu, model_file):
+    """3840x2160 (window offsets no longer fit the packed stage-0 node for the largest levels ->
+    those enter k_finish at cart 0), a padded frame stride and a device pointer that is not
+    4-byte aligned (byte-wise tile staging)."""
+    import ctypes as C
+    import torch
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 24, 5, 4), 8, seed=41, cart_th=0.1, norm_every=5)
+    c, o = api.Cascador(p), Oracle(p)
+    big = synth.make_frames(1, 3840, 2160, seed=42)
+    _compare_trace(c, o, big, scale=1.6, min_size=48)
+    d = c.detect_batch(big, scale=1.6, min_size=48, th=0.6)[0]
+    _compare_detect(d, o.detect(big[0], scale=1.6, min_size=48, th=0.6))
+    assert len(d["scores"]) > 50
+    # padded stride + misaligned base: frames live inside a larger byte buffer at offset 1
+    fr = synth.make_frames(3, 200, 150, seed=43)
+    stride = 200 * 150 + 37
+    flat = torch.zeros(1 + 3 * stride, dtype=torch.uint8, device=gpu)
+    for i in range(3):
+        flat[1 + i * stride: 1 + i * stride + 200 * 150] = torch.from_numpy(fr[i].reshape(-1)).to(gpu)
+    res = (api.jdaResult * 3)()
+    opt = api.jdaDetectOptions(); api.lib.jdaDetectOptionsInit(C.byref(opt))
+    rc = api.lib.jdaDetectBatchDevice(c.h, C.c_void_p(flat.data_ptr() + 1), stride, 3, 200, 150, 1.25, 0.1, 40, -1, -0.5,
+                                      C.byref(opt), res)
+    assert rc == 0, api.last_error()
+    for i in range(3):
+        _compare_detect(api._take(res[i]), o.detect(fr[i]))
+
+
+def test_batch_larger_than_workspace_is_processed_in_passes(built, gpu, model_file, monkeypatch):
+    from jda_amd import api, synth
+    p, _ = model_file((3, 20, 5, 4), 8, seed=44, cart_th=-0.8)
+    frames = synth.make_frames(9, 240, 180, seed=45)
+    want = api.Cascador(p).detect_batch(frames)
+    monkeypatch.setenv("JDA_WORKSPACE_MB", "1")            # ~2 frames per pass
+    c = api.Cascador(p)
+    got, st = c.detect_batch(frames, stats=True)
+    assert st["patch_n"] == 9 * api.count_windows(240, 180)[0]
+    for a, b in zip(got, want):
+        _compare_detect(a, b)
+    tr1 = c.trace(frames)
+    monkeypatch.delenv("JDA_WORKSPACE_MB")
+    tr2 = api.Cascador(p).trace(frames)
+    for k in tr1:
+        assert same(tr1[k], tr2[k]), k
