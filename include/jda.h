@@ -218,6 +218,22 @@ JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames
                               double factor, double overlap, int nms,
                               jdaStats *stats, jdaResultD *out);
 
+/* Dialect CPP, detect method 0 -- the true image pyramid of reference
+ * src/jda/cascador.cpp:216-308 (detectMultiScale + detectSingleScale): a fixed
+ * origin_size x origin_size window (config image_size.origin_size, 48 in the shipped
+ * config) slides with a pixel step over an image that is shrunk by 1/factor per level
+ * ON THE DEVICE with a restatement of cv::resize(INTER_LINEAR); rects are scaled back
+ * with truncating int *= double.  scale==0 models only.  PARITY UNPINNED: cv::resize
+ * itself cannot be compared here (no OpenCV), only its restatement in the oracle. */
+JDA_API int jdaDetectBatchCppPyramid(void *cascador, const unsigned char *const *frames, int n,
+                                     int width, int height, int origin_size, int step,
+                                     double factor, double overlap, int nms,
+                                     jdaStats *stats, jdaResultD *out);
+
+/* The cv::resize(INTER_LINEAR, 8-bit gray) restatement by itself (device kernel), for tests. */
+JDA_API int jdaResizeCv(void *cascador, const unsigned char *data, int width, int height,
+                        unsigned char *out, int out_width, int out_height);
+
 /* Host-only helpers (no GPU needed): the two NMS variants and the model-stream
  * size, exported so that they can be unit-tested and reused.
  * jdaNmsC   : reference c/jda.c:237-316; bboxes are (x,y,size) triples; keep[i]

@@ -104,6 +104,9 @@ def _load():
     lib.jdaResultDRelease.argtypes = [jdaResultD]
     lib.jdaDetectBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    lib.jdaDetectBatchCppPyramid.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    lib.jdaResizeCv.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
     lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
     lib.jdaNmsCpp.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int)]
     lib.jdaResultsPack.argtypes = [C.POINTER(jdaResult), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
@@ -339,6 +342,30 @@ class Cascador:
             raise JdaError(last_error())
         out = [_take_d(res[i]) for i in range(n)]
         return (out, st.asdict()) if stats else out
+
+    def detect_batch_cpp_pyramid(self, frames, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, stats=False):
+        """Dialect CPP, detect method 0: the true image pyramid (reference cascador.cpp:216-308)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, h, w = frames.shape
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        res = (jdaResultD * max(n, 1))()
+        st = jdaStats()
+        rc = lib.jdaDetectBatchCppPyramid(self.h, ptrs, n, w, h, origin_size, step, factor, overlap, 1 if nms else 0,
+                                          C.byref(st), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = [_take_d(res[i]) for i in range(n)]
+        return (out, st.asdict()) if stats else out
+
+    def resize_cv(self, img, out_width, out_height):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((out_height, out_width), np.uint8)
+        if lib.jdaResizeCv(self.h, _u8(img), w, h, _u8(out), out_width, out_height) != 0:
+            raise JdaError(last_error())
+        return out
 
     def trace_cpp(self, frames, minimum_size=20, step=5, factor=1.2):
         frames = np.ascontiguousarray(frames, np.uint8)

@@ -401,10 +401,6 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   const long long wpf = pe->sp.windows;
   const bool want_trace = trace != nullptr;
   const bool multi = hm.multi_scale();
-  if (multi && dialect == JDA_DIALECT_CPP) {
-    fail("dialect CPP supports only scale==0 split nodes (cv::resize is not reproduced; SURVEY.md 8c)");
-    return false;
-  }
   hipStream_t st = user_stream ? user_stream : c->stream;
   if (wpf == 0 || n == 0) return true;
 
@@ -421,8 +417,12 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
 
   int hw = 0, hh = 0, qw = 0, qh = 0;
   if (multi) {
-    const float r = 1.f / sqrtf(2.f);                       // c/jda.c:450-456
-    hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
+    if (dialect == JDA_DIALECT_C) {
+      const float r = 1.f / sqrtf(2.f);                     // c/jda.c:450-456
+      hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
+    } else {
+      hw = (int)(pe->sp.width / std::sqrt(2.)); hh = (int)(pe->sp.height / std::sqrt(2.));   // cascador.cpp:323-324
+    }
     qw = pe->sp.width / 2; qh = pe->sp.height / 2;
     if (hw < 1 || hh < 1 || qw < 1 || qh < 1) { fail("frame too small for the half/quarter images"); return false; }
     if (!ws.pyr.reserve(((size_t)hw * hh + (size_t)qw * qh + 512) * (size_t)fpp)) return false;
@@ -441,8 +441,13 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       const size_t hs = ((size_t)hw * hh + 255) & ~(size_t)255, qs = ((size_t)qw * qh + 255) & ~(size_t)255;
       uint8_t* qbuf = hbuf + hs * (size_t)fpp;
       const int W = pe->sp.width, H = pe->sp.height;
-      JDA_HIP(launch_resize(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, (float)(W - 1) / hw, (float)(H - 1) / hh, st));
-      JDA_HIP(launch_resize(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, (float)(W - 1) / qw, (float)(H - 1) / qh, st));
+      if (dialect == JDA_DIALECT_C) {      // jdaImageResize, c/jda.c:203-230
+        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, (float)(W - 1) / hw, (float)(H - 1) / hh, st));
+        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, (float)(W - 1) / qw, (float)(H - 1) / qh, st));
+      } else {                             // cv::resize, cascador.cpp:330-331
+        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, st));
+        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, st));
+      }
       w.half = hbuf; w.half_stride = hs; w.quarter = qbuf; w.quarter_stride = qs;
     }
     if (want_trace) {
@@ -862,6 +867,125 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   TraceOut<double> tr{carts_n, score, path_hash, shapes};
   RunStats rs;
   if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs)) return -1;
+  return 0;
+}
+
+int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height, unsigned char* out, int ow, int oh) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !data || !out || width <= 0 || height <= 0 || ow <= 0 || oh <= 0) { fail("bad arguments"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!ensure_device(c)) return -1;
+  const unsigned char* frames[1] = {data};
+  size_t stride = 0;
+  if (!stage_frames<double>(c, frames, 1, (size_t)width * height, &stride)) return -1;
+  auto run = [&]() -> bool {
+    if (!c->wd.pyr.reserve((size_t)ow * oh + 256)) return false;
+    JDA_HIP(launch_resize_cv((const uint8_t*)c->wd.frames.p, stride, 1, width, height, (uint8_t*)c->wd.pyr.p,
+                             (size_t)ow * oh, ow, oh, c->stream));
+    JDA_HIP(hipMemcpyAsync(out, c->wd.pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream));
+    JDA_HIP(hipStreamSynchronize(c->stream));
+    return true;
+  };
+  return run() ? 0 : -1;
+}
+
+int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                             int origin_size, int step, double factor, double overlap, int nms,
+                             jdaStats* stats, jdaResultD* out) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  const int L = c->hm.L, dim = c->hm.dim();
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  if (origin_size < 1 || step < 1 || !(factor > 1.0)) { fail("origin_size/step must be positive and factor > 1"); return -1; }
+  if (c->hm.multi_scale()) { fail("method 0 supports only scale==0 split nodes (its per-window half/quarter patches are not reproduced)"); return -1; }
+  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
+  size_t stride0 = 0;
+  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride0)) return -1;
+
+  // per level: rects (already scaled back), scores, normalised shapes, per frame, in scan order
+  struct Cand { int rect[4]; double score; size_t shape_at; };
+  std::vector<std::vector<Cand>> per_frame(n);
+  std::vector<double> shape_pool;
+  RunStats rs_total;
+  long long patch_total = 0;
+  // level images ping-pong inside one buffer; level 0 is the staged input
+  DevBuf levels;
+  const size_t lvl_stride = ((size_t)width * height + 255) & ~(size_t)255;
+  auto body = [&]() -> bool {
+    if (!levels.reserve(2 * lvl_stride * (size_t)std::max(n, 1))) return false;
+    const uint8_t* cur = (const uint8_t*)c->wd.frames.p;
+    size_t cur_stride = stride0;
+    int w = width, h = height, li = 0;
+    double scale = 1.;
+    while (w >= origin_size && h >= origin_size) {               // cascador.cpp:283
+      ScanPlan sp; std::string err;
+      if (!plan_single_level(w, h, origin_size, step, &sp, &err)) { fail(err); return false; }
+      PlanKey key{w, h, 2 /* method 0 level */, origin_size, step, 0, 0ull};
+      PlanEntry* pe = nullptr;
+      if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return false;
+      RawDets<double> dets;
+      RunStats rs;
+      if (!run_device<double>(c, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return false;
+      rs_total.carts += rs.carts; rs_total.out += rs.out; rs_total.gpu_ms += rs.gpu_ms; rs_total.scan_ms += rs.scan_ms;
+      rs_total.carts_scan += rs.carts_scan; rs_total.win_scan += rs.win_scan; rs_total.scan_launches += rs.scan_launches;
+      rs_total.tail += rs.tail;
+      for (int t = 0; t < c->hm.T; t++) rs_total.stage_done[t] += rs.stage_done[t];
+      patch_total += sp.windows * n;
+      for (size_t i = 0; i < dets.gid.size(); i++) {
+        const WinRef wr = locate(sp, dets.gid[i]);
+        Cand cd;
+        int rx = wr.x, ry = wr.y, rw = wr.win, rh = wr.win;
+        rx = (int)(rx * scale); ry = (int)(ry * scale); rw = (int)(rw * scale); rh = (int)(rh * scale);   // cascador.cpp:292-294
+        cd.rect[0] = rx; cd.rect[1] = ry; cd.rect[2] = rw; cd.rect[3] = rh;
+        cd.score = dets.score[i];
+        cd.shape_at = shape_pool.size();
+        shape_pool.insert(shape_pool.end(), dets.shape.begin() + i * dim, dets.shape.begin() + (i + 1) * dim);
+        per_frame[wr.frame].push_back(cd);
+      }
+      scale *= factor;                                            // cascador.cpp:299
+      const int nw = (int)(w / factor), nh = (int)(h / factor);   // cascador.cpp:300-301
+      if (nw < 1 || nh < 1) break;
+      uint8_t* nxt = (uint8_t*)levels.p + (size_t)(li & 1) * lvl_stride * (size_t)n;
+      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, c->stream));   // cascador.cpp:302
+      JDA_HIP(hipStreamSynchronize(c->stream));
+      cur = nxt; cur_stride = lvl_stride; w = nw; h = nh; li++;
+    }
+    return true;
+  };
+  const bool ok = body();
+  levels.release();
+  if (!ok) return -1;
+
+  const double t0 = now_ms();
+  size_t total = 0;
+  for (auto& v : per_frame) total += v.size();
+  parallel_for(n, [&](int f) {
+    const std::vector<Cand>& cs = per_frame[f];
+    const size_t cnt = cs.size();
+    std::vector<int> rc(cnt * 4);
+    std::vector<double> sc(cnt);
+    for (size_t i = 0; i < cnt; i++) { std::memcpy(&rc[4 * i], cs[i].rect, 16); sc[i] = cs[i].score; }
+    std::vector<int> pick;
+    if (nms) pick = nms_dialect_cpp(rc.data(), sc.data(), (int)cnt, overlap);
+    else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
+    jdaResultD& r = out[f];
+    r.n = (int)pick.size(); r.landmark_n = L;
+    r.rects = (int*)std::malloc(std::max<size_t>(1, pick.size() * 4) * sizeof(int));
+    r.scores = (double*)std::malloc(std::max<size_t>(1, pick.size()) * sizeof(double));
+    r.shapes = (double*)std::malloc(std::max<size_t>(1, pick.size() * dim) * sizeof(double));
+    for (size_t i = 0; i < pick.size(); i++) {
+      const int k = pick[i];
+      std::memcpy(r.rects + 4 * i, &rc[4 * k], 4 * sizeof(int));
+      r.scores[i] = sc[k];
+      double* sh = r.shapes + i * dim;
+      std::memcpy(sh, &shape_pool[cs[k].shape_at], dim * sizeof(double));
+      relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
+    }
+  }, total < 20000);
+  fill_stats(stats, rs_total, patch_total, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
 }
 

@@ -126,6 +126,10 @@ hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, i
                          uint8_t* dst, size_t dst_stride, int dw, int dh, float rx, float ry,
                          hipStream_t stream);
 
+// cv::resize(INTER_LINEAR, 8UC1) restatement for dialect CPP (half/quarter images, method-0 pyramid).
+hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
+                            uint8_t* dst, size_t dst_stride, int dw, int dh, hipStream_t stream);
+
 // Resolves stage-0 node offsets for every tiled level (dialect 0 = C, 1 = CPP).
 hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,
                               const void* nodes, const void* mean_shape, int K, int node_n,

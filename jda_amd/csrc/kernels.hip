@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <type_traits>
 
 #include "kernels.h"
@@ -123,6 +124,58 @@ hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, i
   if (dw <= 0 || dh <= 0 || n <= 0) return hipSuccess;
   dim3 block(256), grid((dw + 255) / 256, dh, n);
   hipLaunchKernelGGL(k_resize, grid, block, 0, stream, src, src_stride, sw, sh, dst, dst_stride, dw, dh, rx, ry);
+  return hipGetLastError();
+}
+
+// cv::resize(INTER_LINEAR) for 8-bit single-channel images as dialect CPP uses it for the
+// half/quarter images (cascador.cpp:329-331) and the method-0 pyramid (cascador.cpp:300-303):
+// 11-bit fixed-point bilinear of OpenCV's 2.4/3.x imgwarp.cpp, with its routing of an exact
+// 2x2 down-scale to the box average.  PARITY UNPINNED (no OpenCV here to compare with);
+// bit-exact against the oracle's restatement of the same algorithm.
+__global__ void k_resize_cv(const uint8_t* __restrict__ src, size_t src_stride, int sw, int sh,
+                            uint8_t* __restrict__ dst, size_t dst_stride, int dw, int dh,
+                            double scale_x, double scale_y, int area_fast) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y;
+  const int f = blockIdx.z;
+  if (dx >= dw || dy >= dh) return;
+  const uint8_t* s = src + (size_t)f * src_stride;
+  uint8_t* d = dst + (size_t)f * dst_stride;
+  if (area_fast) {
+    const uint8_t* p = s + (size_t)(2 * dy) * sw + 2 * dx;
+    d[(size_t)dy * dw + dx] = (uint8_t)((p[0] + p[1] + p[sw] + p[sw + 1] + 2) >> 2);
+    return;
+  }
+  float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  const bool edge = sx + 1 >= sw;            // dx >= xmax in OpenCV's loop
+  if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+  float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  auto sat_short = [](float v) { int i = __float2int_rn(v); return i < -32768 ? -32768 : (i > 32767 ? 32767 : i); };
+  const int a0 = sat_short((1.f - fx) * 2048.f), a1 = sat_short(fx * 2048.f);
+  const int b0 = sat_short((1.f - fy) * 2048.f), b1 = sat_short(fy * 2048.f);
+  const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+  const uint8_t* S0 = s + (size_t)y0 * sw;
+  const uint8_t* S1 = s + (size_t)y1 * sw;
+  int r0, r1;
+  if (!edge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
+  else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }
+  d[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
+                            uint8_t* dst, size_t dst_stride, int dw, int dh, hipStream_t stream) {
+  if (dw <= 0 || dh <= 0 || n <= 0) return hipSuccess;
+  const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  const int area = (fabs(scale_x - 2.) < 2.220446049250313e-16 && fabs(scale_y - 2.) < 2.220446049250313e-16) ? 1 : 0;
+  dim3 block(256), grid((dw + 255) / 256, dh, n);
+  hipLaunchKernelGGL(k_resize_cv, grid, block, 0, stream, src, src_stride, sw, sh, dst, dst_stride, dw, dh,
+                     scale_x, scale_y, area);
   return hipGetLastError();
 }
 
@@ -701,6 +754,7 @@ namespace {
 // Where a window reads its pixels for one feature scale.
 struct View {
   const uint8_t* img; int w, h, ox, oy;
+  int pw;   // side of the patch the feature coordinates are scaled by and clamped to
 };
 
 // Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
@@ -711,18 +765,26 @@ __device__ __forceinline__ int node_feature(const typename DL::Node& nd, const t
   using Real = typename DL::Real;
   const Real s1x = sh[nd.lm1x2], s1y = sh[nd.lm1x2 + 1];
   const Real s2x = sh[nd.lm2x2], s2y = sh[nd.lm2x2 + 1];
-  const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
-  const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
-  const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win);
-  const int y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
   if (!multi) {
+    const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
+    const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
+    const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win);
+    const int y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
     const int a = v0.img[(size_t)(v0.oy + y1) * v0.w + v0.ox + x1];
     const int b = v0.img[(size_t)(v0.oy + y2) * v0.w + v0.ox + x2];
     return a - b;
   }
-  // scale != 0: the reference indexes the half/quarter image with full-window
-  // coordinates (c/jda.c:347-354) and may leave it; reads are clamped to the image.
+  // Multi-scale models.  Dialect C scales and clamps with the FULL window side for
+  // every scale (c/jda.c:347-354: ps[1].w = ps[2].w = win_size) and can therefore
+  // leave the half/quarter image: reads are clamped to the image (documented
+  // divergence from its out-of-bounds reads).  Dialect CPP uses each patch's own
+  // size (data.cpp:37-51), which always stays inside the image.
   const View& v = nd.scale == 0 ? v0 : (nd.scale == 1 ? v1 : v2);
+  const int pw = v.pw;
+  const int x1 = clamp_win(DL::coord(s1x, nd.o1x, pw), pw);
+  const int y1 = clamp_win(DL::coord(s1y, nd.o1y, pw), pw);
+  const int x2 = clamp_win(DL::coord(s2x, nd.o2x, pw), pw);
+  const int y2 = clamp_win(DL::coord(s2y, nd.o2y, pw), pw);
   const int gx1 = min(v.ox + x1, v.w - 1), gy1 = min(v.oy + y1, v.h - 1);
   const int gx2 = min(v.ox + x2, v.w - 1), gy2 = min(v.oy + y2, v.h - 1);
   const int a = v.img[(size_t)gy1 * v.w + gx1];
@@ -742,11 +804,20 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   const int x = ix * lv->step, y = iy * lv->step;
   *win = lv->win;
   v0->img = w.frames + (size_t)frame * w.frame_stride; v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
+  v0->pw = lv->win;
   if (multi) {
     v1->img = w.half + (size_t)frame * w.half_stride; v1->w = w.hw; v1->h = w.hh;
-    v1->ox = (int)((float)x * inv_sqrt2); v1->oy = (int)((float)y * inv_sqrt2);      // c/jda.c:345-346
     v2->img = w.quarter + (size_t)frame * w.quarter_stride; v2->w = w.qw; v2->h = w.qh;
-    v2->ox = x / 2; v2->oy = y / 2;                                                    // c/jda.c:351-352
+    if (sizeof(Real) == 4) {
+      // dialect C, c/jda.c:345-354: origins by float multiply / integer halving, full-size patches
+      v1->ox = (int)((float)x * inv_sqrt2); v1->oy = (int)((float)y * inv_sqrt2); v1->pw = lv->win;
+      v2->ox = x / 2; v2->oy = y / 2; v2->pw = lv->win;
+    } else {
+      // dialect CPP, cascador.cpp:340-343: Rect(int(x/r), int(y/r), int(win/r), ..), r = sqrt(2.) in double
+      const double r = sqrt(2.0);
+      v1->ox = (int)((double)x / r); v1->oy = (int)((double)y / r); v1->pw = (int)((double)lv->win / r);
+      v2->ox = x / 2; v2->oy = y / 2; v2->pw = lv->win / 2;
+    }
   }
 }
 

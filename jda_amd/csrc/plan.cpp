@@ -65,4 +65,16 @@ bool plan_dialect_cpp(int width, int height, int minimum_size, int step, double 
   return true;
 }
 
+bool plan_single_level(int width, int height, int win, int step, ScanPlan* plan, std::string* err) {
+  ScanPlan p;
+  p.width = width; p.height = height;
+  if (width <= 0 || height <= 0 || win < 1 || step < 1 || win > width || win > height) {
+    if (err) *err = "level image smaller than the window, or bad window/step";
+    return false;
+  }
+  push_level(&p, win, step);                               // cascador.cpp:221-226,260
+  *plan = std::move(p);
+  return true;
+}
+
 }  // namespace jda

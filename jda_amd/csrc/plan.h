@@ -32,4 +32,8 @@ bool plan_dialect_c(int width, int height, float scale, int min_size, int max_si
 bool plan_dialect_cpp(int width, int height, int minimum_size, int step, double factor,
                       ScanPlan* plan, std::string* err);
 
+// One pyramid level of dialect CPP's method 0 (reference src/jda/cascador.cpp:216-262,
+// detectSingleScale): a fixed win x win window slid with a pixel step over a level image.
+bool plan_single_level(int width, int height, int win, int step, ScanPlan* plan, std::string* err);
+
 }  // namespace jda

@@ -8,12 +8,14 @@
  * What it restates (each function cites the reference lines it follows):
  *   dialect C   -- reference c/jda.c (fp32, truncating coordinates)
  *   dialect CPP -- reference src/jda/{cascador,cart,data,btcart}.cpp (fp64,
- *                  round() coordinates), restricted to scale==0 split nodes
- *                  and similarity transform off (the shipped configuration;
- *                  see SURVEY.md 8c for why the rest is unpinned)
+ *                  round() coordinates), similarity transform off (the shipped
+ *                  configuration); detect method 1 (growing window) and method 0
+ *                  (true image pyramid); half/quarter images and pyramid levels
+ *                  through a restatement of cv::resize (see SURVEY.md 8c for why
+ *                  all of dialect CPP is unpinned)
  *
  * Pinning: dialect C is checked bit-for-bit against the reference's own
- * c/jda.c compiled from /root/reference (oracle/_ref, see oracle/Makefile)
+ * c/jda.c compiled from /root/reference (oracle/_ref, see oracle/build.py)
  * by tests/test_oracle_vs_reference.py, and against the golden vectors under
  * tests/golden/ that were produced by that build.  Dialect CPP cannot be
  * compiled here (needs OpenCV/jsmnpp/liblinear): PARITY UNPINNED for it; it
@@ -172,6 +174,76 @@ void orc_pyramid_dims(int w, int h, int *hw, int *hh, int *qw, int *qh) {
   const float r = 1.f / sqrtf(2.f); /* c/jda.c:450-456 */
   *hw = (int)(w * r); *hh = (int)(h * r);
   *qw = w / 2; *qh = h / 2;
+}
+
+/* ------------------------------------------------------- cv::resize (8UC1) */
+
+/* Restatement of OpenCV's cv::resize(src, dst, Size(dw,dh)) for CV_8UC1 with the
+ * default INTER_LINEAR, as dialect CPP uses it (reference cascador.cpp:300-303,
+ * 329-331): fixed-point bilinear with 11-bit coefficients
+ * (imgproc/src/imgwarp.cpp of the 2.4/3.x line the reference targets, README.md:30),
+ * including the switch to the 2x2 box average when both scale factors are exactly 2.
+ * PARITY UNPINNED: there is no OpenCV in this container to check it against. */
+static int orc_cv_round(double v) { return (int)lrint(v); }          /* cvRound: round half to even */
+static short orc_sat_short(float v) { int i = orc_cv_round(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); }
+
+void orc_resize_cv(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh) {
+  const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  const int isx = (int)scale_x, isy = (int)scale_y;     /* saturate_cast<int>(double) rounds; exact for 2.0 */
+  if (fabs(scale_x - 2.) < 2.220446049250313e-16 && fabs(scale_y - 2.) < 2.220446049250313e-16 && isx == 2 && isy == 2) {
+    /* INTER_LINEAR with scale exactly 2 in both directions is routed to the fast INTER_AREA path */
+    for (int y = 0; y < dh; y++)
+      for (int x = 0; x < dw; x++) {
+        const unsigned char *p = src + (size_t)(2 * y) * sw + 2 * x;
+        dst[(size_t)y * dw + x] = (unsigned char)((p[0] + p[1] + p[sw] + p[sw + 1] + 2) >> 2);
+      }
+    return;
+  }
+  int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+  short *ialpha = (short *)malloc(sizeof(short) * 2 * dw), *ibeta = (short *)malloc(sizeof(short) * 2 * dh);
+  int xmax = dw;
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx + 1 >= sw) { if (dx < xmax) xmax = dx; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = orc_sat_short((1.f - fx) * 2048.f);
+    ialpha[2 * dx + 1] = orc_sat_short(fx * 2048.f);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    ibeta[2 * dy] = orc_sat_short((1.f - fy) * 2048.f);
+    ibeta[2 * dy + 1] = orc_sat_short(fy * 2048.f);
+  }
+  int *row0 = (int *)malloc(sizeof(int) * dw), *row1 = (int *)malloc(sizeof(int) * dw);
+  for (int dy = 0; dy < dh; dy++) {
+    int sy0 = yofs[dy], sy1 = yofs[dy] + 1;
+    if (sy0 < 0) sy0 = 0;
+    if (sy0 > sh - 1) sy0 = sh - 1;
+    if (sy1 < 0) sy1 = 0;
+    if (sy1 > sh - 1) sy1 = sh - 1;
+    const unsigned char *S0 = src + (size_t)sy0 * sw, *S1 = src + (size_t)sy1 * sw;
+    for (int dx = 0; dx < dw; dx++) {
+      const int sx = xofs[dx];
+      if (dx < xmax) {
+        row0[dx] = S0[sx] * ialpha[2 * dx] + S0[sx + 1] * ialpha[2 * dx + 1];
+        row1[dx] = S1[sx] * ialpha[2 * dx] + S1[sx + 1] * ialpha[2 * dx + 1];
+      } else {
+        row0[dx] = S0[sx] * 2048;
+        row1[dx] = S1[sx] * 2048;
+      }
+    }
+    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    for (int dx = 0; dx < dw; dx++)
+      dst[(size_t)dy * dw + dx] = (unsigned char)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs); free(yofs); free(ialpha); free(ibeta); free(row0); free(row1);
 }
 
 /* ------------------------------------------------------------ enumeration */
@@ -464,7 +536,13 @@ long long orc_count_windows_cpp(int w, int h, int minimum_size, int step, double
  * (round half away from zero, clamp common.hpp:227-232); delta shape summed
  * from zero then added, btcart.cpp:407-424.  Apply() with the identity
  * parameter is written out (1*(1*x+0*y)) because it is not a no-op for -0. */
-static int orc_walk_cpp(const orc_model *m, const unsigned char *img, int iw, int x, int y, int win,
+typedef struct {
+  const unsigned char *data; int iw;   /* image and its row stride          */
+  int ox, oy;                          /* patch origin inside that image    */
+  int pw;                              /* patch width == height             */
+} orc_patch;
+
+static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
                         double *shape, double *delta, int *lbf, double *score_out, unsigned *hash_out, int *alive) {
   const int dim = m->dim, node_n = m->node_n, leaf_n = m->leaf_n;
   double score = 0.;
@@ -481,24 +559,27 @@ static int orc_walk_cpp(const orc_model *m, const unsigned char *img, int iw, in
       int at = 0; /* 0-based position in the stored node array == reference idx-1 */
       for (int d = 0; d < m->D - 1; d++) {
         const orc_node *nd = &m->nodes[c * node_n + at];
+        const orc_patch *q = &pt[nd->scale];                    /* data.cpp:21-34 */
+        const int width = q->pw, height = q->pw;                /* data.cpp:37-38: the PATCH's size */
         const double o1x = 1. * (1. * nd->off[0] + 0. * nd->off[1]);
         const double o1y = 1. * (0. * nd->off[0] + 1. * nd->off[1]);
         const double o2x = 1. * (1. * nd->off[2] + 0. * nd->off[3]);
         const double o2y = 1. * (0. * nd->off[2] + 1. * nd->off[3]);
-        const double x1 = (shape[2 * nd->lm1] + o1x) * win;
-        const double y1 = (shape[2 * nd->lm1 + 1] + o1y) * win;
-        const double x2 = (shape[2 * nd->lm2] + o2x) * win;
-        const double y2 = (shape[2 * nd->lm2 + 1] + o2y) * win;
+        const double x1 = (shape[2 * nd->lm1] + o1x) * width;
+        const double y1 = (shape[2 * nd->lm1 + 1] + o1y) * height;
+        const double x2 = (shape[2 * nd->lm2] + o2x) * width;
+        const double y2 = (shape[2 * nd->lm2 + 1] + o2y) * height;
         int ix1 = (int)round(x1), iy1 = (int)round(y1), ix2 = (int)round(x2), iy2 = (int)round(y2);
         if (ix1 < 0) ix1 = 0;
         if (iy1 < 0) iy1 = 0;
-        if (ix1 >= win) ix1 = win - 1;
-        if (iy1 >= win) iy1 = win - 1;
+        if (ix1 >= width) ix1 = width - 1;
+        if (iy1 >= height) iy1 = height - 1;
         if (ix2 < 0) ix2 = 0;
         if (iy2 < 0) iy2 = 0;
-        if (ix2 >= win) ix2 = win - 1;
-        if (iy2 >= win) iy2 = win - 1;
-        const int val = (int)img[(size_t)(y + iy1) * iw + x + ix1] - (int)img[(size_t)(y + iy2) * iw + x + ix2];
+        if (ix2 >= width) ix2 = width - 1;
+        if (iy2 >= height) iy2 = height - 1;
+        const int val = (int)q->data[(size_t)(q->oy + iy1) * q->iw + q->ox + ix1] -
+                        (int)q->data[(size_t)(q->oy + iy2) * q->iw + q->ox + ix2];
         /* reference is 1-based: left child 2i, right 2i+1; 0-based: 2i+1 / 2i+2 */
         at = 2 * at + (val <= nd->th ? 1 : 2);
       }
@@ -528,10 +609,37 @@ static int orc_walk_cpp(const orc_model *m, const unsigned char *img, int iw, in
   return n;
 }
 
+/* The three images of detectMultiScale1 (cascador.cpp:319-331) and the three
+ * patches of one window (cascador.cpp:340-353). */
+typedef struct { unsigned char *half, *quarter; int hw, hh, qw, qh; } orc_pyr_cpp;
+
+static void orc_pyr_cpp_build(const orc_model *m, const unsigned char *img, int w, int h, orc_pyr_cpp *p);
+static int orc_has_multiscale(const orc_model *m);
+
+static void orc_patches_cpp(const unsigned char *img, int w, const orc_pyr_cpp *p, int x, int y, int win, orc_patch *pt) {
+  const double r = sqrt(2.);
+  pt[0].data = img; pt[0].iw = w; pt[0].ox = x; pt[0].oy = y; pt[0].pw = win;
+  pt[1].data = p->half; pt[1].iw = p->hw; pt[1].ox = (int)(x / r); pt[1].oy = (int)(y / r); pt[1].pw = (int)(win / r);
+  pt[2].data = p->quarter; pt[2].iw = p->qw; pt[2].ox = x / 2; pt[2].oy = y / 2; pt[2].pw = win / 2;
+}
+
 static int orc_has_multiscale(const orc_model *m) {
   for (long long i = 0; i < (long long)m->T * m->K * m->node_n; i++)
     if (m->nodes[i].scale != 0) return 1;
   return 0;
+}
+
+void orc_resize_cv(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh);
+
+static void orc_pyr_cpp_build(const orc_model *m, const unsigned char *img, int w, int h, orc_pyr_cpp *p) {
+  p->half = p->quarter = NULL;
+  p->hw = (int)(w / sqrt(2.)); p->hh = (int)(h / sqrt(2.));       /* cascador.cpp:323-326 */
+  p->qw = w / 2; p->qh = h / 2;
+  if (!orc_has_multiscale(m)) return;                             /* the images are only read by scale!=0 nodes */
+  p->half = (unsigned char *)malloc((size_t)(p->hw > 0 ? p->hw : 1) * (p->hh > 0 ? p->hh : 1));
+  p->quarter = (unsigned char *)malloc((size_t)(p->qw > 0 ? p->qw : 1) * (p->qh > 0 ? p->qh : 1));
+  if (p->hw > 0 && p->hh > 0) orc_resize_cv(img, w, h, p->half, p->hw, p->hh);
+  if (p->qw > 0 && p->qh > 0) orc_resize_cv(img, w, h, p->quarter, p->qw, p->qh);
 }
 
 long long orc_trace_cpp(const orc_model *m, const unsigned char *img, int w, int h,
@@ -540,7 +648,9 @@ long long orc_trace_cpp(const orc_model *m, const unsigned char *img, int w, int
   orc_level lv[256];
   long long tot = 0;
   const int nl = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
-  if (nl < 0 || orc_has_multiscale(m)) return -1;
+  if (nl < 0) return -1;
+  orc_pyr_cpp pyr;
+  orc_pyr_cpp_build(m, img, w, h, &pyr);
   double *shape = (double *)malloc(sizeof(double) * m->dim);
   double *delta = (double *)malloc(sizeof(double) * m->dim);
   int *lbf = (int *)malloc(sizeof(int) * m->K);
@@ -549,14 +659,15 @@ long long orc_trace_cpp(const orc_model *m, const unsigned char *img, int w, int
     for (int iy = 0; iy < lv[l].ny; iy++)
       for (int ix = 0; ix < lv[l].nx; ix++, id++) {
         double s; unsigned hsh; int alive;
-        const int n = orc_walk_cpp(m, img, w, ix * lv[l].step, iy * lv[l].step, lv[l].win,
-                                   shape, delta, lbf, &s, &hsh, &alive);
+        orc_patch pt[3];
+        orc_patches_cpp(img, w, &pyr, ix * lv[l].step, iy * lv[l].step, lv[l].win, pt);
+        const int n = orc_walk_cpp(m, pt, shape, delta, lbf, &s, &hsh, &alive);
         if (carts_n) carts_n[id] = n;
         if (score) score[id] = s;
         if (path_hash) path_hash[id] = hsh;
         if (shapes) memcpy(shapes + (size_t)id * m->dim, shape, sizeof(double) * m->dim);
       }
-  free(shape); free(delta); free(lbf);
+  free(shape); free(delta); free(lbf); free(pyr.half); free(pyr.quarter);
   return tot;
 }
 
@@ -597,34 +708,11 @@ static int orc_nms_cpp(const int *r, const double *sc, int n, double overlap, in
   return np;
 }
 
-/* JoinCascador::Detect with method 1 (cascador.cpp:431-477). Outputs sized per
- * window count. rects are (x,y,w,h). Returns detections. */
-int orc_detect_cpp(const orc_model *m, const unsigned char *img, int w, int h,
-                   int minimum_size, int step, double factor, double overlap, int do_nms,
-                   int *rects, double *scores, double *shapes) {
-  orc_level lv[256];
-  long long tot = 0;
-  const int nl = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
-  if (nl < 0 || orc_has_multiscale(m)) return -1;
-  double *shape = (double *)malloc(sizeof(double) * m->dim);
-  double *delta = (double *)malloc(sizeof(double) * m->dim);
-  int *lbf = (int *)malloc(sizeof(int) * m->K);
-  int *r0 = (int *)malloc(sizeof(int) * 4 * (tot > 0 ? tot : 1));
-  double *s0 = (double *)malloc(sizeof(double) * (tot > 0 ? tot : 1));
-  double *h0 = (double *)malloc(sizeof(double) * m->dim * (tot > 0 ? tot : 1));
-  int n = 0;
-  for (int l = 0; l < nl; l++)
-    for (int iy = 0; iy < lv[l].ny; iy++)
-      for (int ix = 0; ix < lv[l].nx; ix++) {
-        double s; unsigned hsh; int alive;
-        const int x = ix * lv[l].step, y = iy * lv[l].step;
-        (void)orc_walk_cpp(m, img, w, x, y, lv[l].win, shape, delta, lbf, &s, &hsh, &alive);
-        if (!alive) continue;
-        r0[4 * n] = x; r0[4 * n + 1] = y; r0[4 * n + 2] = lv[l].win; r0[4 * n + 3] = lv[l].win;
-        s0[n] = s;
-        memcpy(h0 + (size_t)n * m->dim, shape, sizeof(double) * m->dim);
-        n++;
-      }
+static int orc_nms_cpp(const int *r, const double *sc, int n, double overlap, int *picked);
+
+/* Picks, relocates and writes the final lists of Detect (cascador.cpp:443-476). */
+static int orc_finish_cpp(const orc_model *m, const int *r0, const double *s0, const double *h0, int n,
+                          double overlap, int do_nms, int *rects, double *scores, double *shapes) {
   int *picked = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
   int np;
   if (do_nms) np = orc_nms_cpp(r0, s0, n, overlap, picked);
@@ -640,6 +728,110 @@ int orc_detect_cpp(const orc_model *m, const unsigned char *img, int w, int h,
       dst[2 * j + 1] = r0[4 * p + 1] + src[2 * j + 1] * r0[4 * p + 3];
     }
   }
-  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(picked);
+  free(picked);
+  return np;
+}
+
+/* JoinCascador::Detect with method 1 (cascador.cpp:431-477). Outputs sized per
+ * window count. rects are (x,y,w,h). Returns detections. */
+int orc_detect_cpp(const orc_model *m, const unsigned char *img, int w, int h,
+                   int minimum_size, int step, double factor, double overlap, int do_nms,
+                   int *rects, double *scores, double *shapes) {
+  orc_level lv[256];
+  long long tot = 0;
+  const int nl = orc_levels_cpp(w, h, minimum_size, step, factor, lv, 256, &tot);
+  if (nl < 0) return -1;
+  orc_pyr_cpp pyr;
+  orc_pyr_cpp_build(m, img, w, h, &pyr);
+  double *shape = (double *)malloc(sizeof(double) * m->dim);
+  double *delta = (double *)malloc(sizeof(double) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  int *r0 = (int *)malloc(sizeof(int) * 4 * (tot > 0 ? tot : 1));
+  double *s0 = (double *)malloc(sizeof(double) * (tot > 0 ? tot : 1));
+  double *h0 = (double *)malloc(sizeof(double) * m->dim * (tot > 0 ? tot : 1));
+  int n = 0;
+  for (int l = 0; l < nl; l++)
+    for (int iy = 0; iy < lv[l].ny; iy++)
+      for (int ix = 0; ix < lv[l].nx; ix++) {
+        double s; unsigned hsh; int alive;
+        const int x = ix * lv[l].step, y = iy * lv[l].step;
+        orc_patch pt[3];
+        orc_patches_cpp(img, w, &pyr, x, y, lv[l].win, pt);
+        (void)orc_walk_cpp(m, pt, shape, delta, lbf, &s, &hsh, &alive);
+        if (!alive) continue;
+        r0[4 * n] = x; r0[4 * n + 1] = y; r0[4 * n + 2] = lv[l].win; r0[4 * n + 3] = lv[l].win;
+        s0[n] = s;
+        memcpy(h0 + (size_t)n * m->dim, shape, sizeof(double) * m->dim);
+        n++;
+      }
+  const int np = orc_finish_cpp(m, r0, s0, h0, n, overlap, do_nms, rects, scores, shapes);
+  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(pyr.half); free(pyr.quarter);
+  return np;
+}
+
+/* Method 0, the true image pyramid: detectMultiScale + detectSingleScale
+ * (cascador.cpp:216-308).  A fixed origin_size x origin_size window slides with a
+ * pixel step over an image that is shrunk by 1/factor per level with cv::resize
+ * (cumulatively, cascador.cpp:300-303); the per-window cv::resize to
+ * origin_size is the identity (same size); rects are scaled back with truncating
+ * int *= double (cascador.cpp:290-295).  scale==0 models only (the per-window
+ * half/quarter patches of this method are not reproduced).
+ * max_windows bounds the output arrays; returns detections or -1. */
+long long orc_count_windows_pyramid(int w, int h, int origin_size, int step, double factor, int *n_levels) {
+  if (origin_size < 1 || step < 1 || !(factor > 1.0)) return -1;
+  long long tot = 0;
+  int nl = 0;
+  while (w >= origin_size && h >= origin_size) {
+    tot += (long long)((w - origin_size) / step + 1) * ((h - origin_size) / step + 1);
+    nl++;
+    w = (int)(w / factor); h = (int)(h / factor);
+    if (nl > 4096) return -1;
+  }
+  if (n_levels) *n_levels = nl;
+  return tot;
+}
+
+int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, int h,
+                           int origin_size, int step, double factor, double overlap, int do_nms,
+                           int *rects, double *scores, double *shapes) {
+  if (orc_has_multiscale(m)) return -1;
+  int nl = 0;
+  const long long tot = orc_count_windows_pyramid(w, h, origin_size, step, factor, &nl);
+  if (tot < 0) return -1;
+  double *shape = (double *)malloc(sizeof(double) * m->dim);
+  double *delta = (double *)malloc(sizeof(double) * m->dim);
+  int *lbf = (int *)malloc(sizeof(int) * m->K);
+  int *r0 = (int *)malloc(sizeof(int) * 4 * (tot > 0 ? tot : 1));
+  double *s0 = (double *)malloc(sizeof(double) * (tot > 0 ? tot : 1));
+  double *h0 = (double *)malloc(sizeof(double) * m->dim * (tot > 0 ? tot : 1));
+  unsigned char *cur = (unsigned char *)malloc((size_t)w * h);
+  memcpy(cur, img, (size_t)w * h);
+  int width = w, height = h, n = 0;
+  double scale = 1.;
+  while (width >= origin_size && height >= origin_size) {
+    for (int y = 0; y <= height - origin_size; y += step)
+      for (int x = 0; x <= width - origin_size; x += step) {
+        double s; unsigned hsh; int alive;
+        orc_patch pt[3];
+        pt[0].data = cur; pt[0].iw = width; pt[0].ox = x; pt[0].oy = y; pt[0].pw = origin_size;
+        pt[1] = pt[0]; pt[2] = pt[0];
+        (void)orc_walk_cpp(m, pt, shape, delta, lbf, &s, &hsh, &alive);
+        if (!alive) continue;
+        int rx = x, ry = y, rw = origin_size, rh = origin_size;
+        rx *= scale; ry *= scale; rw *= scale; rh *= scale;      /* cascador.cpp:292-294 */
+        r0[4 * n] = rx; r0[4 * n + 1] = ry; r0[4 * n + 2] = rw; r0[4 * n + 3] = rh;
+        s0[n] = s;
+        memcpy(h0 + (size_t)n * m->dim, shape, sizeof(double) * m->dim);
+        n++;
+      }
+    scale *= factor;
+    const int nw = (int)(width / factor), nh = (int)(height / factor);
+    if (nw < 1 || nh < 1) break;
+    unsigned char *nxt = (unsigned char *)malloc((size_t)nw * nh);
+    orc_resize_cv(cur, width, height, nxt, nw, nh);
+    free(cur); cur = nxt; width = nw; height = nh;
+  }
+  const int np = orc_finish_cpp(m, r0, s0, h0, n, overlap, do_nms, rects, scores, shapes);
+  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(cur);
   return np;
 }

@@ -320,30 +320,67 @@ def test_dialects_agree_where_they_must(built, gpu, model_file):
     assert (a["carts_n"] == 16).all() and (b["carts_n"] == 16).all()
 
 
-def test_dialect_cpp_rejects_multiscale(built, gpu, model_file):
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 452, 339), (640, 480, 320, 240), (131, 97, 92, 68), (100, 80, 100, 80),
+                                         (97, 131, 48, 65), (60, 40, 90, 70), (450, 337, 375, 280), (33, 21, 1, 1)])
+def test_cv_resize_kernel_vs_oracle(built, gpu, model_file, sw, sh, dw, dh):
+    """Device restatement of cv::resize(INTER_LINEAR) == the oracle's (both UNPINNED against
+    OpenCV itself): general bilinear, the exact-2x box path, identity, up-scaling."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((2, 8, 5, 3), 8)
+    img = synth.make_frames(1, sw, sh, seed=sw + dh)[0]
+    got, want = api.Cascador(p).resize_cv(img, dw, dh), Oracle(p).resize_cv(img, dw, dh)
+    assert np.array_equal(got, want)
+    if (sw, sh) == (dw, dh):
+        assert np.array_equal(got, img)                          # same-size resize is the identity
+
+
+def test_dialect_cpp_multiscale_method1(built, gpu, model_file):
+    """scale != 0 nodes in dialect CPP: half/quarter images by cv::resize on the device, patches
+    (int(x/r), int(y/r), int(win/r)) and (x/2, y/2, win/2), coordinates scaled by the PATCH size
+    (cascador.cpp:329-353, data.cpp:21-51)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 20, 5, 4), 8, seed=24, cart_th=-0.9, multi_scale=True, f32_exact=False)
+    frames = synth.make_frames(2, 200, 150, seed=34)
+    c, o = api.Cascador(p), Oracle(p)
+    kw = dict(minimum_size=20, step=5, factor=1.2)
+    _compare_trace_cpp(c, o, frames, **kw)
+    got = c.detect_batch_cpp(frames, overlap=0.3, nms=True, **kw)
+    for i in range(2):
+        want = o.detect_cpp(frames[i], overlap=0.3, nms=True, **kw)
+        for k in want:
+            assert same(got[i][k], want[k]), k
+        assert len(want["scores"]) > 0
+
+
+@pytest.mark.parametrize("size,origin,step,factor", [((200, 150), 48, 5, 1.2), ((131, 97), 24, 3, 1.3), ((320, 240), 48, 8, 1.5)])
+def test_dialect_cpp_method0_true_pyramid(built, gpu, model_file, size, origin, step, factor):
+    """detectMultiScale + detectSingleScale (cascador.cpp:216-308): pyramid levels built on the
+    device by repeated cv::resize, fixed window, rects scaled back with truncation."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 20, 5, 4), 8, seed=25, cart_th=-0.7, norm_every=6, f32_exact=False)
+    frames = synth.make_frames(3, size[0], size[1], seed=35)
+    c, o = api.Cascador(p), Oracle(p)
+    for nms in (True, False):
+        got, st = c.detect_batch_cpp_pyramid(frames, origin, step, factor, 0.3, nms, stats=True)
+        tot = 0
+        for i in range(len(frames)):
+            want = o.detect_cpp_pyramid(frames[i], origin, step, factor, 0.3, nms)
+            for k in ("rects", "scores", "shapes"):
+                assert same(got[i][k], want[k]), (nms, i, k)
+            tot += want["windows"]
+        assert st["patch_n"] == tot
+    assert sum(len(g["scores"]) for g in got) > 0
+
+
+def test_method0_rejects_multiscale(built, gpu, model_file):
     from jda_amd import api, synth
     p, _ = model_file((2, 8, 5, 3), 8, seed=24, multi_scale=True)
     c = api.Cascador(p)
     with pytest.raises(api.JdaError, match="scale==0"):
-        c.detect_batch_cpp(synth.make_frames(1, 64, 64, seed=1))
-
-
-# ---------------------------------------------------------------- BASELINE.json configs[4] dimensions
-
-def test_deep_wide_model_config5_dims(built, gpu, tmp_path):
-    """T=7, K=2000, depth 6, 68 landmarks (259,560,576-byte float file, W = 243.7 MB): branchy
-    trees (generic-depth scan path, 31 nodes per cart) and the wide regression gather."""
-    from jda_amd import api, synth
-    from oracle.pyoracle import Oracle
-    m = synth.make_model(7, 2000, 68, 6, seed=2, cart_th=-2.0)
-    p = str(tmp_path / "x.model"); m.save(p, 4)
-    assert os.path.getsize(p) == 259560576                     # SURVEY.md 8a-8
-    c, o = api.Cascador(p, "float"), Oracle(p)
-    frames = synth.make_frames(1, 320, 240, seed=3)
-    _compare_trace(c, o, frames)
-    d = c.detect_batch(frames)[0]
-    _compare_detect(d, o.detect(frames[0]))
-    assert len(d["scores"]) > 0
+        c.detect_batch_cpp_pyramid(synth.make_frames(1, 64, 64, seed=1))
 
 
 # ---------------------------------------------------------------- randomised sweep
@@ -371,7 +408,7 @@ def test_random_configurations_vs_oracle(built, gpu, tmp_path):
         dets = c.detect_batch(frames, th=fin, **kw)
         for i in range(len(frames)):
             _compare_detect(dets[i], o.detect(frames[i], th=fin, **kw))
-        if not m.scale.any():
+        if True:
             ckw = dict(minimum_size=int(rng.integers(12, 40)), step=int(rng.integers(2, 9)),
                        factor=float(rng.choice([1.15, 1.2, 1.5])))
             if min(w, h) >= ckw["minimum_size"]:
