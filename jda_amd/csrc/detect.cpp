@@ -461,11 +461,22 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     if (pe->fast_scan) {
       const int handoff = (int)env_ll("JDA_HANDOFF", 128);
       bool any_glb = false;
+      long long lds_blocks = 0;
       for (int l = 0; l < pe->hp.n_levels; l++) {
         if (pe->hp.lv[l].tiled == 2) any_glb = true;
-        if (pe->hp.lv[l].tiled != 1) continue;
-        JDA_HIP(launch_scan<Real>(l, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+        if (pe->hp.lv[l].tiled == 1) lds_blocks += (long long)pe->hp.lv[l].tiles_x * pe->hp.lv[l].tiles_y * nf;
+      }
+      if (lds_blocks > 0 && lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048)) {
+        // small job (a frame or a few): all LDS-tiled levels in one launch -- every workgroup
+        // is resident at once anyway, so per-level launches would only serialise their latency
+        JDA_HIP(launch_scan<Real>(-2, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
         rs->scan_launches++;
+      } else {
+        for (int l = 0; l < pe->hp.n_levels; l++) {
+          if (pe->hp.lv[l].tiled != 1) continue;
+          JDA_HIP(launch_scan<Real>(l, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+          rs->scan_launches++;
+        }
       }
       if (any_glb) {
         JDA_HIP(launch_scan<Real>(-1, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
@@ -488,10 +499,16 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     };
     long long n_tail = -1, n_mid = -1;
     if (!queue_len(kCntTail, &n_tail)) return false;
-    JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
-    if (T > 1) {
-      if (!queue_len(kCntMid, &n_mid)) return false;
-      JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
+    if (T > 1 && n_tail >= 0 && n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
+      // few windows left: one launch walks them through every remaining stage (no balance problem,
+      // one launch + one synchronisation less)
+      JDA_HIP(launch_finish<Real>(want_trace, 0, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_GM", 4), n_tail, st));
+    } else {
+      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
+      if (T > 1) {
+        if (!queue_len(kCntMid, &n_mid)) return false;
+        JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
+      }
     }
     JDA_HIP(hipEventRecord(c->ev[3], st));
     JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));

@@ -144,7 +144,8 @@ hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all
                           const WorkT<Real>& w, hipStream_t stream);
 
 // Stage-0 scan, carts [0, handoff) of stage 0: level >= 0 = that LDS-tiled level (tiled == 1);
-// level < 0 = every global-pixel level (tiled == 2) in one launch.
+// level == -1 = every global-pixel level (tiled == 2) in one launch; level == -2 = every LDS-tiled
+// level in one launch (small batches).
 template <typename Real>
 hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan, const DevPlan& h_plan,
                        const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,

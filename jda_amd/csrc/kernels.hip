@@ -354,10 +354,10 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   const int lane = tid & 63;
   const int wv = tid >> 6;
 #ifdef JDA_SCAN_TIMING
-  unsigned long long stamps[12];
+  unsigned long long stamps[15];
   int n_stamp = 0;
-  int items_at[12];
-#define JDA_STAMP(v) do { if (n_stamp < 12) { items_at[n_stamp] = (v); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); } } while (0)
+  int items_at[15];
+#define JDA_STAMP(v) do { if (n_stamp < 15) { items_at[n_stamp] = (v); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define JDA_STAMP(v) do { } while (0)
 #endif
@@ -459,18 +459,23 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
     // strictly in cart order with the per-cart reject test.
     auto apply = [&](auto cnt_tag, int k, const int* lf, bool& alive, Real& score, unsigned& hash, int gid) {
       constexpr int CNT = decltype(cnt_tag)::value;
+      // all table reads first and unconditionally (they depend on the leaves only), so that
+      // their LDS round trips overlap; the dependent part below is pure arithmetic
+      CartPar<Real> p[CNT];
+      Real lsv[CNT];
+#pragma unroll
+      for (int u = 0; u < CNT; u++) { p[u] = t_par[k + u]; lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; }
       Real s = score;
       bool dead = false;
       int kd = k;
 #pragma unroll
       for (int u = 0; u < CNT; u++) {
         if (!dead) {
-          const CartPar<Real> p = t_par[k + u];
-          s = s + t_leaf[(k + u) * leaf_n + lf[u]];                        // c/jda.c:396
-          if (p.norm != (Real)0) s = (s - p.mean) / p.std;                 // c/jda.c:397
+          s = s + lsv[u];                                                  // c/jda.c:396
+          if (p[u].norm != (Real)0) s = (s - p[u].mean) / p[u].std;        // c/jda.c:397
           if (TRACE) hash = fnv_step(hash, lf[u]);
           kd = k + u;
-          dead = s < p.th;                                                 // c/jda.c:399
+          dead = s < p[u].th;                                              // c/jda.c:399
         }
       }
       score = s;
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
           }
         }
         __syncthreads();
+        JDA_STAMP(-100 - (r0 - c0));          // timing build: trees of this round done
         if (wv == 0) {
           for (int k = r0; k < r1; k += 4) {
             if (__ballot(alive) == 0ull) break;
@@ -655,12 +661,18 @@ template <typename Real, bool TRACE>
 static hipError_t launch_scan_depth(const DevPlan* d_plan, const DevPlan& h_plan, const DevModelT<Real>& m,
                                     const S0Node* table, const WorkT<Real>& w, int level, int handoff,
                                     hipStream_t stream) {
-  // level >= 0: that LDS-tiled level; level < 0: every global-pixel level in one launch
-  const bool glb = level < 0;
+  // level >= 0: that LDS-tiled level; level == -1: every global-pixel level in one launch;
+  // level == -2: every LDS-tiled level in one launch sized for the largest tile (small
+  // batches, where one launch per level would only add launch latency)
+  const bool glb = level == -1;
   int tiles = 0, pix_bytes = 0;
-  if (glb) {
-    for (int i = 0; i < h_plan.n_levels; i++)
-      if (h_plan.lv[i].tiled == 2) tiles += h_plan.lv[i].tiles_x * h_plan.lv[i].tiles_y;
+  if (level < 0) {
+    for (int i = 0; i < h_plan.n_levels; i++) {
+      const DevLevel& lv = h_plan.lv[i];
+      if (lv.tiled != (glb ? 2 : 1)) continue;
+      tiles += lv.tiles_x * lv.tiles_y;
+      if (!glb) pix_bytes = std::max(pix_bytes, lv.pitch * (lv.win + (lv.th - 1) * lv.step));
+    }
   } else {
     const DevLevel& lv = h_plan.lv[level];
     tiles = lv.tiles_x * lv.tiles_y;
@@ -675,7 +687,8 @@ static hipError_t launch_scan_depth(const DevPlan* d_plan, const DevPlan& h_plan
   auto go = [&](auto kern) {
     if (L.total > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level, tiles, pix_bytes, handoff);
+    hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
+                       pix_bytes, handoff);
   };
   if (glb) {
     if (m.D == 4) go(k_scan<Real, 4, TRACE, true>);

@@ -17,7 +17,7 @@ ok = n >= 3
 print("blocks with stamps", ok.sum(), "(last launch to write each slot wins)")
 for L in sorted(set(lvl[ok].tolist())):
     sel = ok & (lvl == L)
-    ns = n[sel]; st = buf[sel, 1:13].astype(np.int64); it = buf[sel, 16:28].astype(np.int64)
+    ns = n[sel]; st = buf[sel, 1:16].astype(np.int64); it = buf[sel, 16:31].astype(np.int64)
     k = int(np.median(ns))
     rows = sel.sum()
     same = ns == k
