@@ -296,6 +296,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   if (it != c->plans.end()) { *out = &it->second; return true; }
   if ((int)sp.levels.size() > kMaxLevels) { fail("too many pyramid levels"); return false; }
   if (sp.windows * 1LL > 0x7fffffffLL) { fail("frame has too many windows"); return false; }
+  if (sp.width > 65535 || sp.height > 65535) { fail("frames wider or taller than 65535 pixels are not supported"); return false; }
   PlanEntry pe;
   pe.sp = sp;
   // LDS-tiled stage-0 scan needs every stage-0 node to read the origin image
@@ -324,7 +325,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
 
 template <typename Real>
 static size_t bytes_per_window(int dim, bool trace) {
-  size_t b = (4 + sizeof(Real) + 4) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real));
+  size_t b = (4 + sizeof(Real) + 4 + 8) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real)) + 8;
   if (trace) b += 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
   return b;
 }
@@ -339,11 +340,15 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
     w.q_gid = cv.take<uint32_t>(cap);
     w.q_score = cv.take<Real>(cap);
     w.q_kstart = cv.take<uint32_t>(cap);
+    w.q_xy = cv.take<uint32_t>(cap);
+    w.q_wf = cv.take<uint32_t>(cap);
     w.q_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
     w.m_gid = cv.take<uint32_t>(cap);
     w.m_score = cv.take<Real>(cap);
     w.m_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
     w.m_shape = cv.take<Real>(cap * dim);
+    w.m_xy = cv.take<uint32_t>(cap);
+    w.m_wf = cv.take<uint32_t>(cap);
     w.out_gid = cv.take<uint32_t>(cap);
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
@@ -410,6 +415,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
   fpp = std::min<long long>(fpp, n);
   fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
+  fpp = std::min<long long>(fpp, 65535);                       // the queues pack the frame index in 16 bits
   if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
   const size_t cap = (size_t)fpp * (size_t)wpf;
   if (!ensure_workspace<Real>(c, cap, want_trace)) return false;

@@ -88,9 +88,10 @@ struct WorkT {
   const uint8_t* quarter; size_t quarter_stride; int qw, qh;
   // hand-off queue k_scan -> k_finish (plus the windows k_scan does not cover)
   uint32_t* q_gid; Real* q_score; uint32_t* q_hash; uint32_t* q_kstart;
+  uint32_t* q_xy; uint32_t* q_wf;          // x | y << 16 and win | frame << 16 of the queued window
   unsigned long long* counters;                                // see Counter
   // mid queue: windows alive after stage 0, with their regressed shape (k_finish pass 1 -> pass 2)
-  uint32_t* m_gid; Real* m_score; uint32_t* m_hash; Real* m_shape;
+  uint32_t* m_gid; Real* m_score; uint32_t* m_hash; Real* m_shape; uint32_t* m_xy; uint32_t* m_wf;
   // final detections: windows that passed every cart and the final threshold
   uint32_t* out_gid; Real* out_score; Real* out_shape;
   // per-window trace (all null when off), indexed by gid

@@ -77,15 +77,6 @@ __device__ __forceinline__ unsigned long long* shard_counter(unsigned long long*
   return counters + (size_t)(blockIdx.x % kCntShards) * kCntStride + idx;
 }
 
-// level of a frame-local window index (uniform or per-lane; levels are few)
-__device__ __forceinline__ int find_level(const DevPlan* plan, int wid) {
-  int l = 0;
-  const int n = plan->n_levels;
-  for (int i = 1; i < n; i++)
-    if (wid >= plan->lv[i].base) l = i;
-  return l;
-}
-
 }  // namespace
 
 // =============================================================================
@@ -626,6 +617,8 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         w.q_gid[slot] = (uint32_t)(gid0 + (wy0 + wy) * lv.nx + wx0 + wx);
         w.q_score[slot] = q_score[cur * M_MAX + i];
         w.q_kstart[slot] = (uint32_t)K;
+        w.q_xy[slot] = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
+        w.q_wf[slot] = (uint32_t)lv.win | ((uint32_t)frame << 16);
         if (TRACE) w.q_hash[slot] = q_hash[cur * M_MAX + i];
       }
       handed += K;
@@ -729,13 +722,19 @@ __global__ void k_enqueue(const DevPlan* __restrict__ plan, WorkT<Real> w, int p
   if (idx >= total) return;
   const int frame = (int)(idx / per_frame);
   int r = (int)(idx - (long long)frame * per_frame);
-  int wid = -1;
+  int wid = -1, lvl = 0, rel = 0;
   for (int i = 0; i < plan->n_levels; i++) {
     const DevLevel* c = &plan->lv[i];
     if (!all_levels && c->tiled) continue;
     const int cnt = c->nx * c->ny;
-    if (wid < 0 && r < cnt) wid = c->base + r;
+    if (wid < 0 && r < cnt) { wid = c->base + r; lvl = i; rel = r; }
     r -= cnt;
+  }
+  {
+    const DevLevel* c = &plan->lv[lvl];
+    const int iy = rel / c->nx, ix = rel - iy * c->nx;
+    w.q_xy[idx] = (uint32_t)(ix * c->step) | ((uint32_t)(iy * c->step) << 16);
+    w.q_wf[idx] = (uint32_t)c->win | ((uint32_t)frame << 16);
   }
   w.q_gid[idx] = (uint32_t)(frame * plan->windows + wid);
   w.q_score[idx] = (Real)0;
@@ -772,19 +771,19 @@ struct View {
 
 // Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
 // data.cpp:18-58).
-template <typename DL>
+template <typename DL, bool MULTI>
 __device__ __forceinline__ int node_feature(const typename DL::Node& nd, const typename DL::Real* sh, int win,
-                                            const View& v0, const View& v1, const View& v2, bool multi) {
+                                            const View& v0, const View& v1, const View& v2) {
   using Real = typename DL::Real;
   const Real s1x = sh[nd.lm1x2], s1y = sh[nd.lm1x2 + 1];
   const Real s2x = sh[nd.lm2x2], s2y = sh[nd.lm2x2 + 1];
-  if (!multi) {
+  if (!MULTI) {
     const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
     const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
     const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win);
     const int y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
-    const int a = v0.img[(size_t)(v0.oy + y1) * v0.w + v0.ox + x1];
-    const int b = v0.img[(size_t)(v0.oy + y2) * v0.w + v0.ox + x2];
+    const int a = v0.img[(unsigned)((v0.oy + y1) * v0.w + v0.ox + x1)];
+    const int b = v0.img[(unsigned)((v0.oy + y2) * v0.w + v0.ox + x2)];
     return a - b;
   }
   // Multi-scale models.  Dialect C scales and clamps with the FULL window side for
@@ -800,36 +799,33 @@ __device__ __forceinline__ int node_feature(const typename DL::Node& nd, const t
   const int y2 = clamp_win(DL::coord(s2y, nd.o2y, pw), pw);
   const int gx1 = min(v.ox + x1, v.w - 1), gy1 = min(v.oy + y1, v.h - 1);
   const int gx2 = min(v.ox + x2, v.w - 1), gy2 = min(v.oy + y2, v.h - 1);
-  const int a = v.img[(size_t)gy1 * v.w + gx1];
-  const int b = v.img[(size_t)gy2 * v.w + gx2];
+  const int a = v.img[(unsigned)(gy1 * v.w + gx1)];
+  const int b = v.img[(unsigned)(gy2 * v.w + gx2)];
   return a - b;
 }
 
+// Views of a queued window from its packed (x, y, win, frame) -- the producers of the queues
+// know these, so no division or level search is needed here.
 template <typename Real>
-__device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<Real>& w, uint32_t gid, float inv_sqrt2,
-                                              int* win, View* v0, View* v1, View* v2, bool multi) {
-  const int frame = (int)(gid / (uint32_t)plan->windows);
-  const int wid = (int)(gid - (uint32_t)frame * (uint32_t)plan->windows);
-  const int l = find_level(plan, wid);
-  const DevLevel* lv = &plan->lv[l];
-  const int rel = wid - lv->base;
-  const int iy = rel / lv->nx, ix = rel - iy * lv->nx;
-  const int x = ix * lv->step, y = iy * lv->step;
-  *win = lv->win;
+__device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<Real>& w, uint32_t xy, uint32_t wf,
+                                              float inv_sqrt2, int* win, View* v0, View* v1, View* v2, bool multi) {
+  const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+  const int wn = (int)(wf & 0xffffu), frame = (int)(wf >> 16);
+  *win = wn;
   v0->img = w.frames + (size_t)frame * w.frame_stride; v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
-  v0->pw = lv->win;
+  v0->pw = wn;
   if (multi) {
     v1->img = w.half + (size_t)frame * w.half_stride; v1->w = w.hw; v1->h = w.hh;
     v2->img = w.quarter + (size_t)frame * w.quarter_stride; v2->w = w.qw; v2->h = w.qh;
     if (sizeof(Real) == 4) {
       // dialect C, c/jda.c:345-354: origins by float multiply / integer halving, full-size patches
-      v1->ox = (int)((float)x * inv_sqrt2); v1->oy = (int)((float)y * inv_sqrt2); v1->pw = lv->win;
-      v2->ox = x / 2; v2->oy = y / 2; v2->pw = lv->win;
+      v1->ox = (int)((float)x * inv_sqrt2); v1->oy = (int)((float)y * inv_sqrt2); v1->pw = wn;
+      v2->ox = x / 2; v2->oy = y / 2; v2->pw = wn;
     } else {
       // dialect CPP, cascador.cpp:340-343: Rect(int(x/r), int(y/r), int(win/r), ..), r = sqrt(2.) in double
       const double r = sqrt(2.0);
-      v1->ox = (int)((double)x / r); v1->oy = (int)((double)y / r); v1->pw = (int)((double)lv->win / r);
-      v2->ox = x / 2; v2->oy = y / 2; v2->pw = lv->win / 2;
+      v1->ox = (int)((double)x / r); v1->oy = (int)((double)y / r); v1->pw = (int)((double)wn / r);
+      v2->ox = x / 2; v2->oy = y / 2; v2->pw = wn / 2;
     }
   }
 }
@@ -850,20 +846,20 @@ __device__ __forceinline__ double rl(double v, int j) {
 // Tree walks of G carts (k[0..G)) of one stage for the window whose shape is sh[],
 // in lockstep: per tree level the G node records are fetched together, then the
 // 2G pixels, so the memory round trips of the G walks overlap.  -> leaf indices.
-template <typename DL, int G>
+template <typename DL, int G, bool MULTI>
 __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__ stage_nodes, const int* k,
                                            int depth, int node_n, const typename DL::Real* sh, int win,
-                                           const View& v0, const View& v1, const View& v2, bool multi, int* leaf) {
+                                           const View& v0, const View& v1, const View& v2, int* leaf) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
   for (int d = 0; d < depth - 1; d++) {
     typename DL::Node nd[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) nd[g] = stage_nodes[(size_t)k[g] * node_n + node[g]];
+    for (int g = 0; g < G; g++) nd[g] = stage_nodes[(unsigned)(k[g] * node_n + node[g])];
     int feat[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) feat[g] = node_feature<DL>(nd[g], sh, win, v0, v1, v2, multi);
+    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI>(nd[g], sh, win, v0, v1, v2);
 #pragma unroll
     for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (feat[g] <= nd[g].th ? 1 : 2);   // c/jda.c:392-393
   }
@@ -884,10 +880,13 @@ __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real l
     // of that ballot is kept.  Same adds in the same order as the scalar loop.
     Real s = score;
     unsigned long long rej = 0ull;
+    for (int j0 = 0; j0 < 64 && rej == 0ull; j0 += 16) {      // stop at the 16-cart block that rejects
 #pragma unroll
-    for (int j = 0; j < 64; j++) {
-      s = s + rl(ls, j);                                       // c/jda.c:396
-      rej |= __ballot(s < th_k) & (1ull << j);                 // c/jda.c:399
+      for (int jj = 0; jj < 16; jj++) {
+        const int j = j0 + jj;
+        s = s + rl(ls, j);                                     // c/jda.c:396
+        rej |= __ballot(s < th_k) & (1ull << j);               // c/jda.c:399
+      }
     }
     if (rej == 0ull) {
       if (TRACE) {
@@ -919,7 +918,7 @@ __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real l
 // Stages [t_begin, t_end) for every window of the input queue.  Windows that are
 // still alive after stage t_end-1 go to the mid queue (t_end < T) or, after the
 // final threshold, to the detection list (t_end == T).
-template <typename DL, bool TRACE, int kG>
+template <typename DL, bool TRACE, int kG, bool MULTI>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
                                                int t_begin, int t_end, int apply_th, typename DL::Real final_th) {
@@ -931,9 +930,10 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   const int dim_pad = (dim + 1) & ~1;
   Real* sh = (Real*)lds;                                     // current shape        [dim_pad]
   Real* sh2 = sh + dim_pad;                                  // shape being built    [dim_pad]
-  uint16_t* lbf = (uint16_t*)(sh2 + dim_pad);                // leaf of every cart   [K]
-  int* stage_cnt = (int*)(lbf + ((K + 7) & ~7));             // per-block stage counters
-  const bool multi = multi_i != 0;
+  uint32_t* lbf = (uint32_t*)(sh2 + dim_pad);                // W row (in elements) chosen by every cart [K]
+  int* stage_cnt = (int*)(lbf + ((K + 3) & ~3));             // per-block stage counters
+  constexpr bool multi = MULTI;   // split nodes read the half/quarter images too
+  (void)multi_i;
   const int lane = threadIdx.x;
   if (lane < kMaxStages) stage_cnt[lane] = 0;
   const bool from_scan = t_begin == 0;
@@ -948,7 +948,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     if (TRACE) hash = from_scan ? w.q_hash[i] : w.m_hash[i];
     int win;
     View v0{}, v1{}, v2{};
-    decode_window<Real>(plan, w, gid, inv_sqrt2, &win, &v0, &v1, &v2, multi);
+    const uint32_t xy = from_scan ? w.q_xy[i] : w.m_xy[i];
+    const uint32_t wf = from_scan ? w.q_wf[i] : w.m_wf[i];
+    decode_window<Real>(plan, w, xy, wf, inv_sqrt2, &win, &v0, &v1, &v2, multi);
     __syncthreads();                       // previous window's readers are done with sh
     {
       const Real* src = from_scan ? m.mean_shape : w.m_shape + (size_t)i * dim;
@@ -976,14 +978,14 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        walk_carts<DL, kG>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, multi, lf);
+        walk_carts<DL, kG, MULTI>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, lf);
 #pragma unroll
         for (int g = 0; g < kG; g++) {
           const int k = k0 + g * 64 + lane;
           ls[g] = 0; thk[g] = 0; mk[g] = 0; sk[g] = 1; nrm[g] = 0;
           if (k < K) {
-            lbf[k] = (uint16_t)lf[g];
-            ls[g] = leaf_tab[(size_t)k * leaf_n + lf[g]];
+            lbf[k] = (uint32_t)(k * leaf_n + lf[g]) * (uint32_t)dim;
+            ls[g] = leaf_tab[(unsigned)(k * leaf_n + lf[g])];
             thk[g] = cth[k];
             nrm[g] = cnorm[k];
             if (nrm[g]) { mk[g] = cmean[k]; sk[g] = cstd[k]; }
@@ -1004,9 +1006,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        walk_carts<DL, 2>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, multi, lf);
-        if (k0 + lane < k_first) lbf[k0 + lane] = (uint16_t)lf[0];
-        if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint16_t)lf[1];
+        walk_carts<DL, 2, MULTI>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, lf);
+        if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
+        if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)dim;
       }
       __syncthreads();
       // ---- stage regression: K weight rows added strictly in cart order
@@ -1020,11 +1022,11 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         for (; k + 32 <= K; k += 32) {          // 32 row loads in flight, then 32 ordered adds
           Real r[32];
 #pragma unroll
-          for (int u = 0; u < 32; u++) r[u] = col[(size_t)((k + u) * leaf_n + lbf[k + u]) * dim];
+          for (int u = 0; u < 32; u++) r[u] = col[lbf[k + u]];
 #pragma unroll
           for (int u = 0; u < 32; u++) acc = acc + r[u];
         }
-        for (; k < K; k++) acc = acc + col[(size_t)(k * leaf_n + lbf[k]) * dim];
+        for (; k < K; k++) acc = acc + col[lbf[k]];
         if (kCpp) {
           // identity STParameter::Apply (data.hpp:42-45) on (dx,dy): 1*(1*x+0*y) / 1*(0*x+1*y)
           const Real other = __shfl_xor(acc, 1);
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
       o = (unsigned)__shfl((int)o, 0);
       if (o < w.cap) {
-        if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; if (TRACE) w.m_hash[o] = hash; }
+        if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; w.m_xy[o] = xy; w.m_wf[o] = wf; if (TRACE) w.m_hash[o] = hash; }
         for (int d = lane; d < dim; d += 64) w.m_shape[(size_t)o * dim + d] = sh[d];
       }
     }
@@ -1079,7 +1081,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
                               const WorkT<typename DL::Real>& w, int groups, long long n_hint, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
-  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 7) & ~7) * 2 + kMaxStages * sizeof(int);
+  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int);
   const int multi = (w.half != nullptr) ? 1 : 0;
   const float r = 1.f / sqrtf(2.f);
   // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to
@@ -1096,8 +1098,14 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   };
   // groups = 64-cart groups walked speculatively per round: 1 where most windows are
   // rejected within a few carts (throughput), 4 where most pass (latency)
-  if (trace) { if (groups >= 4) go(k_finish<DL, true, 4>); else if (groups >= 2) go(k_finish<DL, true, 2>); else go(k_finish<DL, true, 1>); }
-  else { if (groups >= 4) go(k_finish<DL, false, 4>); else if (groups >= 2) go(k_finish<DL, false, 2>); else go(k_finish<DL, false, 1>); }
+  auto pick = [&](auto trace_tag, auto multi_tag) {
+    constexpr bool TR = decltype(trace_tag)::value, MU = decltype(multi_tag)::value;
+    if (groups >= 4) go(k_finish<DL, TR, 4, MU>);
+    else if (groups >= 2) go(k_finish<DL, TR, 2, MU>);
+    else go(k_finish<DL, TR, 1, MU>);
+  };
+  if (trace) { if (multi) pick(std::true_type{}, std::true_type{}); else pick(std::true_type{}, std::false_type{}); }
+  else { if (multi) pick(std::false_type{}, std::true_type{}); else pick(std::false_type{}, std::false_type{}); }
   return hipGetLastError();
 }
 }  // namespace
