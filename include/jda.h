@@ -218,6 +218,14 @@ JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames
                               double factor, double overlap, int nms,
                               jdaStats *stats, jdaResultD *out);
 
+/* Dialect CPP only: the similarity-transform mode of Validate (reference
+ * src/jda/data.cpp:64-126, config key face.similarity_transform, common.cpp:214; off in
+ * the shipped config).  Per stage, sR = Calc(shape, mean_shape) rotates/scales the node
+ * offsets and the regressed delta shape.  PARITY UNPINNED twice over: dialect CPP itself,
+ * and two OpenCV details it leans on (cv::norm's accumulation order, `Mat_ /= double` as a
+ * multiply by the reciprocal), both restated identically in the oracle and the kernel. */
+JDA_API int jdaSetSimilarityTransform(void *cascador, int on);
+
 /* Dialect CPP, detect method 0 -- the true image pyramid of reference
  * src/jda/cascador.cpp:216-308 (detectMultiScale + detectSingleScale): a fixed
  * origin_size x origin_size window (config image_size.origin_size, 48 in the shipped

@@ -107,6 +107,7 @@ def _load():
     lib.jdaDetectBatchCppPyramid.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     lib.jdaResizeCv.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    lib.jdaSetSimilarityTransform.argtypes = [C.c_void_p, C.c_int]
     lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
     lib.jdaNmsCpp.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int)]
     lib.jdaResultsPack.argtypes = [C.POINTER(jdaResult), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
@@ -228,6 +229,11 @@ class Cascador:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_similarity_transform(self, on):
+        """Dialect CPP: Config face.similarity_transform (reference common.cpp:214)."""
+        if lib.jdaSetSimilarityTransform(self.h, 1 if on else 0) != 0:
+            raise JdaError("jdaSetSimilarityTransform failed")
 
     def serialize(self, path):
         lib.jdaCascadorSerializeTo(self.h, os.fsencode(path))

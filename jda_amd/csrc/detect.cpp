@@ -124,6 +124,7 @@ struct Workspace {
 struct Cascador {
   HostModel hm;
   std::mutex mu;
+  int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
   bool dev_init = false;
   hipStream_t stream = nullptr;
@@ -185,6 +186,41 @@ static bool upload_model(Cascador* c) {
   const size_t carts = (size_t)h.carts();
   const int node_n = h.node_n(), leaf_n = h.leaf_n(), dim = h.dim();
   std::vector<Node> nodes(carts * node_n);
+  // stage-0 similarity transform, reference data.cpp:64-114 (see stp_calc in kernels.hip for the
+  // restated OpenCV details); identity when off
+  double stp0[5] = {1., 1., 0., 0., 1.};
+  if (sizeof(Real) == 8 && c->similarity) {
+    const int L = h.L;
+    std::vector<double> s1(dim), t1(dim), t2(dim);
+    const std::vector<double>& s2 = h.mean_shape;
+    const volatile double zero = 0.;
+    for (int i = 0; i < dim; i++) s1[i] = s2[i] + zero;
+    double x1c = 0., y1c = 0., x2c = 0., y2c = 0.;
+    for (int i = 0; i < L; i++) { x1c += s1[2 * i]; y1c += s1[2 * i + 1]; x2c += s2[2 * i]; y2c += s2[2 * i + 1]; }
+    x1c /= (double)L; y1c /= (double)L; x2c /= (double)L; y2c /= (double)L;
+    for (int i = 0; i < L; i++) {
+      t1[2 * i] = s1[2 * i] - x1c; t1[2 * i + 1] = s1[2 * i + 1] - y1c;
+      t2[2 * i] = s2[2 * i] - x2c; t2[2 * i + 1] = s2[2 * i + 1] - y2c;
+    }
+    auto cvnorm = [](const std::vector<double>& v) {
+      double a = 0.; size_t i = 0; const size_t n = v.size();
+      for (; i + 4 <= n; i += 4) { const double v0 = v[i], v1 = v[i + 1], v2 = v[i + 2], v3 = v[i + 3]; a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3; }
+      for (; i < n; i++) a += v[i] * v[i];
+      return std::sqrt(a);
+    };
+    const double scale1 = cvnorm(t1), scale2 = cvnorm(t2);
+    stp0[0] = scale1 / scale2;
+    const double a1 = 1. / scale1, a2 = 1. / scale2;
+    for (int i = 0; i < dim; i++) { t1[i] = t1[i] * a1 + zero; t2[i] = t2[i] * a2 + zero; }
+    double num = 0., den = 0.;
+    for (int i = 0; i < L; i++) {
+      num += t1[2 * i + 1] * t2[2 * i] - t1[2 * i] * t2[2 * i + 1];
+      den += t1[2 * i] * t2[2 * i] + t1[2 * i + 1] * t2[2 * i + 1];
+    }
+    const double norm = std::sqrt(num * num + den * den);
+    const double sn = num / norm, cs = den / norm;
+    stp0[1] = cs; stp0[2] = -sn; stp0[3] = sn; stp0[4] = cs;
+  }
   for (size_t i = 0; i < nodes.size(); i++) {
     const SplitNode& s = h.nodes[i];
     Node& d = nodes[i];
@@ -193,12 +229,20 @@ static bool upload_model(Cascador* c) {
       // plain narrowing casts, reference c/jda.c:525-532
       d.o1x = (Real)s.off[0]; d.o1y = (Real)s.off[1]; d.o2x = (Real)s.off[2]; d.o2y = (Real)s.off[3];
     } else {
-      // identity STParameter::Apply on each offset pair (data.hpp:42-45, data.cpp:33-34)
-      const volatile double one = 1., zero = 0.;
-      d.o1x = (Real)(one * (one * s.off[0] + zero * s.off[1]));
-      d.o1y = (Real)(one * (zero * s.off[0] + one * s.off[1]));
-      d.o2x = (Real)(one * (one * s.off[2] + zero * s.off[3]));
-      d.o2y = (Real)(one * (zero * s.off[2] + one * s.off[3]));
+      // STParameter::Apply on each offset pair (data.hpp:42-45, data.cpp:33-34) with the parameter
+      // that is the same for every window: the identity when the similarity transform is off, and
+      // -- for STAGE 0 only, where every window holds the mean shape -- Calc(mean+0, mean) when it is
+      // on.  Later stages keep the raw offsets; k_finish applies each window's own parameter.
+      const bool raw = c->similarity && i >= (size_t)h.K * node_n;
+      const volatile double sc = stp0[0], r00 = stp0[1], r01 = stp0[2], r10 = stp0[3], r11 = stp0[4];
+      if (raw) {
+        d.o1x = (Real)s.off[0]; d.o1y = (Real)s.off[1]; d.o2x = (Real)s.off[2]; d.o2y = (Real)s.off[3];
+      } else {
+        d.o1x = (Real)(sc * (r00 * s.off[0] + r01 * s.off[1]));
+        d.o1y = (Real)(sc * (r10 * s.off[0] + r11 * s.off[1]));
+        d.o2x = (Real)(sc * (r00 * s.off[2] + r01 * s.off[3]));
+        d.o2y = (Real)(sc * (r10 * s.off[2] + r11 * s.off[3]));
+      }
     }
   }
   auto cast = [](const std::vector<double>& v) {
@@ -207,7 +251,7 @@ static bool upload_model(Cascador* c) {
     return o;
   };
   std::vector<Real> leaf = cast(h.leaf_score), cth = cast(h.cart_th), cmean = cast(h.cart_mean),
-                    cstd = cast(h.cart_std), w = cast(h.w), ms = cast(h.mean_shape);
+                    cstd = cast(h.cart_std), w = cast(h.w), ms = cast(h.mean_shape), ms_raw = cast(h.mean_shape);
   if (sizeof(Real) == 8) {
     const volatile double zero = 0.;
     for (auto& v : ms) v = (Real)((double)v + zero);   // RandomShape with zero shift, data.cpp:225-236
@@ -217,7 +261,7 @@ static bool upload_model(Cascador* c) {
 
   Carver sz(nullptr);
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
-  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim);
+  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim);
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
   Node* d_nodes = cv.take<Node>(nodes.size());
@@ -228,6 +272,7 @@ static bool upload_model(Cascador* c) {
   uint8_t* d_cnorm = cv.take<uint8_t>(carts);
   Real* d_w = cv.take<Real>(w.size());
   Real* d_ms = cv.take<Real>(dim);
+  Real* d_ms_raw = cv.take<Real>(dim);
   JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
@@ -236,10 +281,12 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_cnorm, cnorm.data(), carts, hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_w, w.data(), w.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
-  m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms;
+  m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
+  m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   mo.ready = true;
   return true;
 }
@@ -752,6 +799,18 @@ int jdaCascadorInfo(void* cascador, jdaModelInfo* info) {
   return 0;
 }
 
+int jdaSetSimilarityTransform(void* cascador, int on) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lock(c->mu);
+  on = on ? 1 : 0;
+  if (c->similarity != on) {
+    c->similarity = on;
+    c->md.ready = false;          // the fp64 node table depends on it (stage-0 offsets carry the transform)
+  }
+  return 0;
+}
+
 int jdaSetDevice(void* cascador, int device) {
   Cascador* c = (Cascador*)cascador;
   if (!c) return -1;
@@ -884,7 +943,7 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   size_t stride = 0;
   if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
-  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, 0, fb};
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
   if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
   TraceOut<double> tr{carts_n, score, path_hash, shapes};
@@ -946,7 +1005,7 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
     while (w >= origin_size && h >= origin_size) {               // cascador.cpp:283
       ScanPlan sp; std::string err;
       if (!plan_single_level(w, h, origin_size, step, &sp, &err)) { fail(err); return false; }
-      PlanKey key{w, h, 2 /* method 0 level */, origin_size, step, 0, 0ull};
+      PlanKey key{w, h, 2 /* method 0 level */, origin_size, step, c->similarity, 0ull};
       PlanEntry* pe = nullptr;
       if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return false;
       RawDets<double> dets;
@@ -1082,7 +1141,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
   size_t stride = 0;
   if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
-  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, 0, fb};
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
   if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
   RawDets<double> dets;

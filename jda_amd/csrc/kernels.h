@@ -77,7 +77,9 @@ struct DevModelT {
   const Real* cstd;        // [T*K]
   const uint8_t* cnorm;    // [T*K] 1 where (mean,std) != (0,1)
   const Real* w;           // [T][K*leaf_n][dim]
-  const Real* mean_shape;  // [dim]
+  const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
+  const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
+  int similarity;          // dialect CPP: Config::with_similarity_transform
 };
 
 // Device buffers of one pass over a sub-batch of frames.

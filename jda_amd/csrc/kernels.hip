@@ -763,6 +763,51 @@ template hipError_t launch_enqueue<double>(const DevPlan*, const DevPlan&, bool,
 
 namespace {
 
+// Similarity transform of dialect CPP's Validate (data.cpp:64-126, data.hpp:18-50).
+template <typename Real>
+struct Stp { Real scale, r00, r01, r10, r11; };
+
+template <typename Real>
+__device__ __forceinline__ void stp_apply(const Stp<Real>& p, Real x, Real y, Real* x2, Real* y2) {   // data.hpp:42-45
+  *x2 = p.scale * (p.r00 * x + p.r01 * y);
+  *y2 = p.scale * (p.r10 * x + p.r11 * y);
+}
+
+// STParameter::Calc(shape, mean_shape) by ONE lane, sequentially, in the reference's order
+// (data.cpp:72-112).  cv::norm = sqrt of squares accumulated four at a time, `Mat_ /= s` =
+// v*(1./s)+0. (UNPINNED restatements of OpenCV, same as the oracle).  t1/t2: LDS scratch.
+__device__ __forceinline__ Stp<double> stp_calc(const double* s1, const double* __restrict__ s2, int L,
+                                                double* t1, double* t2) {
+  double x1c = 0., y1c = 0., x2c = 0., y2c = 0.;
+  for (int i = 0; i < L; i++) { x1c += s1[2 * i]; y1c += s1[2 * i + 1]; x2c += s2[2 * i]; y2c += s2[2 * i + 1]; }
+  x1c /= (double)L; y1c /= (double)L; x2c /= (double)L; y2c /= (double)L;
+  for (int i = 0; i < L; i++) {
+    t1[2 * i] = s1[2 * i] - x1c; t1[2 * i + 1] = s1[2 * i + 1] - y1c;
+    t2[2 * i] = s2[2 * i] - x2c; t2[2 * i + 1] = s2[2 * i + 1] - y2c;
+  }
+  auto cvnorm = [](const double* v, int n) {
+    double s = 0.;
+    int i = 0;
+    for (; i <= n - 4; i += 4) { const double v0 = v[i], v1 = v[i + 1], v2 = v[i + 2], v3 = v[i + 3]; s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3; }
+    for (; i < n; i++) s += v[i] * v[i];
+    return sqrt(s);
+  };
+  const double scale1 = cvnorm(t1, 2 * L), scale2 = cvnorm(t2, 2 * L);
+  Stp<double> p;
+  p.scale = scale1 / scale2;
+  const double a1 = 1. / scale1, a2 = 1. / scale2;
+  for (int i = 0; i < 2 * L; i++) { t1[i] = t1[i] * a1 + 0.; t2[i] = t2[i] * a2 + 0.; }
+  double num = 0., den = 0.;
+  for (int i = 0; i < L; i++) {
+    num += t1[2 * i + 1] * t2[2 * i] - t1[2 * i] * t2[2 * i + 1];
+    den += t1[2 * i] * t2[2 * i] + t1[2 * i + 1] * t2[2 * i + 1];
+  }
+  const double norm = sqrt(num * num + den * den);
+  const double sn = num / norm, cs = den / norm;
+  p.r00 = cs; p.r01 = -sn; p.r10 = sn; p.r11 = cs;
+  return p;
+}
+
 // Where a window reads its pixels for one feature scale.
 struct View {
   const uint8_t* img; int w, h, ox, oy;
@@ -771,12 +816,19 @@ struct View {
 
 // Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
 // data.cpp:18-58).
-template <typename DL, bool MULTI>
-__device__ __forceinline__ int node_feature(const typename DL::Node& nd, const typename DL::Real* sh, int win,
-                                            const View& v0, const View& v1, const View& v2) {
+template <typename DL, bool MULTI, bool ST>
+__device__ __forceinline__ int node_feature(typename DL::Node nd, const typename DL::Real* sh, int win,
+                                            const View& v0, const View& v1, const View& v2,
+                                            const Stp<typename DL::Real>& stp, bool apply_st) {
   using Real = typename DL::Real;
   const Real s1x = sh[nd.lm1x2], s1y = sh[nd.lm1x2 + 1];
   const Real s2x = sh[nd.lm2x2], s2y = sh[nd.lm2x2 + 1];
+  if (ST && apply_st) {       // stp_mc.Apply on both offsets, data.cpp:33-34 (stage 0's are pre-applied)
+    Real ax, ay, bx, by;
+    stp_apply<Real>(stp, nd.o1x, nd.o1y, &ax, &ay);
+    stp_apply<Real>(stp, nd.o2x, nd.o2y, &bx, &by);
+    nd.o1x = ax; nd.o1y = ay; nd.o2x = bx; nd.o2y = by;
+  }
   if (!MULTI) {
     const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
     const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
@@ -846,10 +898,11 @@ __device__ __forceinline__ double rl(double v, int j) {
 // Tree walks of G carts (k[0..G)) of one stage for the window whose shape is sh[],
 // in lockstep: per tree level the G node records are fetched together, then the
 // 2G pixels, so the memory round trips of the G walks overlap.  -> leaf indices.
-template <typename DL, int G, bool MULTI>
+template <typename DL, int G, bool MULTI, bool ST>
 __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__ stage_nodes, const int* k,
                                            int depth, int node_n, const typename DL::Real* sh, int win,
-                                           const View& v0, const View& v1, const View& v2, int* leaf) {
+                                           const View& v0, const View& v1, const View& v2,
+                                           const Stp<typename DL::Real>& stp, bool apply_st, int* leaf) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
@@ -859,7 +912,7 @@ __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__
     for (int g = 0; g < G; g++) nd[g] = stage_nodes[(unsigned)(k[g] * node_n + node[g])];
     int feat[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI>(nd[g], sh, win, v0, v1, v2);
+    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI, ST>(nd[g], sh, win, v0, v1, v2, stp, apply_st);
 #pragma unroll
     for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (feat[g] <= nd[g].th ? 1 : 2);   // c/jda.c:392-393
   }
@@ -918,7 +971,7 @@ __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real l
 // Stages [t_begin, t_end) for every window of the input queue.  Windows that are
 // still alive after stage t_end-1 go to the mid queue (t_end < T) or, after the
 // final threshold, to the detection list (t_end == T).
-template <typename DL, bool TRACE, int kG, bool MULTI>
+template <typename DL, bool TRACE, int kG, bool MULTI, bool ST>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
                                                int t_begin, int t_end, int apply_th, typename DL::Real final_th) {
@@ -932,6 +985,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   Real* sh2 = sh + dim_pad;                                  // shape being built    [dim_pad]
   uint32_t* lbf = (uint32_t*)(sh2 + dim_pad);                // W row (in elements) chosen by every cart [K]
   int* stage_cnt = (int*)(lbf + ((K + 3) & ~3));             // per-block stage counters
+  Real* st_tmp = (Real*)(stage_cnt + kMaxStages);            // similarity-transform scratch [2*dim_pad + 8] (ST only)
   constexpr bool multi = MULTI;   // split nodes read the half/quarter images too
   (void)multi_i;
   const int lane = threadIdx.x;
@@ -969,6 +1023,21 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       const uint8_t* cnorm = m.cnorm + (size_t)t * K;
       const int kbeg = t == 0 ? min(kstart, K) : 0;   // first cart whose score is still to be applied
       const int k_first = kbeg & ~63;
+      // similarity transform of this stage (cascador.cpp:180); identity unless enabled
+      Stp<Real> stp;
+      stp.scale = 1; stp.r00 = 1; stp.r01 = 0; stp.r10 = 0; stp.r11 = 1;
+      if constexpr (ST) {
+        if (lane == 0) {
+          const Stp<double> p = stp_calc((const double*)sh, (const double*)m.mean_shape_raw, m.L, (double*)st_tmp,
+                                         (double*)st_tmp + dim_pad);
+          double* o = (double*)st_tmp + 2 * dim_pad;
+          o[0] = p.scale; o[1] = p.r00; o[2] = p.r01; o[3] = p.r10; o[4] = p.r11;
+        }
+        __syncthreads();
+        const Real* o = st_tmp + 2 * dim_pad;
+        stp.scale = o[0]; stp.r00 = o[1]; stp.r01 = o[2]; stp.r10 = o[3]; stp.r11 = o[4];
+      }
+      const bool apply_st = ST && t > 0;              // stage 0's node offsets carry the transform already
 
       // ---- tree walks, kG groups of 64 carts per round (the shape is fixed during a
       //      stage, so the trees of a stage are independent of each other and of the
@@ -978,7 +1047,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        walk_carts<DL, kG, MULTI>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, lf);
+        walk_carts<DL, kG, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
         for (int g = 0; g < kG; g++) {
           const int k = k0 + g * 64 + lane;
@@ -1006,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        walk_carts<DL, 2, MULTI>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, lf);
+        walk_carts<DL, 2, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
         if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)dim;
       }
@@ -1028,10 +1097,10 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         }
         for (; k < K; k++) acc = acc + col[lbf[k]];
         if (kCpp) {
-          // identity STParameter::Apply (data.hpp:42-45) on (dx,dy): 1*(1*x+0*y) / 1*(0*x+1*y)
+          // stp_mc.Apply(delta, delta) (btcart.cpp:422, data.hpp:42-45) on the (dx,dy) pair held by
+          // lanes d, d^1; with the identity parameter this is the literal 1*(1*x+0*y) / 1*(0*x+1*y)
           const Real other = __shfl_xor(acc, 1);
-          const Real zero = (Real)0, one = (Real)1;
-          acc = (d & 1) ? one * (zero * other + one * acc) : one * (one * acc + zero * other);
+          acc = (d & 1) ? stp.scale * (stp.r10 * other + stp.r11 * acc) : stp.scale * (stp.r00 * acc + stp.r01 * other);
           acc = sh[d] + acc;
         }
         sh2[d] = acc;
@@ -1081,7 +1150,9 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
                               const WorkT<typename DL::Real>& w, int groups, long long n_hint, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
-  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int);
+  const bool st = sizeof(Real) == 8 && m.similarity != 0;
+  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int) +
+                     (st ? (2 * (size_t)dim_pad + 8) * sizeof(Real) : 0);
   const int multi = (w.half != nullptr) ? 1 : 0;
   const float r = 1.f / sqrtf(2.f);
   // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to
@@ -1098,14 +1169,18 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   };
   // groups = 64-cart groups walked speculatively per round: 1 where most windows are
   // rejected within a few carts (throughput), 4 where most pass (latency)
-  auto pick = [&](auto trace_tag, auto multi_tag) {
+  auto pick = [&](auto trace_tag, auto multi_tag, auto st_tag) {
     constexpr bool TR = decltype(trace_tag)::value, MU = decltype(multi_tag)::value;
-    if (groups >= 4) go(k_finish<DL, TR, 4, MU>);
-    else if (groups >= 2) go(k_finish<DL, TR, 2, MU>);
-    else go(k_finish<DL, TR, 1, MU>);
+    constexpr bool STT = decltype(st_tag)::value && sizeof(Real) == 8;
+    if (groups >= 4) go(k_finish<DL, TR, 4, MU, STT>);
+    else if (groups >= 2) go(k_finish<DL, TR, 2, MU, STT>);
+    else go(k_finish<DL, TR, 1, MU, STT>);
   };
-  if (trace) { if (multi) pick(std::true_type{}, std::true_type{}); else pick(std::true_type{}, std::false_type{}); }
-  else { if (multi) pick(std::false_type{}, std::true_type{}); else pick(std::false_type{}, std::false_type{}); }
+  auto pick_m = [&](auto trace_tag, auto st_tag) {
+    if (multi) pick(trace_tag, std::true_type{}, st_tag); else pick(trace_tag, std::false_type{}, st_tag);
+  };
+  if (st) { if (trace) pick_m(std::true_type{}, std::true_type{}); else pick_m(std::false_type{}, std::true_type{}); }
+  else { if (trace) pick_m(std::true_type{}, std::false_type{}); else pick_m(std::false_type{}, std::false_type{}); }
   return hipGetLastError();
 }
 }  // namespace

@@ -536,6 +536,53 @@ long long orc_count_windows_cpp(int w, int h, int minimum_size, int step, double
  * (round half away from zero, clamp common.hpp:227-232); delta shape summed
  * from zero then added, btcart.cpp:407-424.  Apply() with the identity
  * parameter is written out (1*(1*x+0*y)) because it is not a no-op for -0. */
+/* Similarity transform of Validate (data.cpp:64-126, data.hpp:18-50): sR that maps the
+ * mean shape onto the current shape.  UNPINNED details restated from OpenCV: cv::norm of a
+ * CV_64F row = sqrt of a sum of squares accumulated four at a time; `Mat_ /= double` is a
+ * convertTo with alpha = 1./b, i.e. v*(1./b) + 0. */
+typedef struct { double scale, r00, r01, r10, r11; } orc_stp;
+
+static double orc_cvnorm(const double *v, int n) {
+  double s = 0.;
+  int i = 0;
+  for (; i <= n - 4; i += 4) { const double v0 = v[i], v1 = v[i + 1], v2 = v[i + 2], v3 = v[i + 3]; s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3; }
+  for (; i < n; i++) s += v[i] * v[i];
+  return sqrt(s);
+}
+
+static orc_stp orc_stp_calc(const double *s1, const double *s2, int L, int enabled, double *t1, double *t2) {
+  orc_stp p = {1., 1., 0., 0., 1.};
+  if (!enabled) return p;                                    /* data.cpp:68-70 */
+  double x1c = 0., y1c = 0., x2c = 0., y2c = 0.;
+  for (int i = 0; i < L; i++) { x1c += s1[2 * i]; y1c += s1[2 * i + 1]; x2c += s2[2 * i]; y2c += s2[2 * i + 1]; }
+  x1c /= L; y1c /= L; x2c /= L; y2c /= L;
+  for (int i = 0; i < L; i++) {
+    t1[2 * i] = s1[2 * i] - x1c; t1[2 * i + 1] = s1[2 * i + 1] - y1c;
+    t2[2 * i] = s2[2 * i] - x2c; t2[2 * i + 1] = s2[2 * i + 1] - y2c;
+  }
+  const double scale1 = orc_cvnorm(t1, 2 * L), scale2 = orc_cvnorm(t2, 2 * L);
+  p.scale = scale1 / scale2;
+  const double a1 = 1. / scale1, a2 = 1. / scale2;
+  for (int i = 0; i < 2 * L; i++) { t1[i] = t1[i] * a1 + 0.; t2[i] = t2[i] * a2 + 0.; }
+  double num = 0., den = 0.;
+  for (int i = 0; i < L; i++) {
+    num += t1[2 * i + 1] * t2[2 * i] - t1[2 * i] * t2[2 * i + 1];
+    den += t1[2 * i] * t2[2 * i] + t1[2 * i + 1] * t2[2 * i + 1];
+  }
+  const double norm = sqrt(num * num + den * den);
+  const double sn = num / norm, cs = den / norm;
+  p.r00 = cs; p.r01 = -sn; p.r10 = sn; p.r11 = cs;
+  return p;
+}
+
+static void orc_stp_apply(const orc_stp *p, double x, double y, double *x2, double *y2) {   /* data.hpp:42-45 */
+  *x2 = p->scale * (p->r00 * x + p->r01 * y);
+  *y2 = p->scale * (p->r10 * x + p->r11 * y);
+}
+
+static int g_orc_similarity = 0;   /* Config::with_similarity_transform (common.cpp:214) */
+void orc_set_similarity_transform(int on) { g_orc_similarity = on ? 1 : 0; }
+
 typedef struct {
   const unsigned char *data; int iw;   /* image and its row stride          */
   int ox, oy;                          /* patch origin inside that image    */
@@ -553,7 +600,9 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
     shape[2 * j] = m->mean_shape[2 * j] + 0.;
     shape[2 * j + 1] = m->mean_shape[2 * j + 1] + 0.;
   }
+  double *tmp = (double *)malloc(sizeof(double) * 2 * dim);
   for (int t = 0; t < m->T; t++) {
+    const orc_stp stp = orc_stp_calc(shape, m->mean_shape, m->L, g_orc_similarity, tmp, tmp + dim);   /* cascador.cpp:180 */
     for (int k = 0; k < m->K; k++) {
       const long long c = (long long)t * m->K + k;
       int at = 0; /* 0-based position in the stored node array == reference idx-1 */
@@ -561,10 +610,9 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
         const orc_node *nd = &m->nodes[c * node_n + at];
         const orc_patch *q = &pt[nd->scale];                    /* data.cpp:21-34 */
         const int width = q->pw, height = q->pw;                /* data.cpp:37-38: the PATCH's size */
-        const double o1x = 1. * (1. * nd->off[0] + 0. * nd->off[1]);
-        const double o1y = 1. * (0. * nd->off[0] + 1. * nd->off[1]);
-        const double o2x = 1. * (1. * nd->off[2] + 0. * nd->off[3]);
-        const double o2y = 1. * (0. * nd->off[2] + 1. * nd->off[3]);
+        double o1x, o1y, o2x, o2y;
+        orc_stp_apply(&stp, nd->off[0], nd->off[1], &o1x, &o1y);   /* data.cpp:33-34 */
+        orc_stp_apply(&stp, nd->off[2], nd->off[3], &o2x, &o2y);
         const double x1 = (shape[2 * nd->lm1] + o1x) * width;
         const double y1 = (shape[2 * nd->lm1 + 1] + o1y) * height;
         const double x2 = (shape[2 * nd->lm2] + o2x) * width;
@@ -588,7 +636,7 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
       score += m->leaf[c * leaf_n + leaf];
       score = (score - m->cmean[c]) / m->cstd[c];
       n++;
-      if (score < m->cth[c]) { *alive = 0; *score_out = score; *hash_out = hash; return n; }
+      if (score < m->cth[c]) { *alive = 0; *score_out = score; *hash_out = hash; free(tmp); return n; }
       lbf[k] = k * leaf_n + leaf;
     }
     const double *ws = &m->w[(size_t)t * m->K * leaf_n * dim];
@@ -597,13 +645,13 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
       const double *row = ws + (size_t)lbf[k] * dim;
       for (int i = 0; i < dim; i++) delta[i] += row[i];
     }
-    for (int j = 0; j < m->L; j++) {           /* stp_mc.Apply(delta, delta) with identity */
+    for (int j = 0; j < m->L; j++) {           /* stp_mc.Apply(delta, delta), btcart.cpp:422 */
       const double dx = delta[2 * j], dy = delta[2 * j + 1];
-      delta[2 * j] = 1. * (1. * dx + 0. * dy);
-      delta[2 * j + 1] = 1. * (0. * dx + 1. * dy);
+      orc_stp_apply(&stp, dx, dy, &delta[2 * j], &delta[2 * j + 1]);
     }
     for (int i = 0; i < dim; i++) shape[i] += delta[i];
   }
+  free(tmp);
   *score_out = score;
   *hash_out = hash;
   return n;

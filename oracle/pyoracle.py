@@ -148,6 +148,10 @@ class Oracle:
         self.lib.orc_resize(_ptr(img, C.c_ubyte), w, h, _ptr(out, C.c_ubyte), dw, dh)
         return out
 
+    def set_similarity_transform(self, on):
+        """Global switch of the oracle's dialect CPP (Config::with_similarity_transform)."""
+        self.lib.orc_set_similarity_transform(1 if on else 0)
+
     def resize_cv(self, img, dw, dh):
         """Restatement of cv::resize(INTER_LINEAR) for 8-bit gray (parity unpinned)."""
         img = np.ascontiguousarray(img, np.uint8)

@@ -469,3 +469,39 @@ def test_batch_larger_than_workspace_is_processed_in_passes(built, gpu, model_fi
     tr2 = api.Cascador(p).trace(frames)
     for k in tr1:
         assert same(tr1[k], tr2[k]), k
+
+
+@pytest.mark.parametrize("dims", [(3, 20, 5, 4), (2, 70, 9, 5), (4, 12, 27, 3)])
+def test_dialect_cpp_similarity_transform(built, gpu, model_file, dims):
+    """face.similarity_transform = true (data.cpp:64-126): per-stage sR = Calc(shape, mean_shape)
+    applied to node offsets and to the regressed delta; methods 1 and 0.  Unpinned like the rest of
+    dialect CPP (plus cv::norm / Mat_ /= details), bit-exact against the oracle's restatement."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file(dims, 8, seed=51, cart_th=-0.8, norm_every=5, f32_exact=False, w_sigma=6e-3)
+    frames = synth.make_frames(2, 160, 120, seed=52)
+    c, o = api.Cascador(p), Oracle(p)
+    kw = dict(minimum_size=20, step=5, factor=1.2)
+    base = c.trace_cpp(frames, **kw)
+    try:
+        o.set_similarity_transform(True)
+        c.set_similarity_transform(True)
+        _compare_trace_cpp(c, o, frames, **kw)
+        on = c.trace_cpp(frames, **kw)
+        assert not same(on["shapes"], base["shapes"])               # the mode really changes results
+        got = c.detect_batch_cpp(frames, overlap=0.3, nms=True, **kw)
+        pyr = c.detect_batch_cpp_pyramid(frames, 24, 4, 1.25, 0.3, True)
+        for i in range(2):
+            want = o.detect_cpp(frames[i], overlap=0.3, nms=True, **kw)
+            wp = o.detect_cpp_pyramid(frames[i], 24, 4, 1.25, 0.3, True)
+            for k in ("rects", "scores", "shapes"):
+                assert same(got[i][k], want[k]), k
+                assert same(pyr[i][k], wp[k]), k
+        c.set_similarity_transform(False)
+        o.set_similarity_transform(False)
+        _compare_trace_cpp(c, o, frames, **kw)                      # and switching back restores the default
+        back = c.trace_cpp(frames, **kw)
+        for k in base:
+            assert same(back[k], base[k]), k
+    finally:
+        o.set_similarity_transform(False)
