@@ -258,10 +258,12 @@ static bool upload_model(Cascador* c) {
   }
   std::vector<uint8_t> cnorm(carts);
   for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
+  std::vector<Real> par0((size_t)h.K * 4);       // stage 0: {th, mean, std, norm} per cart for k_scan
+  for (int k = 0; k < h.K; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cmean[k]; par0[4 * k + 2] = cstd[k]; par0[4 * k + 3] = cnorm[k] ? (Real)1 : (Real)0; }
 
   Carver sz(nullptr);
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
-  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim);
+  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
   Node* d_nodes = cv.take<Node>(nodes.size());
@@ -273,6 +275,7 @@ static bool upload_model(Cascador* c) {
   Real* d_w = cv.take<Real>(w.size());
   Real* d_ms = cv.take<Real>(dim);
   Real* d_ms_raw = cv.take<Real>(dim);
+  Real* d_par0 = cv.take<Real>(par0.size());
   JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
@@ -282,11 +285,13 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_w, w.data(), w.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
+  m.par0 = d_par0;
   mo.ready = true;
   return true;
 }
@@ -315,8 +320,10 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
     auto try_tile = [&](int tw, int th, int limit) {
       if (d.tiled) return;
       const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
-      int pitch = (pw + 3 + 3) & ~3;
-      if ((pitch & 127) == 0) pitch += 4;     // keep tile rows off a 32-bank multiple
+      // rows are whole 16-byte chunks so that the tile can be filled by LDS-DMA loads; tile
+      // origins are multiples of 16 pixels (tw is 16 or 32), so no extra lead-in is needed
+      int pitch = (pw + 15) & ~15;
+      if ((pitch & 127) == 0) pitch += 16;    // keep tile rows off a 32-bank multiple
       const long long bytes = (long long)pitch * ph;
       if (bytes > limit || bytes > 65535) return;   // S0Node offsets are 16-bit
       d.tiled = 1; d.tw = tw; d.th = th; d.pitch = pitch;

@@ -76,6 +76,7 @@ struct DevModelT {
   const Real* cmean;       // [T*K]
   const Real* cstd;        // [T*K]
   const uint8_t* cnorm;    // [T*K] 1 where (mean,std) != (0,1)
+  const void* par0;        // stage 0 only: {th, mean, std, norm} per cart, packed for k_scan's LDS staging
   const Real* w;           // [T][K*leaf_n][dim]
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)

@@ -321,6 +321,26 @@ __device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __res
   }
 }
 
+// global -> LDS by LDS-DMA (16 bytes per lane, no VGPR round trip); falls back to stage_to_lds
+// for sources that are not 16-byte aligned and for the tail.  The caller waits vmcnt(0) + barrier.
+template <int BLOCK>
+__device__ __forceinline__ void dma_to_lds(unsigned char* lds_dst, const void* __restrict__ src, int nbytes, int tid) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const unsigned char* g = (const unsigned char*)src;
+  int done = 0;
+  if ((((uintptr_t)g) & 15) == 0) {
+    const int chunks = nbytes >> 4;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = wv * 64; base < chunks; base += BLOCK) {
+      if (base + lane < chunks)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + ((size_t)(base + lane) << 4)), (lds_ptr_t)(lds_dst + (base << 4)), 16, 0, 0);
+    }
+    done = chunks << 4;
+  }
+  stage_to_lds<unsigned char, BLOCK, 4>(lds_dst + done, g + done, nbytes - done, tid);
+}
+
 template <typename Real, int DEPTH, bool TRACE, bool GLB>
 __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                               const S0Node* __restrict__ table, WorkT<Real> w,
@@ -392,6 +412,28 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
   const int xshift = x0 - x0a;
   if (GLB) {
     pix = img + (size_t)y0 * W + x0;          // window origins are offsets from the tile origin in the frame
+  } else if (((W & 15) | (x0 & 15) | (int)(w.frame_stride & 15) | (int)(((uintptr_t)w.frames) & 15)) == 0) {
+    // LDS-DMA: `global_load_lds_dwordx4` moves 16 bytes per lane straight from the frame into
+    // LDS (no VGPR round trip); a wave instruction fills 1 KiB of consecutive LDS, i.e. 64
+    // consecutive 16-byte chunks of the row-major tile.  All of a wave's loads are in flight
+    // together; one vmcnt(0) before the barrier.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const int cpr = lv.pitch >> 4;                       // chunks per tile row
+    const int nchunks = ph * cpr;
+    const int maxcol = ((W - x0) >> 4) - 1;              // last chunk that ends inside the frame row
+    int i = wv * 64 + lane;
+    int row = i / cpr, col = i - row * cpr;
+    const int dr = 256 / cpr, dc = 256 - dr * cpr;
+    const uint8_t* g0 = img + (size_t)y0 * W + x0;
+    for (int base = wv * 64; base < nchunks; base += 256) {
+      if (i < nchunks) {
+        const uint8_t* g = g0 + (size_t)row * W + (min(col, maxcol) << 4);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(lds + L.pix + (base << 4)), 16, 0, 0);
+      }
+      i += 256; row += dr; col += dc;
+      if (col >= cpr) { col -= cpr; row++; }
+    }
   } else if (al4) {
     const int ndw = (xshift + pw + 3) >> 2;
     const int w4 = W >> 2, p4 = lv.pitch >> 2;
@@ -423,14 +465,11 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
     }
   }
   // ---- stage the tables of carts [0, K): resolved nodes, leaf scores, cart parameters ----
-  stage_to_lds<S0Node, BLOCK, 4>(t_nodes, table + lv.s0_table, K * node_n, tid);
-  stage_to_lds<Real, BLOCK, 4>(t_leaf, m.leaf, K * leaf_n, tid);
-  for (int k = tid; k < K; k += BLOCK) {
-    CartPar<Real> p;
-    p.th = m.cth[k]; p.mean = m.cmean[k]; p.std = m.cstd[k]; p.norm = m.cnorm[k] ? (Real)1 : (Real)0;
-    t_par[k] = p;
-  }
+  dma_to_lds<BLOCK>(lds + L.nodes, table + lv.s0_table, K * node_n * (int)sizeof(S0Node), tid);
+  dma_to_lds<BLOCK>(lds + L.leaf, m.leaf, K * leaf_n * (int)sizeof(Real), tid);
+  dma_to_lds<BLOCK>(lds + L.par, m.par0, K * (int)sizeof(CartPar<Real>), tid);
   if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+  __builtin_amdgcn_s_waitcnt(0);     // vmcnt(0): LDS-DMA tile loads have landed (a barrier does not drain VMEM)
   __syncthreads();
   JDA_STAMP(lv.tw * lv.th);
 
