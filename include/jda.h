@@ -259,6 +259,9 @@ JDA_API long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_dep
 JDA_API int jdaResultsPack(const jdaResult *results, int n, int frame_offset,
                            float *rows, int capacity_rows);
 
+/* Releases n results at once (same as n jdaResultRelease calls). */
+JDA_API void jdaResultsRelease(jdaResult *results, int n);
+
 /* Per-window trace of the dialect-CPP cascade, like jdaTraceBatch but with the
  * fp64 state of reference Validate (src/jda/cascador.cpp:166-211): carts_n is
  * Validate's `n`. */

@@ -110,6 +110,8 @@ def _load():
     lib.jdaSetSimilarityTransform.argtypes = [C.c_void_p, C.c_int]
     lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
     lib.jdaNmsCpp.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int)]
+    lib.jdaResultsRelease.restype = None
+    lib.jdaResultsRelease.argtypes = [C.POINTER(jdaResult), C.c_int]
     lib.jdaResultsPack.argtypes = [C.POINTER(jdaResult), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.jdaModelStreamBytes.restype = C.c_longlong
     lib.jdaModelStreamBytes.argtypes = [C.c_int] * 5
@@ -288,14 +290,12 @@ class Cascador:
             out = np.empty((max(rows, 0), 5 + self.dim), np.float32)
             if rows > 0:
                 lib.jdaResultsPack(res, n, frame_offset, out.ctypes.data_as(C.POINTER(C.c_float)), rows)
-            for i in range(n):
-                lib.jdaResultRelease(res[i])
+            lib.jdaResultsRelease(res, n)
         elif keep_results:
             out = [_take(res[i]) for i in range(n)]
         else:
             out = [res[i].n for i in range(n)]
-            for i in range(n):
-                lib.jdaResultRelease(res[i])
+            lib.jdaResultsRelease(res, n)
         return (out, st.asdict()) if stats else out
 
     # -- parity instrumentation ---------------------------------------------------

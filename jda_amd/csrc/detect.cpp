@@ -1114,6 +1114,14 @@ int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* row
   return (int)total;
 }
 
+void jdaResultsRelease(jdaResult* results, int n) {
+  if (!results) return;
+  for (int i = 0; i < n; i++) {
+    std::free(results[i].bboxes); std::free(results[i].shapes); std::free(results[i].scores);
+    results[i].bboxes = nullptr; results[i].shapes = nullptr; results[i].scores = nullptr; results[i].n = 0;
+  }
+}
+
 long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
   return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
 }
