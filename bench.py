@@ -176,6 +176,7 @@ def main():
         scan_ms = float(np.mean([s["scan_ms"] for s in stats]))
         gpu_ms = float(np.mean([s["gpu_ms"] for s in stats]))
         host_ms = float(np.mean([s["host_ms"] for s in stats]))
+        call_ms = float(np.mean([s["call_ms"] for s in stats]))
         step_bytes = algorithmic_bytes(dims, st["cart_total_n"], st["stage_done_n"][:T], st["patch_n"], n_det)
         scan_bytes = st["scan_cart_n"] * ((D - 1) * 34 + 16) + st["scan_patch_n"] * 2 * L * 4
         info = {
@@ -183,6 +184,7 @@ def main():
             "images_per_s": B * world * steps / el,
             "ms_per_step": el / steps * 1e3,
             "gpu_ms_per_step": gpu_ms, "scan_ms_per_step": scan_ms, "host_post_ms_per_step": host_ms,
+            "call_ms_per_step": call_ms,
             "average_cart_n": st["average_cart_n"], "finish_fraction": st["stage_done_n"][T - 1] / max(1, st["patch_n"]),
             "detections_after_nms": n_det,
             "step_algorithmic_GBps": step_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,

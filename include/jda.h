@@ -147,6 +147,7 @@ typedef struct {
   int scan_launches;          /* launches of the stage-0 scan kernel (one per tiled level) */
   long long handoff_n;        /* windows handed from the scan to the finishing kernel (incl. untiled levels) */
   long long cart_total_n;     /* carts evaluated over ALL windows (roofline accounting) */
+  double call_ms;             /* wall clock of the whole C call                 */
 } jdaStats;
 
 typedef struct {

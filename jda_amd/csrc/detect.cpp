@@ -595,9 +595,12 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       JDA_HIP(hipMemcpyAsync(s.data(), w.out_score, n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
       JDA_HIP(hipMemcpyAsync(sh.data(), w.out_shape, n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
       JDA_HIP(hipStreamSynchronize(st));
+      // back into scan order: sort (gid, arrival index) packed in one word -- gids are unique
+      std::vector<unsigned long long> key(n_out);
+      for (size_t i = 0; i < n_out; i++) key[i] = ((unsigned long long)g[i] << 32) | (unsigned long long)i;
+      std::sort(key.begin(), key.end());
       std::vector<uint32_t> ord(n_out);
-      std::iota(ord.begin(), ord.end(), 0u);
-      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return g[a] < g[b]; });
+      for (size_t i = 0; i < n_out; i++) ord[i] = (uint32_t)(key[i] & 0xffffffffu);
       const size_t o0 = dets->gid.size();
       dets->gid.resize(o0 + n_out); dets->score.resize(o0 + n_out); dets->shape.resize((o0 + n_out) * dim);
       const uint32_t gid_off = (uint32_t)((size_t)f0 * wpf);
@@ -677,6 +680,7 @@ static jdaResult empty_result(int landmark_n) {
 static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
                            float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
                            jdaResult* out) {
+  const double t_call = now_ms();
   // caller holds c->mu
   if (!c || !out || n < 0) { fail("bad arguments"); return -1; }
   const int L = c->hm.L, dim = c->hm.dim();
@@ -733,6 +737,7 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
     }
   }, dets.gid.size() < 20000);
   fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
+  if (opt && opt->stats) opt->stats->call_ms = now_ms() - t_call;
   return 0;
 }
 

@@ -8,17 +8,28 @@
 namespace jda {
 
 std::vector<int> nms_dialect_c(const int* bb, const float* scores, int n, float overlap) {
-  std::vector<int> order(n);
+  // scratch reused across calls on this thread (the per-frame lists are short and many)
+  static thread_local std::vector<int> order;
+  static thread_local std::vector<char> keep;
+  order.resize(n);
   std::iota(order.begin(), order.end(), 0);
   // The reference orders candidates with an exchange sort under a strict `<`
   // (c/jda.c:256-264). When all scores are distinct its result is THE
-  // descending order, which a stable sort finds in O(n log n). With ties (or
-  // NaN) the exchange sort's permutation is replayed literally.
+  // descending order, which any stable sort finds. With ties (or NaN) the
+  // exchange sort's permutation is replayed literally.
   bool literal = false;
   for (int i = 0; i < n && !literal; i++) literal = std::isnan(scores[i]);
   if (!literal) {
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return scores[a] > scores[b]; });
+    if (n <= 64) {                      // insertion sort: stable, no allocation
+      for (int i = 1; i < n; i++) {
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && scores[order[j]] < scores[v]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = v;
+      }
+    } else {
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+    }
     for (int i = 0; i + 1 < n && !literal; i++) literal = scores[order[i]] == scores[order[i + 1]];
   }
   if (literal) {
@@ -28,7 +39,7 @@ std::vector<int> nms_dialect_c(const int* bb, const float* scores, int n, float 
         if (scores[order[i]] < scores[order[j]]) std::swap(order[i], order[j]);
   }
 
-  std::vector<char> keep(n, 1);
+  keep.assign(n, 1);
   for (int i = 0; i + 1 < n; i++) {                       // c/jda.c:267-284
     const int a = order[i];
     if (!keep[a]) continue;
