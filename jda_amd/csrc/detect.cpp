@@ -108,6 +108,7 @@ struct PlanEntry {
   S0Node* table = nullptr;
   bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
   bool any_untiled = false;
+  unsigned long long last_use = 0;
 };
 
 template <typename Real>
@@ -132,6 +133,7 @@ struct Cascador {
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
+  unsigned long long plan_clock = 0;
   Workspace<float> wf;
   Workspace<double> wd;
   unsigned long long* h_counters = nullptr;  // pinned
@@ -347,7 +349,18 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
 
 static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out) {
   auto it = c->plans.find(key);
-  if (it != c->plans.end()) { *out = &it->second; return true; }
+  if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; *out = &it->second; return true; }
+  // bounded cache: a stream of differently sized images (FDDB) must not pile up device tables
+  const size_t cap = (size_t)std::max<long long>(2, env_ll("JDA_PLAN_CACHE", 64));
+  while (c->plans.size() >= cap) {
+    auto victim = c->plans.begin();
+    for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
+      if (p->second.last_use < victim->second.last_use) victim = p;
+    (void)hipStreamSynchronize(c->stream);
+    if (victim->second.dp) (void)hipFree(victim->second.dp);
+    if (victim->second.table) (void)hipFree(victim->second.table);
+    c->plans.erase(victim);
+  }
   if ((int)sp.levels.size() > kMaxLevels) { fail("too many pyramid levels"); return false; }
   if (sp.windows * 1LL > 0x7fffffffLL) { fail("frame has too many windows"); return false; }
   if (sp.width > 65535 || sp.height > 65535) { fail("frames wider or taller than 65535 pixels are not supported"); return false; }
@@ -370,6 +383,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
     JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream));
   }
+  pe.last_use = ++c->plan_clock;
   auto ins = c->plans.emplace(key, std::move(pe));
   *out = &ins.first->second;
   return true;

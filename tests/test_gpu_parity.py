@@ -505,3 +505,18 @@ def test_dialect_cpp_similarity_transform(built, gpu, model_file, dims):
             assert same(back[k], base[k]), k
     finally:
         o.set_similarity_transform(False)
+
+
+def test_plan_cache_is_bounded(built, gpu, model_file, monkeypatch):
+    """A stream of differently sized images (the FDDB case) evicts old scan plans instead of
+    accumulating device tables; results are unaffected by eviction and re-creation."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("JDA_PLAN_CACHE", "3")
+    p, _ = model_file((3, 20, 5, 4), 8, seed=61, cart_th=-0.9)
+    c, o = api.Cascador(p), Oracle(p)
+    sizes = [(120 + 7 * i, 100 + 5 * i) for i in range(8)]
+    imgs = [synth.make_frames(1, w, h, seed=i)[0] for i, (w, h) in enumerate(sizes)]
+    for rep in range(2):
+        for im in imgs + imgs[::-1]:
+            _compare_detect(c.detect(im), o.detect(im))
