@@ -148,6 +148,7 @@ typedef struct {
   long long handoff_n;        /* windows handed from the scan to the finishing kernel (incl. untiled levels) */
   long long cart_total_n;     /* carts evaluated over ALL windows (roofline accounting) */
   double call_ms;             /* wall clock of the whole C call                 */
+  int dense_passes;           /* passes that ran in dense mode (whole stages per window tile, k_stage) */
 } jdaStats;
 
 typedef struct {

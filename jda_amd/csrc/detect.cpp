@@ -108,6 +108,7 @@ struct PlanEntry {
   S0Node* table = nullptr;
   bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
   bool any_untiled = false;
+  bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
   unsigned long long last_use = 0;
 };
 
@@ -260,8 +261,8 @@ static bool upload_model(Cascador* c) {
   }
   std::vector<uint8_t> cnorm(carts);
   for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
-  std::vector<Real> par0((size_t)h.K * 4);       // stage 0: {th, mean, std, norm} per cart for k_scan
-  for (int k = 0; k < h.K; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cmean[k]; par0[4 * k + 2] = cstd[k]; par0[4 * k + 3] = cnorm[k] ? (Real)1 : (Real)0; }
+  std::vector<Real> par0(carts * 4);             // {th, mean, std, norm} per cart, packed for LDS staging
+  for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cmean[k]; par0[4 * k + 2] = cstd[k]; par0[4 * k + 3] = cnorm[k] ? (Real)1 : (Real)0; }
 
   Carver sz(nullptr);
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
@@ -393,7 +394,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
 
 template <typename Real>
 static size_t bytes_per_window(int dim, bool trace) {
-  size_t b = (4 + sizeof(Real) + 4 + 8) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real)) + 8;
+  size_t b = (4 + sizeof(Real) + 4 + 8) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real)) + 8 + 4;
   if (trace) b += 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
   return b;
 }
@@ -417,6 +418,7 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
     w.m_shape = cv.take<Real>(cap * dim);
     w.m_xy = cv.take<uint32_t>(cap);
     w.m_wf = cv.take<uint32_t>(cap);
+    w.st_carts = cv.take<int>(cap);
     w.out_gid = cv.take<uint32_t>(cap);
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
@@ -460,6 +462,7 @@ struct RunStats {
   long long stage_done[kMaxStages] = {0};
   double gpu_ms = 0, scan_ms = 0;
   int scan_launches = 0;
+  int dense_passes = 0;
 };
 
 // Runs the device pipeline over n frames resident in device memory.
@@ -528,6 +531,29 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
       JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
     }
+    // ---- dense mode (k_stage): when most windows survive the first carts, whole stages are
+    //      walked tile by tile instead of window by window.  Decided from the previous pass on
+    //      this plan (pe->dense_hint) or, below, from the hand-off count of this pass; the
+    //      results do not depend on the choice. ----
+    const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
+    const int dense_lds_max = (int)env_ll("JDA_DENSE_LDS_MAX", 160 * 1024);
+    const int dense_fixed = (int)stage_lds_bytes(dim, hm.node_n(), hm.leaf_n(), (int)sizeof(Real));
+    const bool dense_ok = dense_env != 0 && !multi && !(dialect == JDA_DIALECT_CPP && c->similarity) &&
+                          dim <= 160 && hm.leaf_n() <= 256 && dense_fixed <= dense_lds_max;
+    const int dense_pix_cap = std::max(0, std::min<int>((int)env_ll("JDA_DENSE_PIX", 16 * 1024), dense_lds_max - dense_fixed));
+    const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
+    auto run_dense = [&]() -> bool {
+      for (int t = 0; t < T; t++)
+        for (int l = 0; l < pe->hp.n_levels; l++)
+          JDA_HIP(launch_stage<Real>(want_trace, l, t, apply_th, th, pe->dp, pe->hp, m, w, dense_pix_cap, dense_lds_max, st));
+      return true;
+    };
+    bool dense = dense_ok && (dense_env == 2 || pe->dense_hint);
+    if (dense) {
+      JDA_HIP(hipEventRecord(c->ev[1], st));
+      JDA_HIP(hipEventRecord(c->ev[2], st));
+      if (!run_dense()) return false;
+    } else {
     // ---- windows k_scan does not cover enter the hand-off queue at cart 0 ----
     if (!pe->fast_scan || pe->any_untiled) JDA_HIP(launch_enqueue<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
     // ---- stage-0 scan: first `handoff` carts, one launch per tiled level ----
@@ -573,7 +599,18 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     };
     long long n_tail = -1, n_mid = -1;
     if (!queue_len(kCntTail, &n_tail)) return false;
-    if (T > 1 && n_tail >= 0 && n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
+    if (dense_ok && n_tail >= 0 && (double)n_tail >= dense_frac * (double)nf * (double)wpf && n_tail > 4096) {
+      // most windows are still alive after the scan: start over in dense mode (the scan's work
+      // is a small part of T*K carts per window) and remember the choice for the next pass
+      dense = true;
+      pe->dense_hint = true;
+      JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntShards * kCntStride, st));
+      if (want_trace) {
+        JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
+        JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
+      }
+      if (!run_dense()) return false;
+    } else if (T > 1 && n_tail >= 0 && n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
       JDA_HIP(launch_finish<Real>(want_trace, 0, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_GM", 4), n_tail, st));
@@ -584,6 +621,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
         JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
       }
     }
+    }   // !dense
     JDA_HIP(hipEventRecord(c->ev[3], st));
     JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
     JDA_HIP(hipStreamSynchronize(st));
@@ -598,6 +636,11 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     rs->win_scan += (long long)c->h_counters[kCntWinScan];
     for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntStage0 + t];
     rs->tail += (long long)c->h_counters[kCntTail];
+    if (dense) {
+      rs->dense_passes++;
+      // fall back to the sparse pipeline when stage 0 rejects most windows after all
+      if ((double)c->h_counters[kCntStage0] < 0.5 * dense_frac * (double)nf * (double)wpf) pe->dense_hint = false;
+    }
     const size_t n_out = (size_t)c->h_counters[kCntOut];
     rs->out += (long long)n_out;
     if (n_out > cap) { fail("internal: more detections than windows"); return false; }
@@ -679,6 +722,7 @@ static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int 
   st->gpu_ms = rs.gpu_ms; st->scan_ms = rs.scan_ms; st->host_ms = host_ms;
   st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
   st->handoff_n = rs.tail;
+  st->dense_passes = rs.dense_passes;
 }
 
 static jdaResult empty_result(int landmark_n) {

@@ -76,7 +76,7 @@ struct DevModelT {
   const Real* cmean;       // [T*K]
   const Real* cstd;        // [T*K]
   const uint8_t* cnorm;    // [T*K] 1 where (mean,std) != (0,1)
-  const void* par0;        // stage 0 only: {th, mean, std, norm} per cart, packed for k_scan's LDS staging
+  const void* par0;        // {th, mean, std, norm} per cart [T*K], packed for LDS staging (k_scan, k_stage)
   const Real* w;           // [T][K*leaf_n][dim]
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
@@ -95,6 +95,9 @@ struct WorkT {
   unsigned long long* counters;                                // see Counter
   // mid queue: windows alive after stage 0, with their regressed shape (k_finish pass 1 -> pass 2)
   uint32_t* m_gid; Real* m_score; uint32_t* m_hash; Real* m_shape; uint32_t* m_xy; uint32_t* m_wf;
+  // dense mode (k_stage): per-window state indexed by gid -- m_score / m_hash / m_shape are reused as
+  // score / hash / shape, st_carts holds carts evaluated (-1 = still alive)
+  int* st_carts;
   // final detections: windows that passed every cart and the final threshold
   uint32_t* out_gid; Real* out_score; Real* out_shape;
   // per-window trace (all null when off), indexed by gid
@@ -161,6 +164,14 @@ template <typename Real>
 hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
                          int groups, long long n_hint, hipStream_t stream);
+
+// Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
+// pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).
+template <typename Real>
+hipError_t launch_stage(bool trace, int level, int t, bool apply_final_th, Real final_th, const DevPlan* d_plan,
+                        const DevPlan& h_plan, const DevModelT<Real>& m, const WorkT<Real>& w, int pix_cap,
+                        int lds_max, hipStream_t stream);
+size_t stage_lds_bytes(int dim, int node_n, int leaf_n, int real_bytes);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

@@ -520,3 +520,56 @@ def test_plan_cache_is_bounded(built, gpu, model_file, monkeypatch):
     for rep in range(2):
         for im in imgs + imgs[::-1]:
             _compare_detect(c.detect(im), o.detect(im))
+
+
+# ---------------------------------------------------------------- dense mode (k_stage)
+
+@pytest.mark.parametrize("dims,cart_th", [((3, 70, 9, 5), None), ((3, 70, 9, 5), -0.4), ((2, 130, 27, 4), -0.2),
+                                          ((4, 12, 40, 3), None)])
+def test_dense_mode_is_a_third_implementation_of_the_walk(built, gpu, model_file, monkeypatch, dims, cart_th):
+    """Tile-per-workgroup whole-stage kernel vs the scan + wave-per-window pipeline vs the oracle:
+    same carts_n / score / hash / shape bits, same detections, same counters.  `auto` picks it when most
+    windows survive the scan; `2` forces it even for a rejecting cascade (tiles die off early)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    kw = {} if cart_th is None else {"cart_th": cart_th, "norm_every": 7}
+    p, _ = model_file(dims, 8, seed=61, **kw)
+    frames = synth.make_frames(3, 333, 250, seed=62)
+    o = Oracle(p)
+    monkeypatch.setenv("JDA_DENSE", "0")
+    c0 = api.Cascador(p)
+    tr0 = c0.trace(frames)
+    d0, s0 = c0.detect_batch(frames, stats=True)
+    assert s0["dense_passes"] == 0
+    for mode in ("2", "1"):
+        monkeypatch.setenv("JDA_DENSE", mode)
+        c = api.Cascador(p)
+        _compare_trace(c, o, frames[:1])
+        tr = c.trace(frames)
+        for k in tr0:
+            assert same(tr0[k], tr[k]), (mode, k)
+        d, s = c.detect_batch(frames, stats=True)
+        for a, b in zip(d, d0):
+            _compare_detect(a, b)
+        for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n"):
+            assert s[k] == s0[k], (mode, k)
+        assert list(s["stage_done_n"]) == list(s0["stage_done_n"])
+        if mode == "2" or cart_th is None:
+            assert s["dense_passes"] >= 1, "dense mode did not run"
+
+
+def test_dense_mode_dialect_cpp(built, gpu, model_file, monkeypatch):
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 20, 5, 4), 8, seed=63)
+    frames = synth.make_frames(2, 200, 150, seed=64)
+    monkeypatch.setenv("JDA_DENSE", "2")
+    c, o = api.Cascador(p), Oracle(p)
+    g = c.trace_cpp(frames, 20, 5, 1.2)
+    off = 0
+    for i in range(len(frames)):
+        r = o.trace_cpp(frames[i], 20, 5, 1.2)
+        n = len(r["carts_n"])
+        for k in ("carts_n", "score", "path_hash", "shapes"):
+            assert same(r[k], g[k][off:off + n]), (i, k)
+        off += n
