@@ -55,6 +55,35 @@ struct DialectC {           // reference c/jda.c
     const float v = (s + o) * (float)win;
     return to_int_x86(v);
   }
+  // clamp_win(coord(s, o, win), win) in 4 instructions instead of 8 (the walks are VALU bound).
+  // v_cvt_i32_f32 saturates: NaN -> 0, v >= 2^31 -> INT_MAX, v <= -2^31 -> INT_MIN, where x86
+  // gives INT_MIN for all three, which the clamp then turns into 0.  No float below 2^31
+  // converts to INT_MAX (the largest is 2^31 - 128), so INT_MAX marks exactly the positive
+  // overflow; r + 1 wraps it to INT_MIN, and median(r + 1, 1, win) - 1 is the clamped pixel:
+  // NaN -> 0, either overflow -> 0, r < 0 -> 0, r >= win -> win - 1.
+  static __device__ __forceinline__ int pixel(float s, float o, int win) {
+    const float v = (s + o) * (float)win;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    const int r1 = (int)((unsigned)r + 1u);
+    int m;
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(m) : "v"(r1), "v"(win));
+    return m - 1;
+  }
+  // The same for an (x, y) pair, returned 1-BASED (kBias): the caller folds the -1s into its
+  // tile base address.  The add and the multiply are packed (two independent IEEE operations).
+  static constexpr int kBias = 1;
+  static __device__ __forceinline__ void pixel_pair(float sx, float sy, float ox, float oy, int win, int* x, int* y) {
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    const float fw = (float)win;
+    const V2 v = (V2{sx, sy} + V2{ox, oy}) * V2{fw, fw};
+    int rx, ry;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(rx) : "v"(v.x));
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ry) : "v"(v.y));
+    const int rx1 = (int)((unsigned)rx + 1u), ry1 = (int)((unsigned)ry + 1u);
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(*x) : "v"(rx1), "v"(win));
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(*y) : "v"(ry1), "v"(win));
+  }
 };
 
 struct DialectCPP {         // reference src/jda (Validate / CalcFeatureValue)
@@ -64,6 +93,11 @@ struct DialectCPP {         // reference src/jda (Validate / CalcFeatureValue)
   static __device__ __forceinline__ int coord(double s, double o, int win) {
     const double v = (s + o) * (double)win;
     return to_int_x86(round(v));
+  }
+  static __device__ __forceinline__ int pixel(double s, double o, int win) { return clamp_win(coord(s, o, win), win); }
+  static constexpr int kBias = 0;
+  static __device__ __forceinline__ void pixel_pair(double sx, double sy, double ox, double oy, int win, int* x, int* y) {
+    *x = clamp_win(coord(sx, ox, win), win); *y = clamp_win(coord(sy, oy, win), win);
   }
 };
 
@@ -883,12 +917,12 @@ __device__ __forceinline__ int node_feature(typename DL::Node nd, const typename
     nd.o1x = ax; nd.o1y = ay; nd.o2x = bx; nd.o2y = by;
   }
   if (!MULTI) {
-    const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win);
-    const int y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
-    const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win);
-    const int y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
-    const int a = v0.img[(unsigned)((v0.oy + y1) * v0.w + v0.ox + x1)];
-    const int b = v0.img[(unsigned)((v0.oy + y2) * v0.w + v0.ox + x2)];
+    // (DL::pixel's fused clamp does not pay here: k_finish is not VALU bound, measured 3 % slower)
+    const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win), y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
+    const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win), y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
+    // rows and widths are below 2^16: 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate)
+    const int a = v0.img[__umul24((unsigned)(v0.oy + y1), (unsigned)v0.w) + (unsigned)(v0.ox + x1)];
+    const int b = v0.img[__umul24((unsigned)(v0.oy + y2), (unsigned)v0.w) + (unsigned)(v0.ox + x2)];
     return a - b;
   }
   // Multi-scale models.  Dialect C scales and clamps with the FULL window side for
@@ -1291,7 +1325,9 @@ struct DenseLds {
 }  // namespace
 
 template <typename DL, bool TRACE, bool GLB, int ACC>
-__global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
+__global__ __launch_bounds__(kDenseM)
+__attribute__((amdgpu_waves_per_eu(ACC * (int)sizeof(typename DL::Real) <= 256 ? 2 : 1)))   // LDS allows 2-3 workgroups per CU
+void k_stage(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                    WorkT<typename DL::Real> w, int level, int t, int pix_bytes,
                                                    int pitch, int chunk, int apply_th, typename DL::Real final_th) {
   using Real = typename DL::Real;
@@ -1344,17 +1380,24 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
   int xshift = 0, ppitch = pitch;
   if (GLB) { pix = img + (size_t)y0 * W + x0; ppitch = W; }
   else xshift = load_tile<BLOCK>(lds + L.pix, w.frames, w.frame_stride, img, W, x0, y0, pw, ph, pitch, tid);
-  const int base = (wy * lv.step) * ppitch + wx * lv.step + xshift;
+  const int base = (wy * lv.step) * ppitch + wx * lv.step + xshift - DL::kBias * (ppitch + 1);   // pixel_pair is kBias-based
 
   // stage-start shape: LDS column for the tree walks; the regression sums start from it
-  // (dialect C) or from zero (dialect CPP, btcart.cpp:407-424)
-  Real acc[ACC];
+  // (dialect C) or from zero (dialect CPP, btcart.cpp:407-424).  The sums are kept as (x, y)
+  // pairs: rows are read 2 coordinates at a time and added with one packed add (two
+  // independent IEEE adds -- same bits as two scalar ones).
+  typedef Real Vec2 __attribute__((ext_vector_type(2)));
+  Vec2 acc[ACC / 2];
   {
     const Real* src = (t == 0 || !alive) ? m.mean_shape : w.m_shape + (size_t)gid * dim;
 #pragma unroll
-    for (int d = 0; d < ACC; d++) {
-      acc[d] = 0;
-      if (d < dim) { const Real v = src[d]; sh[d * BLOCK + tid] = v; if (!kCpp) acc[d] = v; }
+    for (int d2 = 0; d2 < ACC / 2; d2++) {
+      acc[d2] = Vec2{0, 0};
+      if (2 * d2 < dim) {
+        const Real vx = src[2 * d2], vy = src[2 * d2 + 1];
+        sh[(2 * d2) * BLOCK + tid] = vx; sh[(2 * d2 + 1) * BLOCK + tid] = vy;
+        if (!kCpp) acc[d2] = Vec2{vx, vy};
+      }
     }
   }
   int carts_n = -1;
@@ -1364,6 +1407,7 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
   const CartPar<Real>* g_par = (const CartPar<Real>*)m.par0 + (size_t)t * K;
   const Real* g_w = m.w + (size_t)t * K * leaf_n * dim;
 
+#pragma nounroll
   for (int c0 = 0; c0 < K; c0 += chunk) {
     const int cn = min(chunk, K - c0);
     if (__syncthreads_or(alive ? 1 : 0) == 0) break;          // also: previous chunk's table readers are done
@@ -1373,6 +1417,7 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
     dma_to_lds<BLOCK>(lds + L.wts, g_w + (size_t)c0 * leaf_n * dim, cn * leaf_n * dim * (int)sizeof(Real), tid);
     __builtin_amdgcn_s_waitcnt(0);                    // vmcnt(0): DMA (tile on the first pass, tables) has landed
     __syncthreads();
+#pragma nounroll
     for (int kk = 0; kk < cn; kk += G) {
       if (__ballot(alive) == 0ull) break;
       if (!alive) continue;
@@ -1380,6 +1425,7 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
       int node[G], kc[G];
 #pragma unroll
       for (int g = 0; g < G; g++) { node[g] = 0; kc[g] = min(kk + g, cn - 1); }
+#pragma nounroll
       for (int d = 0; d < depth; d++) {
         Node nd[G];
 #pragma unroll
@@ -1393,12 +1439,11 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
         int pa[G], pb[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
-          const int x1 = clamp_win(DL::coord(sv[g][0], nd[g].o1x, win), win);
-          const int y1 = clamp_win(DL::coord(sv[g][1], nd[g].o1y, win), win);
-          const int x2 = clamp_win(DL::coord(sv[g][2], nd[g].o2x, win), win);
-          const int y2 = clamp_win(DL::coord(sv[g][3], nd[g].o2y, win), win);
-          pa[g] = pix[base + y1 * ppitch + x1];
-          pb[g] = pix[base + y2 * ppitch + x2];
+          int x1, y1, x2, y2;
+          DL::pixel_pair(sv[g][0], sv[g][1], nd[g].o1x, nd[g].o1y, win, &x1, &y1);
+          DL::pixel_pair(sv[g][2], sv[g][3], nd[g].o2x, nd[g].o2y, win, &x2, &y2);
+          pa[g] = pix[__umul24((unsigned)y1, (unsigned)ppitch) + (unsigned)x1 + (unsigned)base];   // 24-bit multiply: full rate
+          pb[g] = pix[__umul24((unsigned)y2, (unsigned)ppitch) + (unsigned)x2 + (unsigned)base];
         }
 #pragma unroll
         for (int g = 0; g < G; g++) node[g] = 2 * node[g] + ((pa[g] - pb[g] <= nd[g].th) ? 1 : 2);   // c/jda.c:391-393
@@ -1413,9 +1458,9 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
 #pragma unroll
       for (int g = 0; g < G; g++) {
         if (kk + g < cn) {                                                // wave-uniform
-          const Real* row = t_w + (size_t)((kk + g) * leaf_n + lf[g]) * dim;
+          const Vec2* row = (const Vec2*)(t_w + (size_t)((kk + g) * leaf_n + lf[g]) * dim);   // dim is even: aligned
 #pragma unroll
-          for (int d = 0; d < ACC; d++) acc[d] = acc[d] + row[d];         // coordinates >= dim: slack, never stored
+          for (int d2 = 0; d2 < ACC / 2; d2++) acc[d2] = acc[d2] + row[d2];   // coordinates >= dim: slack, never stored
           if (alive) {
             Real sc = score + lsv[g];                                      // c/jda.c:396
             if (p[g].norm != (Real)0) sc = (sc - p[g].mean) / p[g].std;    // c/jda.c:397
@@ -1433,17 +1478,17 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
     // stage passed: new shape (dialect CPP adds the identity-transformed delta once, btcart.cpp:407-424)
     Real* dst = w.m_shape + (size_t)gid * dim;
 #pragma unroll
-    for (int d = 0; d < ACC; d++) {
-      if (d < dim) {
-        Real v = acc[d];
+    for (int d2 = 0; d2 < ACC / 2; d2++) {
+      if (2 * d2 < dim) {
+        Real vx = acc[d2].x, vy = acc[d2].y;
         if (kCpp) {
-          const Real other = acc[d ^ 1];
-          const Real zero = (Real)0, one = (Real)1;
-          v = (d & 1) ? one * (zero * other + one * v) : one * (one * v + zero * other);   // data.hpp:42-45
-          v = sh[d * BLOCK + tid] + v;
+          const Real zero = (Real)0, one = (Real)1;                       // stp_mc.Apply with the identity, data.hpp:42-45
+          const Real ax = one * (one * vx + zero * vy), ay = one * (zero * vx + one * vy);
+          vx = sh[(2 * d2) * BLOCK + tid] + ax;
+          vy = sh[(2 * d2 + 1) * BLOCK + tid] + ay;
         }
-        dst[d] = v;
-        if (TRACE && t == T - 1) w.tr_shape[(size_t)gid * dim + d] = v;
+        dst[2 * d2] = vx; dst[2 * d2 + 1] = vy;
+        if (TRACE && t == T - 1) { w.tr_shape[(size_t)gid * dim + 2 * d2] = vx; w.tr_shape[(size_t)gid * dim + 2 * d2 + 1] = vy; }
       }
     }
     atomicAdd(shard_counter(w.counters, kCntStage0 + t), 1ull);
@@ -1471,20 +1516,28 @@ __global__ __launch_bounds__(kDenseM) void k_stage(const DevPlan* __restrict__ p
 namespace {
 inline int dense_acc(int dim) { return dim <= 12 ? 12 : dim <= 32 ? 32 : dim <= 64 ? 64 : 160; }
 
-// Cart chunk and LDS budget of one k_stage launch.  Tiers: 3, 2 or 1 workgroups per CU (160 KB
-// of LDS); the smallest tier that fits any chunk wins (measured: two resident workgroups with
-// 4-cart chunks beat one with 32-cart chunks), and within it the longest chunk.  lds_max caps
-// the tiers (returns 0: nothing fits).
+// Cart chunk and LDS budget of one k_stage launch.  The walk is latency bound (measured: LDS
+// and VALU are each under half busy), so resident workgroups count more than chunk length:
+// 16-cart chunks cost nothing against 64, 4-cart chunks ~10 %.  Tiers = 5, 4, 3, 2, 1 workgroups
+// per CU (160 KB of LDS): first the smallest tier that fits a 16-cart chunk among the tiers
+// with >= 3 workgroups, else the smallest tier that fits any chunk (two resident workgroups
+// with 4-cart chunks beat one with 32-cart chunks).  lds_max caps the tiers (0: nothing fits).
 template <typename Real, typename Node>
 int dense_chunk(int pix_bytes, int dim, int node_n, int leaf_n, int K, int lds_max) {
   const int acc = dense_acc(dim);
-  const int tiers[3] = {53248, 81920, 163840};
+  const int tiers[5] = {32768, 40960, 53248, 81920, 163840};
+  auto fits = [&](int ch, int budget) {
+    return DenseLds<Real, Node>(pix_bytes, dim, node_n, leaf_n, ch, acc).total <= (budget < lds_max ? budget : lds_max);
+  };
   for (int ti = 0; ti < 3; ti++) {
-    const int budget = tiers[ti] < lds_max ? tiers[ti] : lds_max;
-    for (int ch = 64; ch >= 4; ch >>= 1)
-      if (DenseLds<Real, Node>(pix_bytes, dim, node_n, leaf_n, ch, acc).total <= budget) return ch;
-    if (budget == lds_max) break;
+    if (!fits(16, tiers[ti])) continue;
+    int ch = 16;
+    while (ch < 64 && fits(ch * 2, tiers[ti])) ch *= 2;
+    return ch;
   }
+  for (int ti = 0; ti < 5; ti++)
+    for (int ch = 64; ch >= 4; ch >>= 1)
+      if (fits(ch, tiers[ti])) return ch;
   return 0;
 }
 
@@ -1502,8 +1555,9 @@ hipError_t launch_stage_impl(bool trace, int level, int t, bool apply_th, typena
   const bool glb = need > pix_cap;
   const int pix_bytes = glb ? 0 : (int)need;
   const int acc = dense_acc(m.dim);
-  const int chunk = dense_chunk<Real, Node>(pix_bytes, m.dim, m.node_n, m.leaf_n, m.K, lds_max);
+  int chunk = dense_chunk<Real, Node>(pix_bytes, m.dim, m.node_n, m.leaf_n, m.K, lds_max);
   if (chunk == 0) return hipErrorInvalidValue;
+  if (const char* e = getenv("JDA_DENSE_CHUNK")) chunk = std::max(4, std::min(chunk, atoi(e)));   // experiments
   const DenseLds<Real, Node> L(pix_bytes, m.dim, m.node_n, m.leaf_n, chunk, acc);
   const int tiles = ((lv.nx + kDenseTw - 1) / kDenseTw) * ((lv.ny + kDenseTh - 1) / kDenseTh);
   const int groups = (w.n_frames + 7) / 8;
