@@ -190,6 +190,7 @@ def main():
             "step_algorithmic_GBps": step_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
             "scan_algorithmic_bytes": scan_bytes, "scan_launches": st["scan_launches"],
             "scan_window_fraction": st["scan_patch_n"] / max(1, st["patch_n"]),
+            "dense_passes_per_step": st["dense_passes"],
         }
         casc.close()
         return info, mp

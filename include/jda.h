@@ -140,7 +140,8 @@ typedef struct {
   long long stage_done_n[16]; /* windows that completed stage t (shape update) */
   double average_cart_n;      /* cart_gothrough_n / nonface_patch_n           */
   double gpu_ms;              /* device time of the call (HIP events)         */
-  double scan_ms;             /* device time of the stage-0 scan kernel alone */
+  double scan_ms;             /* device time of the stage-0 scan launches (first start to last end; */
+                              /* two sub-batches scan side by side on big batches)                  */
   double host_ms;             /* host post-processing (sort, NMS, relocation) */
   long long scan_cart_n;      /* part of cart_gothrough_n done by the stage-0 scan kernel */
   long long scan_patch_n;     /* windows the stage-0 scan kernel covered      */

@@ -276,11 +276,13 @@ class Cascador:
 
     # -- batch resident in device memory (torch uint8 CUDA tensor [n,h,w]) ------------
     def detect_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True,
-                            stats=False, keep_results=True, frame_offset=0):
+                            stats=False, keep_results=True, frame_offset=0, hip_stream=None):
         assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
         n, h, w = d_frames.shape
         res = (jdaResult * max(n, 1))()
         o, st = self._opts(nms, stats)
+        if hip_stream is not None:      # a hipStream_t handle (e.g. torch.cuda.Stream().cuda_stream): work is ordered on it
+            o.hip_stream = C.c_void_p(hip_stream)
         rc = lib.jdaDetectBatchDevice(self.h, C.c_void_p(d_frames.data_ptr()), h * w, n, w, h, scale, 0.1,
                                       min_size, max_size, th, C.byref(o), res)
         if rc != 0:

@@ -112,15 +112,18 @@ struct PlanEntry {
   unsigned long long last_use = 0;
 };
 
+constexpr int kLanes = 2;     // sub-batches in flight at once, each on its own stream + workspace
+
 template <typename Real>
 struct Workspace {
   DevBuf buf;
   DevBuf frames;     // staging for host-frame entry points
   DevBuf pyr;        // half + quarter images (multi-scale models)
-  WorkT<Real> w{};
+  WorkT<Real> w[kLanes] = {};   // one carving per lane (run_device)
   size_t cap = 0;
   bool trace = false;
   int dim = 0;
+  int lanes = 0;
 };
 
 struct Cascador {
@@ -129,8 +132,9 @@ struct Cascador {
   int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
   bool dev_init = false;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream[kLanes] = {nullptr, nullptr};                  // one per lane, see Pass / run_device
+  hipEvent_t ev[kLanes][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t ev_user = nullptr;
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -173,9 +177,10 @@ static bool ensure_device(Cascador* c) {
   }
   if (c->device >= n) { fail("device ordinal out of range"); return false; }
   JDA_HIP(hipSetDevice(c->device));
-  JDA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (auto& ev : c->ev) JDA_HIP(hipEventCreate(&ev));
-  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipHostMallocDefault));
+  for (auto& st : c->stream) JDA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  for (auto& lane : c->ev) for (auto& ev : lane) JDA_HIP(hipEventCreate(&ev));
+  JDA_HIP(hipEventCreate(&c->ev_user));
+  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntShards * kCntStride * kLanes, hipHostMallocDefault));
   c->dev_init = true;
   return true;
 }
@@ -334,6 +339,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
     if (fast_scan && (long long)s.nx * s.ny >= 128) {
       for (auto& o : opts) try_tile(o[0], o[1], pref);
       try_tile(16, 16, budget);
+      if (env_ll("JDA_TILE_16x8", 0)) try_tile(16, 8, budget);
     }
     // no LDS tile: k_scan reads the frame through L1/L2 if its offsets fit the packed node
     if (fast_scan && !d.tiled && env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
@@ -357,7 +363,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     auto victim = c->plans.begin();
     for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
       if (p->second.last_use < victim->second.last_use) victim = p;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream[0]);
     if (victim->second.dp) (void)hipFree(victim->second.dp);
     if (victim->second.table) (void)hipFree(victim->second.table);
     c->plans.erase(victim);
@@ -382,7 +388,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     JDA_HIP(hipMalloc((void**)&pe.table, entries * sizeof(S0Node)));
     const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
     const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
-    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream));
+    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream[0]));
   }
   pe.last_use = ++c->plan_clock;
   auto ins = c->plans.emplace(key, std::move(pe));
@@ -400,12 +406,12 @@ static size_t bytes_per_window(int dim, bool trace) {
 }
 
 template <typename Real>
-static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
+static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
   Workspace<Real>& ws = Sel<Real>::ws(c);
   const int dim = c->hm.dim();
-  if (ws.cap >= cap && (ws.trace || !trace) && ws.dim == dim) return true;
-  auto carve = [&](Carver& cv) {
-    WorkT<Real>& w = ws.w;
+  if (ws.cap >= cap && (ws.trace || !trace) && ws.dim == dim && ws.lanes >= lanes) return true;
+  auto carve_lane = [&](Carver& cv, int lane) {
+    WorkT<Real>& w = ws.w[lane];
     w.q_gid = cv.take<uint32_t>(cap);
     w.q_score = cv.take<Real>(cap);
     w.q_kstart = cv.take<uint32_t>(cap);
@@ -433,13 +439,15 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace) {
       w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
     }
   };
+  auto carve = [&](Carver& cv) { for (int l = 0; l < lanes; l++) carve_lane(cv, l); };
+  for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);   // nothing may still use the old carving
   Carver sz(nullptr);
   carve(sz);
   if (!ws.buf.reserve(sz.off + 256)) return false;
   Carver cv(ws.buf.p);
   carve(cv);
-  ws.w.cap = (unsigned)cap;
-  ws.cap = cap; ws.trace = trace; ws.dim = dim;
+  for (int l = 0; l < lanes; l++) ws.w[l].cap = (unsigned)cap;
+  ws.cap = cap; ws.trace = trace; ws.dim = dim; ws.lanes = lanes;
   return true;
 }
 
@@ -465,99 +473,99 @@ struct RunStats {
   int dense_passes = 0;
 };
 
-// Runs the device pipeline over n frames resident in device memory.
+// One sub-batch of frames going through the device pipeline on one lane (stream + workspace).
+// The pipeline has four host-visible waits (hand-off count, mid-queue count, counters, results);
+// the methods are the pieces between them, so that run_device can interleave two lanes: while
+// one lane's latency-bound finishing kernels and host work run, the other lane's scan keeps
+// the machine busy.
 template <typename Real>
-static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
-                       bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
-                       const TraceOut<Real>* trace, RunStats* rs) {
-  constexpr int dialect = Sel<Real>::dialect;
-  const HostModel& hm = c->hm;
-  const DevModelT<Real>& m = Sel<Real>::model(c).m;
-  const int dim = hm.dim(), T = hm.T;
-  const long long wpf = pe->sp.windows;
-  const bool want_trace = trace != nullptr;
-  const bool multi = hm.multi_scale();
-  hipStream_t st = user_stream ? user_stream : c->stream;
-  if (wpf == 0 || n == 0) return true;
+struct Pass {
+  Cascador* c; PlanEntry* pe; const TraceOut<Real>* trace; RawDets<Real>* dets; RunStats* rs;
+  bool apply_th; Real th; bool multi = false;   // multi: hm().multi_scale(), a scan of the model: computed once
+  int lane = 0; hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
+  WorkT<Real> w; size_t cap = 0;
+  int f0 = 0, nf = 0;
+  // state between the steps
+  bool dense = false, finished = false;
+  long long n_tail = -1, n_mid = -1;
+  size_t n_out = 0;
+  std::vector<uint32_t> g; std::vector<Real> sc, sh;
 
-  // frames per pass, bounded by the workspace budget
-  const size_t bpw = bytes_per_window<Real>(dim, want_trace);
-  const long long budget = env_ll("JDA_WORKSPACE_MB", 24 * 1024) << 20;
-  long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
-  fpp = std::min<long long>(fpp, n);
-  fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
-  fpp = std::min<long long>(fpp, 65535);                       // the queues pack the frame index in 16 bits
-  if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
-  const size_t cap = (size_t)fpp * (size_t)wpf;
-  if (!ensure_workspace<Real>(c, cap, want_trace)) return false;
-  Workspace<Real>& ws = Sel<Real>::ws(c);
+  const HostModel& hm() const { return c->hm; }
+  const DevModelT<Real>& model() const { return Sel<Real>::model(c).m; }
+  bool want_trace() const { return trace != nullptr; }
+  long long windows() const { return (long long)nf * pe->sp.windows; }
 
-  int hw = 0, hh = 0, qw = 0, qh = 0;
-  if (multi) {
-    if (dialect == JDA_DIALECT_C) {
-      const float r = 1.f / sqrtf(2.f);                     // c/jda.c:450-456
-      hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
-    } else {
-      hw = (int)(pe->sp.width / std::sqrt(2.)); hh = (int)(pe->sp.height / std::sqrt(2.));   // cascador.cpp:323-324
+  bool dense_ok(int* pix_cap, int* lds_max) const {
+    constexpr int dialect = Sel<Real>::dialect;
+    const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
+    *lds_max = (int)env_ll("JDA_DENSE_LDS_MAX", 160 * 1024);
+    const int dim = hm().dim();
+    const int fixed = (int)stage_lds_bytes(dim, hm().node_n(), hm().leaf_n(), (int)sizeof(Real));
+    *pix_cap = std::max(0, std::min<int>((int)env_ll("JDA_DENSE_PIX", 16 * 1024), *lds_max - fixed));
+    return dense_env != 0 && !multi && !(dialect == JDA_DIALECT_CPP && c->similarity) &&
+           dim <= 160 && hm().leaf_n() <= 256 && fixed <= *lds_max;
+  }
+  bool run_dense() {
+    int pix_cap, lds_max;
+    (void)dense_ok(&pix_cap, &lds_max);
+    for (int t = 0; t < hm().T; t++)
+      for (int l = 0; l < pe->hp.n_levels; l++)
+        JDA_HIP(launch_stage<Real>(want_trace(), l, t, apply_th, th, pe->dp, pe->hp, model(), w, pix_cap, lds_max, st));
+    return true;
+  }
+  bool clear_counters() {
+    JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntShards * kCntStride, st));
+    if (want_trace()) {
+      JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)windows(), st));
+      JDA_HIP(launch_trace_fill<Real>(model(), w, (unsigned)windows(), st));
     }
-    qw = pe->sp.width / 2; qh = pe->sp.height / 2;
-    if (hw < 1 || hh < 1 || qw < 1 || qh < 1) { fail("frame too small for the half/quarter images"); return false; }
-    if (!ws.pyr.reserve(((size_t)hw * hh + (size_t)qw * qh + 512) * (size_t)fpp)) return false;
+    return true;
+  }
+  bool read_counter(int counter) {     // asynchronous: the value is in h_cnt[0] after the next stream sync
+    JDA_HIP(hipMemcpyAsync(h_cnt, w.counters + counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    return true;
   }
 
-  for (int f0 = 0; f0 < n; f0 += (int)fpp) {
-    const int nf = std::min<int>((int)fpp, n - f0);
-    WorkT<Real> w = ws.w;
-    w.frames = d_frames + (size_t)f0 * stride; w.frame_stride = stride; w.n_frames = nf;
-    w.half = nullptr; w.quarter = nullptr; w.half_stride = w.quarter_stride = 0;
-    w.hw = hw; w.hh = hh; w.qw = qw; w.qh = qh;
-    JDA_HIP(hipEventRecord(c->ev[0], st));
-    JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntShards * kCntStride, st));
+  // step 1: pyramids (multi-scale models), stage-0 scan (or everything, in dense mode)
+  bool issue_scan(uint8_t* hbuf, size_t hs, uint8_t* qbuf, size_t qs, hipEvent_t scan_after) {
+    constexpr int dialect = Sel<Real>::dialect;
+    const DevModelT<Real>& m = model();
+    JDA_HIP(hipEventRecord(ev[0], st));
     if (multi) {
-      uint8_t* hbuf = (uint8_t*)ws.pyr.p;
-      const size_t hs = ((size_t)hw * hh + 255) & ~(size_t)255, qs = ((size_t)qw * qh + 255) & ~(size_t)255;
-      uint8_t* qbuf = hbuf + hs * (size_t)fpp;
       const int W = pe->sp.width, H = pe->sp.height;
+      const size_t stride = w.frame_stride;
       if (dialect == JDA_DIALECT_C) {      // jdaImageResize, c/jda.c:203-230
-        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, (float)(W - 1) / hw, (float)(H - 1) / hh, st));
-        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, (float)(W - 1) / qw, (float)(H - 1) / qh, st));
+        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, hbuf, hs, w.hw, w.hh, (float)(W - 1) / w.hw, (float)(H - 1) / w.hh, st));
+        JDA_HIP(launch_resize(w.frames, stride, nf, W, H, qbuf, qs, w.qw, w.qh, (float)(W - 1) / w.qw, (float)(H - 1) / w.qh, st));
       } else {                             // cv::resize, cascador.cpp:330-331
-        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, hbuf, hs, hw, hh, st));
-        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, qbuf, qs, qw, qh, st));
+        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, hbuf, hs, w.hw, w.hh, st));
+        JDA_HIP(launch_resize_cv(w.frames, stride, nf, W, H, qbuf, qs, w.qw, w.qh, st));
       }
       w.half = hbuf; w.half_stride = hs; w.quarter = qbuf; w.quarter_stride = qs;
     }
-    if (want_trace) {
-      JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
-      JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
-    }
+    if (!clear_counters()) return false;
     // ---- dense mode (k_stage): when most windows survive the first carts, whole stages are
     //      walked tile by tile instead of window by window.  Decided from the previous pass on
-    //      this plan (pe->dense_hint) or, below, from the hand-off count of this pass; the
-    //      results do not depend on the choice. ----
-    const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
-    const int dense_lds_max = (int)env_ll("JDA_DENSE_LDS_MAX", 160 * 1024);
-    const int dense_fixed = (int)stage_lds_bytes(dim, hm.node_n(), hm.leaf_n(), (int)sizeof(Real));
-    const bool dense_ok = dense_env != 0 && !multi && !(dialect == JDA_DIALECT_CPP && c->similarity) &&
-                          dim <= 160 && hm.leaf_n() <= 256 && dense_fixed <= dense_lds_max;
-    const int dense_pix_cap = std::max(0, std::min<int>((int)env_ll("JDA_DENSE_PIX", 16 * 1024), dense_lds_max - dense_fixed));
-    const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
-    auto run_dense = [&]() -> bool {
-      for (int t = 0; t < T; t++)
-        for (int l = 0; l < pe->hp.n_levels; l++)
-          JDA_HIP(launch_stage<Real>(want_trace, l, t, apply_th, th, pe->dp, pe->hp, m, w, dense_pix_cap, dense_lds_max, st));
-      return true;
-    };
-    bool dense = dense_ok && (dense_env == 2 || pe->dense_hint);
+    //      this plan (pe->dense_hint) or, in after_tail, from the hand-off count of this pass;
+    //      the results do not depend on the choice. ----
+    int pix_cap, lds_max;
+    const bool ok = dense_ok(&pix_cap, &lds_max);
+    dense = ok && (env_ll("JDA_DENSE", 1) == 2 || pe->dense_hint);
     if (dense) {
-      JDA_HIP(hipEventRecord(c->ev[1], st));
-      JDA_HIP(hipEventRecord(c->ev[2], st));
-      if (!run_dense()) return false;
-    } else {
+      JDA_HIP(hipEventRecord(ev[1], st));
+      JDA_HIP(hipEventRecord(ev[2], st));
+      finished = true;
+      return run_dense();
+    }
     // ---- windows k_scan does not cover enter the hand-off queue at cart 0 ----
     if (!pe->fast_scan || pe->any_untiled) JDA_HIP(launch_enqueue<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
-    // ---- stage-0 scan: first `handoff` carts, one launch per tiled level ----
-    JDA_HIP(hipEventRecord(c->ev[1], st));
+    // ---- stage-0 scan: first `handoff` carts, one launch per LDS-tiled level ----
+    // (optionally staggered behind the previous lane's scan, JDA_LANES_STAGGER=1; measured
+    // SLOWER than letting both scans share the machine: 2.65 ms vs 2.39 ms per 256-frame step,
+    // because half-size scans are less efficient and k_finish is throughput bound itself)
+    if (scan_after) JDA_HIP(hipStreamWaitEvent(st, scan_after, 0));
+    JDA_HIP(hipEventRecord(ev[1], st));
     if (pe->fast_scan) {
       const int handoff = (int)env_ll("JDA_HANDOFF", 128);
       bool any_glb = false;
@@ -569,111 +577,242 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       if (lds_blocks > 0 && lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048)) {
         // small job (a frame or a few): all LDS-tiled levels in one launch -- every workgroup
         // is resident at once anyway, so per-level launches would only serialise their latency
-        JDA_HIP(launch_scan<Real>(-2, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+        JDA_HIP(launch_scan<Real>(-2, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
         rs->scan_launches++;
       } else {
         for (int l = 0; l < pe->hp.n_levels; l++) {
           if (pe->hp.lv[l].tiled != 1) continue;
-          JDA_HIP(launch_scan<Real>(l, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+          JDA_HIP(launch_scan<Real>(l, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
           rs->scan_launches++;
         }
       }
       if (any_glb) {
-        JDA_HIP(launch_scan<Real>(-1, want_trace, handoff, pe->dp, pe->hp, m, pe->table, w, st));
+        JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
         rs->scan_launches++;
       }
     }
-    JDA_HIP(hipEventRecord(c->ev[2], st));
-    // ---- every survivor: remaining carts, regressions, later stages, final cut ----
-    // Two launches so that the few windows that pass stage 0 (and then cost whole stages
-    // each) are spread over the machine again.  The queue lengths are read back first
-    // (two small synchronisations) so that each launch gets one workgroup per window.
-    const bool sized = env_ll("JDA_FINISH_SIZED", 1) != 0;
-    auto queue_len = [&](int counter, long long* n) -> bool {
-      *n = -1;
-      if (!sized) return true;
-      JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters + counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipStreamSynchronize(st));
-      *n = (long long)std::min<unsigned long long>(c->h_counters[0], cap);
-      return true;
-    };
-    long long n_tail = -1, n_mid = -1;
-    if (!queue_len(kCntTail, &n_tail)) return false;
-    if (dense_ok && n_tail >= 0 && (double)n_tail >= dense_frac * (double)nf * (double)wpf && n_tail > 4096) {
+    JDA_HIP(hipEventRecord(ev[2], st));
+    // the hand-off queue length sizes the finishing launches (one workgroup per window)
+    return read_counter(kCntTail);
+  }
+
+  // step 2: every survivor of the scan: remaining carts of stage 0 (+ all stages when few are left)
+  bool after_tail() {
+    if (finished) return true;
+    JDA_HIP(hipStreamSynchronize(st));
+    n_tail = (long long)std::min<unsigned long long>(h_cnt[0], cap);
+    const int T = hm().T;
+    int pix_cap, lds_max;
+    const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
+    if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
       // most windows are still alive after the scan: start over in dense mode (the scan's work
       // is a small part of T*K carts per window) and remember the choice for the next pass
-      dense = true;
+      dense = true; finished = true;
       pe->dense_hint = true;
-      JDA_HIP(hipMemsetAsync(w.counters, 0, sizeof(unsigned long long) * kCntShards * kCntStride, st));
-      if (want_trace) {
-        JDA_HIP(hipMemsetAsync(w.tr_carts, 0, sizeof(int) * (size_t)nf * wpf, st));
-        JDA_HIP(launch_trace_fill<Real>(m, w, (unsigned)((size_t)nf * wpf), st));
-      }
-      if (!run_dense()) return false;
-    } else if (T > 1 && n_tail >= 0 && n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
+      if (!clear_counters()) return false;
+      return run_dense();
+    }
+    if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
-      JDA_HIP(launch_finish<Real>(want_trace, 0, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_GM", 4), n_tail, st));
-    } else {
-      JDA_HIP(launch_finish<Real>(want_trace, 0, 1, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
-      if (T > 1) {
-        if (!queue_len(kCntMid, &n_mid)) return false;
-        JDA_HIP(launch_finish<Real>(want_trace, 1, T, apply_th, th, pe->dp, m, w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
-      }
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", 4), n_tail, st));
+      finished = true;
+      return true;
     }
-    }   // !dense
-    JDA_HIP(hipEventRecord(c->ev[3], st));
-    JDA_HIP(hipMemcpyAsync(c->h_counters, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
+    // Two launches so that the few windows that pass stage 0 (and then cost whole stages
+    // each) are spread over the machine again.
+    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
+    return read_counter(kCntMid);
+  }
+
+  // step 3: stages 1..T-1 of the windows that passed stage 0
+  bool after_mid() {
+    if (finished) return true;
     JDA_HIP(hipStreamSynchronize(st));
-    for (int sh = 1; sh < kCntShards; sh++)     // fold the counter shards into shard 0
-      for (int i = 0; i < kCntTotal; i++) c->h_counters[i] += c->h_counters[sh * kCntStride + i];
-    float ms_all = 0, ms_scan = 0;
-    (void)hipEventElapsedTime(&ms_all, c->ev[0], c->ev[3]);
-    (void)hipEventElapsedTime(&ms_scan, c->ev[1], c->ev[2]);
-    rs->gpu_ms += ms_all; rs->scan_ms += ms_scan;
-    rs->carts += (long long)c->h_counters[kCntCarts];
-    rs->carts_scan += (long long)c->h_counters[kCntCartsScan];
-    rs->win_scan += (long long)c->h_counters[kCntWinScan];
-    for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)c->h_counters[kCntStage0 + t];
-    rs->tail += (long long)c->h_counters[kCntTail];
+    n_mid = (long long)std::min<unsigned long long>(h_cnt[0], cap);
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
+    finished = true;
+    return true;
+  }
+
+  // step 4: counters -> host (asynchronous)
+  bool issue_counters() {
+    JDA_HIP(hipEventRecord(ev[3], st));
+    JDA_HIP(hipMemcpyAsync(h_cnt, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
+    return true;
+  }
+
+  // step 5: statistics, detections -> host (asynchronous)
+  bool after_counters() {
+    const int T = hm().T, dim = hm().dim();
+    JDA_HIP(hipStreamSynchronize(st));
+    for (int shd = 1; shd < kCntShards; shd++)     // fold the counter shards into shard 0
+      for (int i = 0; i < kCntTotal; i++) h_cnt[i] += h_cnt[shd * kCntStride + i];
+    rs->carts += (long long)h_cnt[kCntCarts];
+    rs->carts_scan += (long long)h_cnt[kCntCartsScan];
+    rs->win_scan += (long long)h_cnt[kCntWinScan];
+    for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)h_cnt[kCntStage0 + t];
+    rs->tail += (long long)h_cnt[kCntTail];
     if (dense) {
       rs->dense_passes++;
       // fall back to the sparse pipeline when stage 0 rejects most windows after all
-      if ((double)c->h_counters[kCntStage0] < 0.5 * dense_frac * (double)nf * (double)wpf) pe->dense_hint = false;
+      const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
+      if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * (double)windows()) pe->dense_hint = false;
     }
-    const size_t n_out = (size_t)c->h_counters[kCntOut];
+    n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;
     if (n_out > cap) { fail("internal: more detections than windows"); return false; }
-    // ---- detections of this pass -> host, sorted back into scan order ----
     if (n_out && dets) {
-      std::vector<uint32_t> g(n_out);
-      std::vector<Real> s(n_out), sh(n_out * dim);
+      g.resize(n_out); sc.resize(n_out); sh.resize(n_out * dim);
       JDA_HIP(hipMemcpyAsync(g.data(), w.out_gid, n_out * 4, hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipMemcpyAsync(s.data(), w.out_score, n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
+      JDA_HIP(hipMemcpyAsync(sc.data(), w.out_score, n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
       JDA_HIP(hipMemcpyAsync(sh.data(), w.out_shape, n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
+    }
+    return true;
+  }
+
+  // step 6: detections of this pass sorted back into scan order and appended; trace arrays
+  bool collect() {
+    const int dim = hm().dim();
+    const long long wpf = pe->sp.windows;
+    if (n_out && dets) {
       JDA_HIP(hipStreamSynchronize(st));
       // back into scan order: sort (gid, arrival index) packed in one word -- gids are unique
       std::vector<unsigned long long> key(n_out);
       for (size_t i = 0; i < n_out; i++) key[i] = ((unsigned long long)g[i] << 32) | (unsigned long long)i;
       std::sort(key.begin(), key.end());
-      std::vector<uint32_t> ord(n_out);
-      for (size_t i = 0; i < n_out; i++) ord[i] = (uint32_t)(key[i] & 0xffffffffu);
       const size_t o0 = dets->gid.size();
       dets->gid.resize(o0 + n_out); dets->score.resize(o0 + n_out); dets->shape.resize((o0 + n_out) * dim);
       const uint32_t gid_off = (uint32_t)((size_t)f0 * wpf);
       for (size_t i = 0; i < n_out; i++) {
-        const uint32_t j = ord[i];
+        const uint32_t j = (uint32_t)(key[i] & 0xffffffffu);
         dets->gid[o0 + i] = g[j] + gid_off;
-        dets->score[o0 + i] = s[j];
+        dets->score[o0 + i] = sc[j];
         std::memcpy(&dets->shape[(o0 + i) * dim], &sh[(size_t)j * dim], dim * sizeof(Real));
       }
     }
-    if (want_trace) {
-      const size_t nw = (size_t)nf * wpf, o = (size_t)f0 * wpf;
+    if (want_trace()) {
+      JDA_HIP(hipStreamSynchronize(st));
+      const size_t nw = (size_t)windows(), o = (size_t)f0 * wpf;
       if (trace->carts_n) JDA_HIP(hipMemcpy(trace->carts_n + o, w.tr_carts, nw * 4, hipMemcpyDeviceToHost));
       if (trace->score) JDA_HIP(hipMemcpy(trace->score + o, w.tr_score, nw * sizeof(Real), hipMemcpyDeviceToHost));
       if (trace->path_hash) JDA_HIP(hipMemcpy(trace->path_hash + o, w.tr_hash, nw * 4, hipMemcpyDeviceToHost));
       if (trace->shapes) JDA_HIP(hipMemcpy(trace->shapes + o * dim, w.tr_shape, nw * dim * sizeof(Real), hipMemcpyDeviceToHost));
+    }
+    return true;
+  }
+};
+
+// Runs the device pipeline over n frames resident in device memory.  Large batches are split
+// into sub-batches that alternate between two lanes (streams with their own workspace), see Pass.
+template <typename Real>
+static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+                       bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
+                       const TraceOut<Real>* trace, RunStats* rs) {
+  constexpr int dialect = Sel<Real>::dialect;
+  const HostModel& hm = c->hm;
+  const int dim = hm.dim();
+  const long long wpf = pe->sp.windows;
+  const bool want_trace = trace != nullptr;
+  const bool multi = hm.multi_scale();
+  if (wpf == 0 || n == 0) return true;
+
+  // two lanes when the batch is big enough for each half to fill the machine
+  const long long lanes_min = env_ll("JDA_LANES_MIN_WINDOWS", 2000000);
+  int lanes = (int)env_ll("JDA_LANES", 2);
+  if (lanes < 1) lanes = 1;
+  if (lanes > kLanes) lanes = kLanes;
+  if (n < 2 || (long long)n * wpf < lanes_min * 2) lanes = 1;
+
+  // frames per sub-batch, bounded by the workspace budget (shared by the lanes)
+  const size_t bpw = bytes_per_window<Real>(dim, want_trace);
+  const long long budget = (env_ll("JDA_WORKSPACE_MB", 24 * 1024) << 20) / lanes;
+  long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
+  fpp = std::min<long long>(fpp, (n + lanes - 1) / lanes);
+  fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
+  fpp = std::min<long long>(fpp, 65535);                       // the queues pack the frame index in 16 bits
+  if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
+  const size_t cap = (size_t)fpp * (size_t)wpf;
+  if (!ensure_workspace<Real>(c, cap, want_trace, lanes)) return false;
+  Workspace<Real>& ws = Sel<Real>::ws(c);
+
+  int hw = 0, hh = 0, qw = 0, qh = 0;
+  size_t hs = 0, qs = 0;
+  if (multi) {
+    if (dialect == JDA_DIALECT_C) {
+      const float r = 1.f / sqrtf(2.f);                     // c/jda.c:450-456
+      hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
+    } else {
+      hw = (int)(pe->sp.width / std::sqrt(2.)); hh = (int)(pe->sp.height / std::sqrt(2.));   // cascador.cpp:323-324
+    }
+    qw = pe->sp.width / 2; qh = pe->sp.height / 2;
+    if (hw < 1 || hh < 1 || qw < 1 || qh < 1) { fail("frame too small for the half/quarter images"); return false; }
+    hs = ((size_t)hw * hh + 255) & ~(size_t)255; qs = ((size_t)qw * qh + 255) & ~(size_t)255;
+    if (!ws.pyr.reserve((hs + qs) * (size_t)fpp * (size_t)lanes + 512)) return false;
+  }
+
+  // lane 0 runs on the caller's stream when one was given; the other lane is ordered after the
+  // work already queued there
+  hipStream_t lane_stream[kLanes];
+  for (int l = 0; l < lanes; l++) lane_stream[l] = c->stream[l];
+  if (user_stream) {
+    lane_stream[0] = user_stream;
+    if (lanes > 1) {
+      JDA_HIP(hipEventRecord(c->ev_user, user_stream));
+      for (int l = 1; l < lanes; l++) JDA_HIP(hipStreamWaitEvent(lane_stream[l], c->ev_user, 0));
+    }
+  }
+
+  std::vector<Pass<Real>> ps;
+  for (int f0 = 0; f0 < n;) {
+    // one round: up to `lanes` sub-batches in flight, their steps interleaved
+    ps.clear();
+    for (int l = 0; l < lanes && f0 < n; l++) {
+      Pass<Real> p;
+      p.c = c; p.pe = pe; p.trace = trace; p.dets = dets; p.rs = rs; p.apply_th = apply_th; p.th = th; p.multi = multi;
+      p.lane = l; p.st = lane_stream[l]; p.ev = c->ev[l];
+      p.h_cnt = c->h_counters + (size_t)l * kCntShards * kCntStride;
+      p.w = ws.w[l]; p.cap = cap;
+      p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);
+      p.w.frames = d_frames + (size_t)f0 * stride; p.w.frame_stride = stride; p.w.n_frames = p.nf;
+      p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
+      p.w.hw = hw; p.w.hh = hh; p.w.qw = qw; p.w.qh = qh;
+      f0 += p.nf;
+      ps.push_back(std::move(p));
+    }
+    for (auto& p : ps) {
+      uint8_t* hbuf = multi ? (uint8_t*)ws.pyr.p + (hs + qs) * (size_t)fpp * (size_t)p.lane : nullptr;
+      hipEvent_t scan_after = (p.lane > 0 && env_ll("JDA_LANES_STAGGER", 0)) ? c->ev[p.lane - 1][2] : nullptr;
+      if (!p.issue_scan(hbuf, hs, hbuf ? hbuf + hs * (size_t)fpp : nullptr, qs, scan_after)) return false;
+    }
+    for (auto& p : ps) if (!p.after_tail()) return false;
+    for (auto& p : ps) if (!p.after_mid()) return false;
+    for (auto& p : ps) if (!p.issue_counters()) return false;
+    // per lane in frame order (dets stay sorted by gid): the first lane's host work overlaps
+    // the other lane's last kernels
+    for (auto& p : ps) if (!p.after_counters() || !p.collect()) return false;
+    // scan time of the round: the lanes' scans run side by side, so their union (first scan
+    // start to last scan end) is what one step spends scanning, not the sum of the spans
+    float ms_scan = 0;
+    for (auto& p : ps) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ps[0].ev[1], p.ev[2]) == hipSuccess) ms_scan = std::max(ms_scan, ms);
+    }
+    rs->scan_ms += ms_scan;
+    // device time of the round: first lane's start to the last lane's end
+    float ms_all = 0;
+    for (auto& p : ps) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ps[0].ev[0], p.ev[3]) == hipSuccess) ms_all = std::max(ms_all, ms);
+    }
+    rs->gpu_ms += ms_all;
+    if (env_ll("JDA_DEBUG_TIMES", 0)) {
+      for (auto& p : ps) {
+        float a = 0, b = 0, d = 0;
+        (void)hipEventElapsedTime(&a, p.ev[0], p.ev[1]); (void)hipEventElapsedTime(&b, p.ev[1], p.ev[2]);
+        (void)hipEventElapsedTime(&d, p.ev[2], p.ev[3]);
+        fprintf(stderr, "[jda] lane %d frames %d: pre %.3f scan %.3f finish %.3f ms (n_tail %lld n_mid %lld)\n", p.lane, p.nf, a, b, d, p.n_tail, p.n_mid);
+      }
     }
   }
   return true;
@@ -805,8 +944,8 @@ static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n,
   *stride = (fbytes + 255) & ~(size_t)255;
   if (!ws.frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
   for (int i = 0; i < n; i++)
-    JDA_HIP(hipMemcpyAsync((uint8_t*)ws.frames.p + (size_t)i * *stride, frames[i], fbytes, hipMemcpyHostToDevice, c->stream));
-  JDA_HIP(hipStreamSynchronize(c->stream));
+    JDA_HIP(hipMemcpyAsync((uint8_t*)ws.frames.p + (size_t)i * *stride, frames[i], fbytes, hipMemcpyHostToDevice, c->stream[0]));
+  JDA_HIP(hipStreamSynchronize(c->stream[0]));
   return true;
 }
 
@@ -849,14 +988,15 @@ void jdaCascadorRelease(void* cascador) {
   if (!c) return;
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (auto& st : c->stream) (void)hipStreamSynchronize(st);
     for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
     c->mf.buf.release(); c->md.buf.release();
     c->wf.buf.release(); c->wf.frames.release(); c->wf.pyr.release();
     c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
-    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_user) (void)hipEventDestroy(c->ev_user);
+    for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
   }
   delete c;
 }
@@ -991,9 +1131,9 @@ int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int he
     if (!dst || dw < 1 || dh < 1) return true;
     if (!c->wf.pyr.reserve((size_t)dw * dh + 256)) return false;
     JDA_HIP(launch_resize((const uint8_t*)c->wf.frames.p, stride, 1, width, height, (uint8_t*)c->wf.pyr.p,
-                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, c->stream));
-    JDA_HIP(hipMemcpyAsync(dst, c->wf.pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, c->stream));
-    JDA_HIP(hipStreamSynchronize(c->stream));
+                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, c->stream[0]));
+    JDA_HIP(hipMemcpyAsync(dst, c->wf.pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, c->stream[0]));
+    JDA_HIP(hipStreamSynchronize(c->stream[0]));
     return true;
   };
   if (!one(half, w1, h1) || !one(quarter, w2, h2)) return -1;
@@ -1034,9 +1174,9 @@ int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height
   auto run = [&]() -> bool {
     if (!c->wd.pyr.reserve((size_t)ow * oh + 256)) return false;
     JDA_HIP(launch_resize_cv((const uint8_t*)c->wd.frames.p, stride, 1, width, height, (uint8_t*)c->wd.pyr.p,
-                             (size_t)ow * oh, ow, oh, c->stream));
-    JDA_HIP(hipMemcpyAsync(out, c->wd.pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream));
-    JDA_HIP(hipStreamSynchronize(c->stream));
+                             (size_t)ow * oh, ow, oh, c->stream[0]));
+    JDA_HIP(hipMemcpyAsync(out, c->wd.pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream[0]));
+    JDA_HIP(hipStreamSynchronize(c->stream[0]));
     return true;
   };
   return run() ? 0 : -1;
@@ -1101,8 +1241,8 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
       const int nw = (int)(w / factor), nh = (int)(h / factor);   // cascador.cpp:300-301
       if (nw < 1 || nh < 1) break;
       uint8_t* nxt = (uint8_t*)levels.p + (size_t)(li & 1) * lvl_stride * (size_t)n;
-      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, c->stream));   // cascador.cpp:302
-      JDA_HIP(hipStreamSynchronize(c->stream));
+      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, c->stream[0]));   // cascador.cpp:302
+      JDA_HIP(hipStreamSynchronize(c->stream[0]));
       cur = nxt; cur_stride = lvl_stride; w = nw; h = nh; li++;
     }
     return true;

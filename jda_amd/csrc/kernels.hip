@@ -588,6 +588,19 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
 
         int k = c0;
+        if (GLB) {
+          // pixels come through L1/L2 here: each tree level is a global-load round trip, so
+          // twice as many independent trees are kept in flight
+          for (; k + 8 <= c1; k += 8) {
+            if (__ballot(alive) == 0ull) break;
+            if (alive) {
+              int lf[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) lf[u] = scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+              apply(std::integral_constant<int, 8>{}, k, lf, alive, score, hash, gid);
+            }
+          }
+        }
         for (; k + 4 <= c1; k += 4) {
           if (__ballot(alive) == 0ull) break;
           if (alive) {

@@ -8,9 +8,13 @@
 namespace jda {
 
 bool HostModel::multi_scale() const {
-  for (const SplitNode& n : nodes)
-    if (n.scale != 0) return true;
-  return false;
+  if (multi_cache < 0) {              // asked on every detect call: scan the nodes once
+    int any = 0;
+    for (const SplitNode& n : nodes)
+      if (n.scale != 0) { any = 1; break; }
+    multi_cache = any;
+  }
+  return multi_cache != 0;
 }
 
 long long model_stream_bytes(int T, int K, int L, int D, int rb) {

@@ -40,7 +40,8 @@ struct HostModel {
   std::vector<double> cart_th, cart_mean, cart_std;  // [T*K]
   std::vector<double> w;             // [T][K*LEAF][2L]
 
-  bool multi_scale() const;
+  bool multi_scale() const;          // any split node reads the half/quarter image (cached after the first call)
+  mutable int multi_cache = -1;
 };
 
 // Bytes of a well-formed stream with these dimensions.

@@ -573,3 +573,42 @@ def test_dense_mode_dialect_cpp(built, gpu, model_file, monkeypatch):
         for k in ("carts_n", "score", "path_hash", "shapes"):
             assert same(r[k], g[k][off:off + n]), (i, k)
         off += n
+
+
+# ---------------------------------------------------------------- two lanes
+
+@pytest.mark.parametrize("passes", [False, True])
+def test_two_lanes_give_the_same_results_as_one(built, gpu, model_file, monkeypatch, passes):
+    """Big batches are split into sub-batches that run on two streams with their own workspace
+    (run_device); forced here on a small batch, also with more sub-batches than lanes."""
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=71, cart_th=-0.9, norm_every=9)
+    frames = synth.make_frames(7, 240, 180, seed=72)
+    monkeypatch.setenv("JDA_LANES", "1")
+    c1 = api.Cascador(p)
+    want, s1 = c1.detect_batch(frames, stats=True)
+    tr1 = c1.trace(frames)
+    monkeypatch.setenv("JDA_LANES", "2")
+    monkeypatch.setenv("JDA_LANES_MIN_WINDOWS", "1")
+    if passes:
+        monkeypatch.setenv("JDA_WORKSPACE_MB", "1")        # ~1 frame per sub-batch: several rounds
+    c2 = api.Cascador(p)
+    got, s2 = c2.detect_batch(frames, stats=True)
+    for a, b in zip(got, want):
+        _compare_detect(a, b)
+    for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n", "handoff_n"):
+        assert s1[k] == s2[k], k
+    assert list(s1["stage_done_n"]) == list(s2["stage_done_n"])
+    tr2 = c2.trace(frames)
+    for k in tr1:
+        assert same(tr1[k], tr2[k]), k
+    # a caller-provided stream carries lane 0; the other lane is ordered behind it
+    import torch
+    st = torch.cuda.Stream()
+    d = torch.from_numpy(frames).cuda()
+    with torch.cuda.stream(st):
+        d2 = d.clone()
+        res = c2.detect_batch_device(d2, 1.25, 40, -1, -0.5, hip_stream=st.cuda_stream)
+    ref = c1.detect_batch(frames, 1.25, 40, -1, -0.5)
+    for a, b in zip(res, ref):
+        _compare_detect(a, b)
