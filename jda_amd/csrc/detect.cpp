@@ -1333,8 +1333,8 @@ long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int 
 // timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
 __attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {
   Cascador* c = (Cascador*)cascador;
-  if (!c || !c->wf.w.dbg) return -1;
-  return hipMemcpy(out, c->wf.w.dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  if (!c || !c->wf.w[0].dbg) return -1;
+  return hipMemcpy(out, c->wf.w[0].dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 

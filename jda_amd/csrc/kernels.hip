@@ -286,7 +286,7 @@ struct ScanLds {
     q_score = o; o += 2 * m_max * (int)sizeof(Real);
     q_widx = o; o += 2 * m_max * 2; o = (o + 15) & ~15;
     q_hash = o; if (TRACE) o += 2 * m_max * 4;
-    lfbuf = o; o += 32 * 64;            // leaf indices of 32 carts x 64 windows (cart-parallel phases)
+    lfbuf = o; o += 32 * 64;            // leaf indices of 32 carts x 64 windows or 16 x 128 (cart-parallel phases)
     misc = o; o += 64;
     total = o;
   }
@@ -446,7 +446,7 @@ __device__ __forceinline__ void dma_to_lds(unsigned char* lds_dst, const void* _
 template <typename Real, int DEPTH, bool TRACE, bool GLB>
 __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                               const S0Node* __restrict__ table, WorkT<Real> w,
-                                              int level, int tiles_total, int pix_bytes, int handoff) {
+                                              int level, int tiles_total, int pix_bytes, int handoff, int cp_max) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BLOCK = 256;
   constexpr int M_MAX = 512;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
       }
     };
 
-    const bool cart_parallel = n_items <= 64 && c1 - c0 >= 16 && leaf_n <= 256;
+    const bool cart_parallel = n_items <= cp_max && c1 - c0 >= 16 && leaf_n <= 256;
     if (!cart_parallel) {
       // ---- lane = window, every wave walks the whole chunk for its own windows ----
       for (int i0 = 0; i0 < n_items; i0 += BLOCK) {
@@ -632,42 +632,95 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         }
       }
     } else {
-      // ---- at most one wave of windows left: the four waves split the CARTS of the
-      //      chunk (trees only, 8 carts per wave and round), then wave 0 replays the
-      //      scores of the round in cart order from the leaf indices in LDS ----
-      bool alive = lane < n_items;
+      // ---- at most two waves of windows left: the waves split the CARTS of the chunk
+      //      (trees only, 8 carts per wave and round: one batch, 3 dependent round trips).
+      //      Up to 64 windows: one item group, 4 waves x 8 = 32 carts per round; up to 128: two
+      //      groups of 64 windows with 2 waves x 8 = 16 carts per round each.  Then the first
+      //      wave of each group replays the scores of the round in cart order from the leaf
+      //      indices in LDS.  These phases are latency bound (few windows, long cart ranges).
+      const int groups = n_items <= 64 ? 1 : 2;
+      const int wpg = 4 / groups;                       // waves per item group
+      const int grp = wv / wpg, wig = wv - grp * wpg;   // this wave's group, and its index inside
+      const int rc = 8 * wpg;                           // carts per round
+      const int istride = 64 * groups;                  // lfbuf[cart in round][item]: 32x64 or 16x128
+      const int item = grp * 64 + lane;
+      bool alive = item < n_items;
+      const bool has_item = alive;
       int widx = 0;
       Real score = 0;
       unsigned hash = kFnvSeed;
       if (alive) {
-        widx = q_widx[cur * M_MAX + lane];
-        score = q_score[cur * M_MAX + lane];
-        if (TRACE) hash = q_hash[cur * M_MAX + lane];
+        widx = q_widx[cur * M_MAX + item];
+        score = q_score[cur * M_MAX + item];
+        if (TRACE) hash = q_hash[cur * M_MAX + item];
       }
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const int base = (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
       const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
-      for (int r0 = c0; r0 < c1; r0 += 32) {
-        const int r1 = min(c1, r0 + 32);
-        const int ka = r0 + wv * 8, kb = min(r1, ka + 8);
-        if (lane < n_items) {
-          for (int k = ka; k < kb; k += 4) {
+      for (int r0 = c0; r0 < c1; r0 += rc) {
+        const int r1 = min(c1, r0 + rc);
+        const int ka = r0 + wig * 8, kb = min(r1, ka + 8);
+        if (has_item) {
+          if (kb - ka == 8) {
+            int lf8[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-              if (k + u < kb)
-                lfbuf[(k + u - r0) * 64 + lane] =
-                    (uint8_t)(scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n);
+            for (int u = 0; u < 8; u++) lf8[u] = scan_tree<DEPTH, GLB>(t_nodes + (ka + u) * node_n, pix, base, m.D) - node_n;
+#pragma unroll
+            for (int u = 0; u < 8; u++) lfbuf[(ka + u - r0) * istride + item] = (uint8_t)lf8[u];
+          } else {
+            for (int k = ka; k < kb; k += 4) {
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if (k + u < kb)
+                  lfbuf[(k + u - r0) * istride + item] =
+                      (uint8_t)(scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n);
+            }
           }
         }
         __syncthreads();
         JDA_STAMP(-100 - (r0 - c0));          // timing build: trees of this round done
-        if (wv == 0) {
-          for (int k = r0; k < r1; k += 4) {
+        if (wig == 0) {
+          int k = r0;
+          // 16 carts at a time when none of them is normalised: all leaf scores and thresholds
+          // are fetched first (two LDS round trips for the batch instead of two per 4 carts),
+          // then the recurrence runs in registers, strictly in cart order (c/jda.c:395-399)
+          for (; k + 16 <= r1; k += 16) {
+            if (__ballot(alive) == 0ull) break;
+            const Real nrm = t_par[k + (lane & 15)].norm;
+            if (__ballot(nrm != (Real)0) != 0ull) break;          // rare: the generic loop below takes over
+            if (alive) {
+              int lf[16];
+              Real lsv[16], thv[16];
+#pragma unroll
+              for (int u = 0; u < 16; u++) lf[u] = (int)lfbuf[(k + u - r0) * istride + item];
+#pragma unroll
+              for (int u = 0; u < 16; u++) { lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; thv[u] = t_par[k + u].th; }
+              Real sc = score;
+              bool dead = false;
+              int kd = k;
+#pragma unroll
+              for (int u = 0; u < 16; u++) {
+                if (!dead) {
+                  sc = sc + lsv[u];                                        // c/jda.c:396 (no normalisation here)
+                  if (TRACE) hash = fnv_step(hash, lf[u]);
+                  kd = k + u;
+                  dead = sc < thv[u];                                      // c/jda.c:399
+                }
+              }
+              score = sc;
+              if (dead) {
+                alive = false;
+                my_carts += kd + 1;
+                if (TRACE) { w.tr_carts[gid] = kd + 1; w.tr_score[gid] = sc; w.tr_hash[gid] = hash; }
+              }
+            }
+          }
+          for (; k < r1; k += 4) {
             if (__ballot(alive) == 0ull) break;
             if (alive) {
               int lf[4];
 #pragma unroll
-              for (int u = 0; u < 4; u++) lf[u] = (k + u < r1) ? (int)lfbuf[(k + u - r0) * 64 + lane] : 0;
+              for (int u = 0; u < 4; u++) lf[u] = (k + u < r1) ? (int)lfbuf[(k + u - r0) * istride + item] : 0;
               if (k + 4 <= r1) {
                 apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
               } else {
@@ -679,13 +732,14 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         }
         __syncthreads();
       }
-      if (wv == 0) {
+      if (wig == 0) {
         const unsigned long long mask = __ballot(alive);
         if (mask) {
-          const int cnt = __popcll(mask);
-          if (lane == 0) misc[cur ^ 1] = cnt;
+          int wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&misc[cur ^ 1], __popcll(mask));
+          wbase = __shfl(wbase, 0);
           if (alive) {
-            const int pos = __popcll(mask & lanes_below(lane));
+            const int pos = wbase + __popcll(mask & lanes_below(lane));
             q_widx[(cur ^ 1) * M_MAX + pos] = (uint16_t)widx;
             q_score[(cur ^ 1) * M_MAX + pos] = score;
             if (TRACE) q_hash[(cur ^ 1) * M_MAX + pos] = hash;
@@ -775,13 +829,17 @@ static hipError_t launch_scan_depth(const DevPlan* d_plan, const DevPlan& h_plan
   handoff = std::min(handoff, scan_handoff_cap(m.node_n, m.leaf_n, (int)sizeof(Real)));
   const int carts = std::min(m.K, handoff);
   const ScanLds<Real, TRACE> L(pix_bytes, carts, m.node_n, m.leaf_n, 512);
+  // windows left in a tile at or below which a phase splits the carts over the waves (64: one item
+  // group, 128: two); experiments: JDA_CP_MAX / JDA_CP_MAX_GLB
+  int cp_max = glb ? 128 : 128;
+  if (const char* e = getenv(glb ? "JDA_CP_MAX_GLB" : "JDA_CP_MAX")) cp_max = std::max(0, std::min(128, atoi(e)));
   const int groups = (w.n_frames + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * tiles)), block(256);
   auto go = [&](auto kern) {
     if (L.total > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
-                       pix_bytes, handoff);
+                       pix_bytes, handoff, cp_max);
   };
   if (glb) {
     if (m.D == 4) go(k_scan<Real, 4, TRACE, true>);
