@@ -103,6 +103,17 @@ struct DialectCPP {         // reference src/jda (Validate / CalcFeatureValue)
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
 
+// value of lane j (wave-uniform j), for any lane mask
+__device__ __forceinline__ int rl(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float rl(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ double rl(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
   return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
@@ -286,7 +297,7 @@ struct ScanLds {
     q_score = o; o += 2 * m_max * (int)sizeof(Real);
     q_widx = o; o += 2 * m_max * 2; o = (o + 15) & ~15;
     q_hash = o; if (TRACE) o += 2 * m_max * 4;
-    lfbuf = o; o += 32 * 64;            // leaf indices of 32 carts x 64 windows or 16 x 128 (cart-parallel phases)
+    lfbuf = o; o += 2048;               // leaf indices [window][cart of the round], n_pad x (2048 / n_pad) (late phases)
     misc = o; o += 64;
     total = o;
   }
@@ -632,86 +643,105 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         }
       }
     } else {
-      // ---- at most two waves of windows left: the waves split the CARTS of the chunk
-      //      (trees only, 8 carts per wave and round: one batch, 3 dependent round trips).
-      //      Up to 64 windows: one item group, 4 waves x 8 = 32 carts per round; up to 128: two
-      //      groups of 64 windows with 2 waves x 8 = 16 carts per round each.  Then the first
-      //      wave of each group replays the scores of the round in cart order from the leaf
-      //      indices in LDS.  These phases are latency bound (few windows, long cart ranges).
-      const int groups = n_items <= 64 ? 1 : 2;
-      const int wpg = 4 / groups;                       // waves per item group
-      const int grp = wv / wpg, wig = wv - grp * wpg;   // this wave's group, and its index inside
-      const int rc = 8 * wpg;                           // carts per round
-      const int istride = 64 * groups;                  // lfbuf[cart in round][item]: 32x64 or 16x128
-      const int item = grp * 64 + lane;
-      bool alive = item < n_items;
-      const bool has_item = alive;
+      // ---- at most two waves of windows left: (window, cart) PAIRS are spread over the 256
+      //      lanes (trees only), then the scores of the round are replayed in cart order, lane =
+      //      window, from the leaf indices in LDS.  These phases are latency and issue bound (few
+      //      windows, long cart ranges), so a lane should walk as few trees as possible:
+      //      n_pad = windows rounded up to 16/32/64/128; lane -> window tid % n_pad, carts
+      //      tid / n_pad + j * (256 / n_pad); a round covers as many carts as lfbuf holds
+      //      (2048 / n_pad: 128, 64, 32, 16), i.e. at most 8 trees per lane, walked as one batch.
+      const int lg = n_items <= 16 ? 4 : (n_items <= 32 ? 5 : (n_items <= 64 ? 6 : 7));
+      const int n_pad = 1 << lg;
+      const int rc = 2048 >> lg;                        // carts per round
+      const int cstride = 256 >> lg;                    // cart stride of a lane
+      const int item = tid & (n_pad - 1);
+      const bool has_item = item < n_items;
+      const bool replayer = tid < n_pad;                // lanes [0, n_pad) also own the windows' scores
+      const int replay_waves = n_pad <= 64 ? 1 : 2;
+      bool alive = replayer && has_item;
       int widx = 0;
       Real score = 0;
       unsigned hash = kFnvSeed;
-      if (alive) {
+      if (has_item) {
         widx = q_widx[cur * M_MAX + item];
-        score = q_score[cur * M_MAX + item];
-        if (TRACE) hash = q_hash[cur * M_MAX + item];
+        if (replayer) { score = q_score[cur * M_MAX + item]; if (TRACE) hash = q_hash[cur * M_MAX + item]; }
       }
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const int base = (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
       const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
       for (int r0 = c0; r0 < c1; r0 += rc) {
         const int r1 = min(c1, r0 + rc);
-        const int ka = r0 + wig * 8, kb = min(r1, ka + 8);
+        const int ka = r0 + (tid >> lg);
         if (has_item) {
-          if (kb - ka == 8) {
+          if (ka + 7 * cstride < r1) {
             int lf8[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) lf8[u] = scan_tree<DEPTH, GLB>(t_nodes + (ka + u) * node_n, pix, base, m.D) - node_n;
+            for (int u = 0; u < 8; u++)
+              lf8[u] = scan_tree<DEPTH, GLB>(t_nodes + (ka + u * cstride) * node_n, pix, base, m.D) - node_n;
 #pragma unroll
-            for (int u = 0; u < 8; u++) lfbuf[(ka + u - r0) * istride + item] = (uint8_t)lf8[u];
+            for (int u = 0; u < 8; u++) lfbuf[item * rc + (ka + u * cstride - r0)] = (uint8_t)lf8[u];
           } else {
-            for (int k = ka; k < kb; k += 4) {
+            for (int k = ka; k < r1; k += 4 * cstride) {
+              int lf4[4];
 #pragma unroll
               for (int u = 0; u < 4; u++)
-                if (k + u < kb)
-                  lfbuf[(k + u - r0) * istride + item] =
-                      (uint8_t)(scan_tree<DEPTH, GLB>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n);
+                lf4[u] = scan_tree<DEPTH, GLB>(t_nodes + min(k + u * cstride, r1 - 1) * node_n, pix, base, m.D) - node_n;
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if (k + u * cstride < r1) lfbuf[item * rc + (k + u * cstride - r0)] = (uint8_t)lf4[u];
             }
           }
         }
         __syncthreads();
         JDA_STAMP(-100 - (r0 - c0));          // timing build: trees of this round done
-        if (wig == 0) {
+        if (wv < replay_waves) {
           int k = r0;
           // 16 carts at a time when none of them is normalised: all leaf scores and thresholds
           // are fetched first (two LDS round trips for the batch instead of two per 4 carts),
           // then the recurrence runs in registers, strictly in cart order (c/jda.c:395-399)
           for (; k + 16 <= r1; k += 16) {
             if (__ballot(alive) == 0ull) break;
-            const Real nrm = t_par[k + (lane & 15)].norm;
-            if (__ballot(nrm != (Real)0) != 0ull) break;          // rare: the generic loop below takes over
+            const CartPar<Real> pm = t_par[k + (lane & 15)];       // lane u (mod 16): cart k+u
+            if (__ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
+            const Real th_mine = pm.th;                            // broadcast from lane u below (no LDS read per cart)
             if (alive) {
               int lf[16];
               Real lsv[16], thv[16];
+              // the window's 16 leaf indices are 16 consecutive bytes of lfbuf[window][cart]
+              const uint4 pk = *(const uint4*)(lfbuf + item * rc + (k - r0));
+              const unsigned pw4[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-              for (int u = 0; u < 16; u++) lf[u] = (int)lfbuf[(k + u - r0) * istride + item];
+              for (int u = 0; u < 16; u++) lf[u] = (int)((pw4[u >> 2] >> (8 * (u & 3))) & 0xffu);
 #pragma unroll
-              for (int u = 0; u < 16; u++) { lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; thv[u] = t_par[k + u].th; }
+              for (int u = 0; u < 16; u++) { lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; thv[u] = rl(th_mine, u); }
+              // branch-free: the 16 partial sums (the same adds in the same order), a bit per
+              // rejecting cart, then the first set bit names the cart the window died at
+              Real sums[16];
               Real sc = score;
-              bool dead = false;
-              int kd = k;
+              unsigned rej = 0u;
 #pragma unroll
               for (int u = 0; u < 16; u++) {
-                if (!dead) {
-                  sc = sc + lsv[u];                                        // c/jda.c:396 (no normalisation here)
-                  if (TRACE) hash = fnv_step(hash, lf[u]);
-                  kd = k + u;
-                  dead = sc < thv[u];                                      // c/jda.c:399
-                }
+                sc = sc + lsv[u];                                          // c/jda.c:396 (no normalisation here)
+                sums[u] = sc;
+                rej |= (sc < thv[u]) ? (1u << u) : 0u;                     // c/jda.c:399
               }
-              score = sc;
-              if (dead) {
+              if (rej) {
+                const int j = __ffs((int)rej) - 1;
+                Real sd = sums[0];
+#pragma unroll
+                for (int u = 1; u < 16; u++) sd = (j >= u) ? sums[u] : sd;
+                if (TRACE)
+                  for (int u = 0; u <= j; u++) hash = fnv_step(hash, lf[u]);
+                score = sd;
                 alive = false;
-                my_carts += kd + 1;
-                if (TRACE) { w.tr_carts[gid] = kd + 1; w.tr_score[gid] = sc; w.tr_hash[gid] = hash; }
+                my_carts += k + j + 1;
+                if (TRACE) { w.tr_carts[gid] = k + j + 1; w.tr_score[gid] = sd; w.tr_hash[gid] = hash; }
+              } else {
+                if (TRACE) {
+#pragma unroll
+                  for (int u = 0; u < 16; u++) hash = fnv_step(hash, lf[u]);
+                }
+                score = sc;
               }
             }
           }
@@ -720,7 +750,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
             if (alive) {
               int lf[4];
 #pragma unroll
-              for (int u = 0; u < 4; u++) lf[u] = (k + u < r1) ? (int)lfbuf[(k + u - r0) * istride + item] : 0;
+              for (int u = 0; u < 4; u++) lf[u] = (k + u < r1) ? (int)lfbuf[item * rc + (k + u - r0)] : 0;
               if (k + 4 <= r1) {
                 apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
               } else {
@@ -732,7 +762,7 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
         }
         __syncthreads();
       }
-      if (wig == 0) {
+      if (wv < replay_waves) {
         const unsigned long long mask = __ballot(alive);
         if (mask) {
           int wbase = 0;
@@ -1041,15 +1071,6 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
 }
 
 // value held by lane j, as a wave-uniform scalar
-__device__ __forceinline__ int rl(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
-__device__ __forceinline__ float rl(float v, int j) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
-}
-__device__ __forceinline__ double rl(double v, int j) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-  return __hiloint2double(hi, lo);
-}
 
 }  // namespace
 
