@@ -703,17 +703,22 @@ __global__ __launch_bounds__(256) void k_scan(const DevPlan* __restrict__ plan, 
             if (__ballot(alive) == 0ull) break;
             const CartPar<Real> pm = t_par[k + (lane & 15)];       // lane u (mod 16): cart k+u
             if (__ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
-            const Real th_mine = pm.th;                            // broadcast from lane u below (no LDS read per cart)
+            // thresholds: lane u holds cart k+u's; broadcast with readlane HERE, with the whole wave
+            // active -- inside the divergent block below the lanes without a live window would not
+            // have loaded theirs
+            Real thv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) thv[u] = rl(pm.th, u);
             if (alive) {
               int lf[16];
-              Real lsv[16], thv[16];
+              Real lsv[16];
               // the window's 16 leaf indices are 16 consecutive bytes of lfbuf[window][cart]
               const uint4 pk = *(const uint4*)(lfbuf + item * rc + (k - r0));
               const unsigned pw4[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
               for (int u = 0; u < 16; u++) lf[u] = (int)((pw4[u >> 2] >> (8 * (u & 3))) & 0xffu);
 #pragma unroll
-              for (int u = 0; u < 16; u++) { lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; thv[u] = rl(th_mine, u); }
+              for (int u = 0; u < 16; u++) lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]];
               // branch-free: the 16 partial sums (the same adds in the same order), a bit per
               // rejecting cart, then the first set bit names the cart the window died at
               Real sums[16];
