@@ -675,8 +675,10 @@ struct Pass {
   bool collect() {
     const int dim = hm().dim();
     const long long wpf = pe->sp.windows;
+    const double t_dbg = now_ms();
     if (n_out && dets) {
       JDA_HIP(hipStreamSynchronize(st));
+      if (env_ll("JDA_DEBUG_TIMES", 0)) fprintf(stderr, "[jda] lane %d: results D2H wait %.3f ms (%zu detections)\n", lane, now_ms() - t_dbg, n_out);
       // back into scan order: sort (gid, arrival index) packed in one word -- gids are unique
       std::vector<unsigned long long> key(n_out);
       for (size_t i = 0; i < n_out; i++) key[i] = ((unsigned long long)g[i] << 32) | (unsigned long long)i;
@@ -690,6 +692,7 @@ struct Pass {
         dets->score[o0 + i] = sc[j];
         std::memcpy(&dets->shape[(o0 + i) * dim], &sh[(size_t)j * dim], dim * sizeof(Real));
       }
+      if (env_ll("JDA_DEBUG_TIMES", 0)) fprintf(stderr, "[jda] lane %d: collect total %.3f ms\n", lane, now_ms() - t_dbg);
     }
     if (want_trace()) {
       JDA_HIP(hipStreamSynchronize(st));

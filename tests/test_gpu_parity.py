@@ -612,3 +612,19 @@ def test_two_lanes_give_the_same_results_as_one(built, gpu, model_file, monkeypa
     ref = c1.detect_batch(frames, 1.25, 40, -1, -0.5)
     for a, b in zip(res, ref):
         _compare_detect(a, b)
+
+
+@pytest.mark.parametrize("size", [(100, 75), (64, 50), (131, 58), (90, 200)])
+@pytest.mark.parametrize("cart_th", [None, -1.6, -1.0])
+def test_levels_with_a_handful_of_windows(built, gpu, model_file, size, cart_th):
+    """Tiles with 1..16 windows go through k_scan's late-phase mapping ((window, cart) pairs over all
+    lanes, 16-cart register replay) from cart 16 on; with slowly rejecting thresholds they die there."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    kw = {} if cart_th is None else {"cart_th": cart_th, "norm_every": 50}
+    p, _ = model_file((2, 160, 9, 4), 8, seed=81, **kw)
+    frames = synth.make_frames(3, size[0], size[1], seed=82)
+    c, o = api.Cascador(p), Oracle(p)
+    _compare_trace(c, o, frames, scale=1.25, min_size=40, max_size=-1)
+    for i, d in enumerate(c.detect_batch(frames, 1.25, 40, -1, -1.0)):
+        _compare_detect(d, o.detect(frames[i], 1.25, 40, -1, -1.0))
