@@ -142,6 +142,10 @@ struct Cascador {
   Workspace<float> wf;
   Workspace<double> wd;
   unsigned long long* h_counters = nullptr;  // pinned
+  // host frames whose H2D copies run_device issues per sub-batch (set by stage_frames(.., defer), consumed
+  // by the next run_device): the copies of one sub-batch then overlap the kernels of the other lane
+  const unsigned char* const* pending_host = nullptr;
+  size_t pending_fbytes = 0;
 };
 
 template <typename Real> struct Sel;
@@ -473,6 +477,27 @@ struct RunStats {
   int dense_passes = 0;
 };
 
+// Copies a run of host frames to the staging buffer (frame i at dst + i*stride) on a stream.
+// Frames that lie back to back in host memory (one array) go as ONE strided copy: 256 separate
+// 300-KB copies from pageable memory reach ~15 GB/s, one copy of the batch ~40 GB/s.
+static bool copy_frames_h2d(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes,
+                            hipStream_t st) {
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && frames[j] == frames[j - 1] + fbytes) j++;
+    if (j - i == 1) {
+      JDA_HIP(hipMemcpyAsync(dst + (size_t)i * stride, frames[i], fbytes, hipMemcpyHostToDevice, st));
+    } else if (stride == fbytes) {
+      JDA_HIP(hipMemcpyAsync(dst + (size_t)i * stride, frames[i], fbytes * (size_t)(j - i), hipMemcpyHostToDevice, st));
+    } else {
+      JDA_HIP(hipMemcpy2DAsync(dst + (size_t)i * stride, stride, frames[i], fbytes, fbytes, (size_t)(j - i),
+                               hipMemcpyHostToDevice, st));
+    }
+    i = j;
+  }
+  return true;
+}
+
 // One sub-batch of frames going through the device pipeline on one lane (stream + workspace).
 // The pipeline has four host-visible waits (hand-off count, mid-queue count, counters, results);
 // the methods are the pieces between them, so that run_device can interleave two lanes: while
@@ -485,6 +510,7 @@ struct Pass {
   int lane = 0; hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
   WorkT<Real> w; size_t cap = 0;
   int f0 = 0, nf = 0;
+  const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
   // state between the steps
   bool dense = false, finished = false;
   long long n_tail = -1, n_mid = -1;
@@ -532,6 +558,8 @@ struct Pass {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
     JDA_HIP(hipEventRecord(ev[0], st));
+    if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes, st))
+      return false;
     if (multi) {
       const int W = pe->sp.width, H = pe->sp.height;
       const size_t stride = w.frame_stride;
@@ -718,7 +746,16 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   const long long wpf = pe->sp.windows;
   const bool want_trace = trace != nullptr;
   const bool multi = hm.multi_scale();
-  if (wpf == 0 || n == 0) return true;
+  const unsigned char* const* host_frames = c->pending_host;   // set by stage_frames(.., defer = true)
+  const size_t host_fbytes = c->pending_fbytes;
+  c->pending_host = nullptr; c->pending_fbytes = 0;
+  if (host_frames && d_frames != (const uint8_t*)Sel<Real>::ws(c).frames.p) host_frames = nullptr;   // stale: not this call's staging
+  if (n == 0) return true;
+  if (wpf == 0) {     // nothing to scan; still honour the staging contract
+    if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(d_frames), stride, host_frames, n, host_fbytes, c->stream[0])) return false;
+    if (host_frames) JDA_HIP(hipStreamSynchronize(c->stream[0]));
+    return true;
+  }
 
   // two lanes when the batch is big enough for each half to fill the machine
   const long long lanes_min = env_ll("JDA_LANES_MIN_WINDOWS", 2000000);
@@ -726,12 +763,17 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   if (lanes < 1) lanes = 1;
   if (lanes > kLanes) lanes = kLanes;
   if (n < 2 || (long long)n * wpf < lanes_min * 2) lanes = 1;
+  // frames still on the host: smaller sub-batches on two lanes, so that the (host-blocking, pageable)
+  // copy of one sub-batch overlaps the kernels of the previous one
+  const long long host_chunk = env_ll("JDA_HOST_CHUNK", 128);
+  if (host_frames && n >= 2 * host_chunk && env_ll("JDA_LANES", 2) >= 2) lanes = 2;
 
   // frames per sub-batch, bounded by the workspace budget (shared by the lanes)
   const size_t bpw = bytes_per_window<Real>(dim, want_trace);
   const long long budget = (env_ll("JDA_WORKSPACE_MB", 24 * 1024) << 20) / lanes;
   long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
   fpp = std::min<long long>(fpp, (n + lanes - 1) / lanes);
+  if (host_frames && lanes > 1) fpp = std::min<long long>(fpp, std::max<long long>(1, host_chunk));
   fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
   fpp = std::min<long long>(fpp, 65535);                       // the queues pack the frame index in 16 bits
   if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
@@ -778,6 +820,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       p.w = ws.w[l]; p.cap = cap;
       p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);
       p.w.frames = d_frames + (size_t)f0 * stride; p.w.frame_stride = stride; p.w.n_frames = p.nf;
+      if (host_frames) { p.host_frames = host_frames + f0; p.host_fbytes = host_fbytes; }
       p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
       p.w.hw = hw; p.w.hh = hh; p.w.qw = qw; p.w.qh = qh;
       f0 += p.nf;
@@ -941,13 +984,21 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   return 0;
 }
 
+// Reserves the staging buffer for n host frames.  defer = false: copies them now (callers that touch
+// the staged frames before run_device); defer = true: leaves the copies to run_device (per sub-batch).
 template <typename Real>
-static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n, size_t fbytes, size_t* stride) {
+static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n, size_t fbytes, size_t* stride,
+                         bool defer = false) {
   Workspace<Real>& ws = Sel<Real>::ws(c);
   *stride = (fbytes + 255) & ~(size_t)255;
-  if (!ws.frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
   for (int i = 0; i < n; i++)
-    JDA_HIP(hipMemcpyAsync((uint8_t*)ws.frames.p + (size_t)i * *stride, frames[i], fbytes, hipMemcpyHostToDevice, c->stream[0]));
+    if (!frames[i]) { fail("null frame pointer"); return false; }
+  if (ws.frames.bytes < *stride * (size_t)std::max(n, 1))
+    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
+  if (!ws.frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
+  c->pending_host = nullptr; c->pending_fbytes = 0;
+  if (defer) { c->pending_host = frames; c->pending_fbytes = fbytes; return true; }
+  if (!copy_frames_h2d((uint8_t*)ws.frames.p, *stride, frames, n, fbytes, c->stream[0])) return false;
   JDA_HIP(hipStreamSynchronize(c->stream[0]));
   return true;
 }
@@ -1056,6 +1107,7 @@ int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t f
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchDevice runs dialect C; use jdaDetectBatchCpp"); return -1; }
   if (!cascador) { fail("null cascador"); return -1; }
   std::lock_guard<std::mutex> lock(((Cascador*)cascador)->mu);
+  ((Cascador*)cascador)->pending_host = nullptr;      // frames are already on the device
   return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
 }
 
@@ -1070,7 +1122,7 @@ int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, in
   size_t stride = 0;
   std::lock_guard<std::mutex> lock(c->mu);
   if (!ensure_device(c)) return -1;
-  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   return detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, n, width, height, scale, min_size, max_size, th, opt, out);
 }
 
@@ -1105,7 +1157,7 @@ int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int
   if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
   if (!ensure_device(c) || !upload_model<float>(c)) return -1;
   size_t stride = 0;
-  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
   PlanEntry* pe = nullptr;
@@ -1154,7 +1206,7 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
   if (!ensure_device(c) || !upload_model<double>(c)) return -1;
   size_t stride = 0;
-  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
   PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
@@ -1360,7 +1412,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
   if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
   if (!ensure_device(c) || !upload_model<double>(c)) return -1;
   size_t stride = 0;
-  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
   PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
