@@ -108,6 +108,7 @@ struct PlanEntry {
   S0Node* table = nullptr;
   bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
   bool any_untiled = false;
+  size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
   unsigned long long last_use = 0;
 };
@@ -138,6 +139,8 @@ struct Cascador {
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
+  struct PlanBuffers { DevPlan* dp; S0Node* table; size_t table_cap; };
+  std::vector<PlanBuffers> plan_pool;     // device allocations of evicted plans (hipFree + hipMalloc per miss cost ~0.1 ms)
   unsigned long long plan_clock = 0;
   Workspace<float> wf;
   Workspace<double> wd;
@@ -181,11 +184,20 @@ static bool ensure_device(Cascador* c) {
   }
   if (c->device >= n) { fail("device ordinal out of range"); return false; }
   JDA_HIP(hipSetDevice(c->device));
-  for (auto& st : c->stream) JDA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  for (auto& lane : c->ev) for (auto& ev : lane) JDA_HIP(hipEventCreate(&ev));
+  // lane 0 now; the second lane's stream and events when a batch first needs them (ensure_lane):
+  // cascadors that only see single frames (one per host thread in the FDDB harness) keep one stream
+  JDA_HIP(hipStreamCreateWithFlags(&c->stream[0], hipStreamNonBlocking));
+  for (auto& ev : c->ev[0]) JDA_HIP(hipEventCreate(&ev));
   JDA_HIP(hipEventCreate(&c->ev_user));
   JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntShards * kCntStride * kLanes, hipHostMallocDefault));
   c->dev_init = true;
+  return true;
+}
+
+static bool ensure_lane(Cascador* c, int lane) {
+  if (c->stream[lane]) return true;
+  JDA_HIP(hipStreamCreateWithFlags(&c->stream[lane], hipStreamNonBlocking));
+  for (auto& ev : c->ev[lane]) JDA_HIP(hipEventCreate(&ev));
   return true;
 }
 
@@ -367,9 +379,8 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     auto victim = c->plans.begin();
     for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
       if (p->second.last_use < victim->second.last_use) victim = p;
-    (void)hipStreamSynchronize(c->stream[0]);
-    if (victim->second.dp) (void)hipFree(victim->second.dp);
-    if (victim->second.table) (void)hipFree(victim->second.table);
+    // the caller holds c->mu and every detect call ends synchronised, so nothing is using the victim
+    c->plan_pool.push_back({victim->second.dp, victim->second.table, victim->second.table_cap});
     c->plans.erase(victim);
   }
   if ((int)sp.levels.size() > kMaxLevels) { fail("too many pyramid levels"); return false; }
@@ -383,16 +394,27 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
   pe.fast_scan = s0_plain && env_ll("JDA_NO_FAST_SCAN", 0) == 0;
   assign_tiles(sp, c->hm, pe.fast_scan, &pe);
-  JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
-  JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
   size_t entries = 0;
   for (int i = 0; i < pe.hp.n_levels; i++)
     if (pe.hp.lv[i].tiled) entries += n0;
+  if (!c->plan_pool.empty()) {            // recycle an evicted plan's allocations
+    Cascador::PlanBuffers b = c->plan_pool.back();
+    c->plan_pool.pop_back();
+    pe.dp = b.dp; pe.table = b.table; pe.table_cap = b.table_cap;
+    if (pe.table_cap < entries) { if (pe.table) (void)hipFree(pe.table); pe.table = nullptr; pe.table_cap = 0; }
+  }
+  if (!pe.dp) JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
+  JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
   if (entries) {
-    JDA_HIP(hipMalloc((void**)&pe.table, entries * sizeof(S0Node)));
+    if (!pe.table) {
+      pe.table_cap = std::max(entries, (size_t)16 * n0);      // room for 16 levels: most recycled tables fit the next plan
+      JDA_HIP(hipMalloc((void**)&pe.table, pe.table_cap * sizeof(S0Node)));
+    }
     const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
     const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
     JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream[0]));
+    // the scans that read the table run on other streams (second lane, caller's stream)
+    JDA_HIP(hipStreamSynchronize(c->stream[0]));
   }
   pe.last_use = ++c->plan_clock;
   auto ins = c->plans.emplace(key, std::move(pe));
@@ -799,7 +821,10 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   // lane 0 runs on the caller's stream when one was given; the other lane is ordered after the
   // work already queued there
   hipStream_t lane_stream[kLanes];
-  for (int l = 0; l < lanes; l++) lane_stream[l] = c->stream[l];
+  for (int l = 0; l < lanes; l++) {
+    if (!ensure_lane(c, l)) return false;
+    lane_stream[l] = c->stream[l];
+  }
   if (user_stream) {
     lane_stream[0] = user_stream;
     if (lanes > 1) {
@@ -1042,8 +1067,9 @@ void jdaCascadorRelease(void* cascador) {
   if (!c) return;
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
-    for (auto& st : c->stream) (void)hipStreamSynchronize(st);
+    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
     for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
+    for (auto& b : c->plan_pool) { if (b.dp) (void)hipFree(b.dp); if (b.table) (void)hipFree(b.table); }
     c->mf.buf.release(); c->md.buf.release();
     c->wf.buf.release(); c->wf.frames.release(); c->wf.pyr.release();
     c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();

@@ -612,6 +612,12 @@ def test_two_lanes_give_the_same_results_as_one(built, gpu, model_file, monkeypa
     ref = c1.detect_batch(frames, 1.25, 40, -1, -0.5)
     for a, b in zip(res, ref):
         _compare_detect(a, b)
+    # ... also when the plan (stage-0 tables, built on an internal stream) is new in that very call
+    c3 = api.Cascador(p)
+    with torch.cuda.stream(st):
+        res3 = c3.detect_batch_device(d2, 1.25, 40, -1, -0.5, hip_stream=st.cuda_stream)
+    for a, b in zip(res3, ref):
+        _compare_detect(a, b)
 
 
 @pytest.mark.parametrize("size", [(100, 75), (64, 50), (131, 58), (90, 200)])
