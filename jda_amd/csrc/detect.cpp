@@ -138,6 +138,8 @@ struct Cascador {
   hipStream_t stream[kLanes] = {nullptr, nullptr};                  // one per lane, see Pass / run_device
   hipEvent_t ev[kLanes][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t ev_user = nullptr;
+  hipStream_t side[kLanes] = {nullptr, nullptr};            // global-pixel scan launch of a lane, next to its LDS-tiled launches
+  hipEvent_t ev_side[kLanes][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -200,6 +202,13 @@ static bool ensure_lane(Cascador* c, int lane) {
   if (c->stream[lane]) return true;
   JDA_HIP(hipStreamCreateWithFlags(&c->stream[lane], hipStreamNonBlocking));
   for (auto& ev : c->ev[lane]) JDA_HIP(hipEventCreate(&ev));
+  return true;
+}
+
+static bool ensure_side(Cascador* c, int lane) {
+  if (c->side[lane]) return true;
+  JDA_HIP(hipStreamCreateWithFlags(&c->side[lane], hipStreamNonBlocking));
+  for (auto& ev : c->ev_side[lane]) JDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   return true;
 }
 
@@ -531,7 +540,8 @@ template <typename Real>
 struct Pass {
   Cascador* c; PlanEntry* pe; const TraceOut<Real>* trace; RawDets<Real>* dets; RunStats* rs;
   bool apply_th; Real th; bool multi = false;   // multi: hm().multi_scale(), a scan of the model: computed once
-  int lane = 0; hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
+  int lane = 0; bool solo = true;   // solo: the only lane of this call
+  hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
   WorkT<Real> w; size_t cap = 0;
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
@@ -620,7 +630,7 @@ struct Pass {
     JDA_HIP(hipEventRecord(ev[1], st));
     if (pe->fast_scan) {
       const int handoff = (int)env_ll("JDA_HANDOFF", 128);
-      bool any_glb = false;
+      bool any_glb = false, side_pending = false;
       long long lds_blocks = 0;
       for (int l = 0; l < pe->hp.n_levels; l++) {
         if (pe->hp.lv[l].tiled == 2) any_glb = true;
@@ -629,10 +639,43 @@ struct Pass {
       if (lds_blocks > 0 && lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048)) {
         // small job (a frame or a few): all LDS-tiled levels in one launch -- every workgroup
         // is resident at once anyway, so per-level launches would only serialise their latency
+        if (any_glb && solo && env_ll("JDA_SIDE_SMALL", 0) && ensure_side(c, lane)) {
+          hipStream_t sd = c->side[lane];
+          JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
+          JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
+          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, sd));
+          JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
+          rs->scan_launches++;
+          any_glb = false;
+          side_pending = true;
+        }
         JDA_HIP(launch_scan<Real>(-2, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
         rs->scan_launches++;
       } else {
-        for (int l = 0; l < pe->hp.n_levels; l++) {
+        // odd lanes go through the levels in the opposite order (global-pixel launch first): the
+        // texture-addresser-bound launch of one lane then runs next to the LDS/VALU-bound launches
+        // of the other instead of next to its twin
+        const bool rev = (lane & 1) && env_ll("JDA_LANES_REVERSE", 1);
+        if (any_glb && solo && env_ll("JDA_SIDE_STREAM", 1) && ensure_side(c, lane)) {
+          // one lane only: the global-pixel launch goes to a side stream, forked here and joined
+          // before the hand-off count is read, so that it runs next to the LDS-tiled launches
+          // (with two lanes the other lane already provides that mix; measured slower there)
+          hipStream_t sd = c->side[lane];
+          JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
+          JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
+          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, sd));
+          JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
+          rs->scan_launches++;
+          any_glb = false;
+          side_pending = true;
+        }
+        if (rev && any_glb) {
+          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
+          rs->scan_launches++;
+          any_glb = false;
+        }
+        for (int li = 0; li < pe->hp.n_levels; li++) {
+          const int l = rev ? pe->hp.n_levels - 1 - li : li;
           if (pe->hp.lv[l].tiled != 1) continue;
           JDA_HIP(launch_scan<Real>(l, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
           rs->scan_launches++;
@@ -642,6 +685,7 @@ struct Pass {
         JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
         rs->scan_launches++;
       }
+      if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
@@ -842,7 +886,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     for (int l = 0; l < lanes && f0 < n; l++) {
       Pass<Real> p;
       p.c = c; p.pe = pe; p.trace = trace; p.dets = dets; p.rs = rs; p.apply_th = apply_th; p.th = th; p.multi = multi;
-      p.lane = l; p.st = lane_stream[l]; p.ev = c->ev[l];
+      p.lane = l; p.solo = lanes == 1; p.st = lane_stream[l]; p.ev = c->ev[l];
       p.h_cnt = c->h_counters + (size_t)l * kCntShards * kCntStride;
       p.w = ws.w[l]; p.cap = cap;
       p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);
@@ -1138,6 +1182,8 @@ void jdaCascadorRelease(void* cascador) {
     for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
     for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& st : c->side) if (st) (void)hipStreamDestroy(st);
+    for (auto& l : c->ev_side) for (auto& ev : l) if (ev) (void)hipEventDestroy(ev);
   }
   delete c;
 }
