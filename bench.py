@@ -143,19 +143,20 @@ def main():
         torch.cuda.synchronize()
 
     def run_regime(regime, steps, warmup, th, lanes=None):
-        """lanes=1 serialises the library's two sub-batch lanes (JDA_LANES): the k_scan launches then run back
-        to back and the HIP-event span around them is the sum of their durations (roofline leg)."""
-        saved = os.environ.get("JDA_LANES")
-        if lanes is not None:
-            os.environ["JDA_LANES"] = str(lanes)
+        """lanes=1 serialises the library's two sub-batch lanes and keeps the global-pixel launch on the lane's own
+        stream (JDA_LANES=1, JDA_SIDE_STREAM=0): the k_scan launches then run back to back and the HIP-event span
+        around them is the sum of their durations (roofline leg)."""
+        keys = {"JDA_LANES": str(lanes), "JDA_SIDE_STREAM": "0"} if lanes is not None else {}
+        saved = {k: os.environ.get(k) for k in keys}
+        os.environ.update(keys)
         try:
             return _run_regime(regime, steps, warmup, th)
         finally:
-            if lanes is not None:
-                if saved is None:
-                    os.environ.pop("JDA_LANES", None)
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
                 else:
-                    os.environ["JDA_LANES"] = saved
+                    os.environ[k] = v
 
     def _run_regime(regime, steps, warmup, th):
         mp = model_path(dims, regime, 1, calib)
@@ -253,8 +254,9 @@ def main():
                                    "'launch' here = the %d launches of one step)" % roof_info["scan_launches"],
                          "algorithmic_bytes_per_step": roof_info["scan_algorithmic_bytes"],
                          "kernel_ms_per_step": roof_info["scan_ms_per_step"],
-                         "measured_with": "JDA_LANES=1 (sub-batches serialised: the HIP-event span around the k_scan "
-                                          "launches is the sum of their durations; the throughput legs use 2 lanes)",
+                         "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0 (launches serialised on one stream: the HIP-event span "
+                                          "around the k_scan launches is the sum of their durations; the throughput "
+                                          "legs overlap two sub-batches on two streams)",
                          "note": "algorithmic bytes = SURVEY 8(d) per-window figure; they are served from LDS/L2 by "
                                  "design, HBM traffic is the frames + model once"},
             "cpu_baseline": cpu,

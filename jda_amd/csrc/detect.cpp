@@ -959,6 +959,13 @@ static WinRef locate(const ScanPlan& sp, uint32_t gid) {
 class PostPool {
  public:
   static PostPool& get() { static PostPool p; return p; }
+  // A batch call announces its post-processing job ahead of time (when it starts its GPU work):
+  // the workers wake up now and spin until the job arrives or `ms` have passed.
+  void prewake(int n, double ms) {
+    if (ms <= 0 || n < 64 || workers_.empty()) return;     // off by default: measured neutral to slightly negative
+    { std::lock_guard<std::mutex> lk(mu_); armed_until_.store(now_ms() + ms); }
+    cv_.notify_all();
+  }
   // heavy: the items are expensive (many detections per frame), worth spreading even a few of them
   void run(int n, const std::function<void(int)>& fn, bool heavy) {
     const bool use = workers_.empty() ? false : (heavy ? n >= 2 : n >= 64);
@@ -966,11 +973,11 @@ class PostPool {
     auto job = std::make_shared<Job>();
     job->chunk = heavy ? 1 : 8;
     job->fn = &fn; job->n = n; job->chunks = (n + job->chunk - 1) / job->chunk;
-    { std::lock_guard<std::mutex> lk(mu_); job_ = job; gen_++; }
+    { std::lock_guard<std::mutex> lk(mu_); job_ = job; gen_.fetch_add(1, std::memory_order_release); }
     cv_.notify_all();
     work(*job);
     while (job->done.load(std::memory_order_acquire) < job->chunks) std::this_thread::yield();
-    { std::lock_guard<std::mutex> lk(mu_); job_.reset(); }
+    { std::lock_guard<std::mutex> lk(mu_); job_.reset(); armed_until_.store(0.0); }
     job_mu_.unlock();
   }
 
@@ -1004,9 +1011,18 @@ class PostPool {
       std::shared_ptr<Job> job;
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+        cv_.wait(lk, [&]() { return stop_ || gen_.load() != seen || now_ms() < armed_until_.load(); });
         if (stop_) return;
-        seen = gen_;
+      }
+      // armed (a batch call is in flight): stay awake until its job arrives -- a sleeping worker
+      // can take longer to wake than the whole 0.2 ms job lasts
+      while (gen_.load(std::memory_order_acquire) == seen && now_ms() < armed_until_.load(std::memory_order_relaxed))
+        std::this_thread::yield();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (stop_) return;
+        if (gen_.load() == seen) continue;       // the arming ran out without a job
+        seen = gen_.load();
         job = job_;               // may already be gone (a late wake-up): nothing to do then
       }
       if (job) work(*job);        // a finished job hands out no chunk, so its fn is never called late
@@ -1015,7 +1031,8 @@ class PostPool {
   std::mutex mu_, job_mu_;
   std::condition_variable cv_;
   std::shared_ptr<Job> job_;
-  unsigned long long gen_ = 0;
+  std::atomic<unsigned long long> gen_{0};
+  std::atomic<double> armed_until_{0.0};
   bool stop_ = false;
   std::vector<std::thread> workers_;
 };
@@ -1069,6 +1086,7 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   if (!get_plan(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
   RawDets<float> dets;
   RunStats rs;
+  PostPool::get().prewake(n, env_ll("JDA_POST_PREWAKE_MS", 0));   // per-frame NMS + assembly follows the GPU work
   if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
     return -1;
 

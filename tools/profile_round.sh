@@ -12,15 +12,15 @@ python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu --no-allpass"
 # kernel trace: one lane (k_scan launches back to back: durations comparable with roofline.kernel_ms_per_step)
-JDA_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt_lane1 -- $B --steps 10 --warmup 2 > $O/bench_kt_lane1.json 2> /dev/null
+JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/kt_lane1 -- $B --steps 10 --warmup 2 > $O/bench_kt_lane1.json 2> /dev/null
 # kernel trace: default (two lanes, kernels of the two sub-batches overlap)
 rocprofv3 --kernel-trace --stats -d $O/kt -- $B --steps 10 --warmup 2 > $O/bench_kt.json 2> /dev/null
 # HBM traffic: separate passes, one counter each (1 warm-up + 4 steps + roofline leg 1 + 4 = 10 passes of the batch)
-JDA_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -- $B --steps 4 --warmup 1 > /dev/null 2>&1
-JDA_LANES=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -- $B --steps 4 --warmup 1 > /dev/null 2>&1
+JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -- $B --steps 4 --warmup 1 > /dev/null 2>&1
+JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -- $B --steps 4 --warmup 1 > /dev/null 2>&1
 # SQ counters, cascade regime
-JDA_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq1 -- $B --steps 4 --warmup 1 > /dev/null 2>&1
-JDA_LANES=1 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM -d $O/pmc_sq2 -- $B --steps 4 --warmup 1 > /dev/null 2>&1
+JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq1 -- $B --steps 4 --warmup 1 > /dev/null 2>&1
+JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM -d $O/pmc_sq2 -- $B --steps 4 --warmup 1 > /dev/null 2>&1
 # SQ counters, all-pass regime (k_stage)
 A="python $R/tools/allpass.py --steps 1 --batch 64"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $O/pmc_stage -- $A > $O/allpass.txt 2>&1
