@@ -995,7 +995,10 @@ class PostPool {
     }
   }
   PostPool() {
-    const long long want = env_ll("JDA_POST_THREADS", 6);
+    // Off by default: typically 0.22 -> 0.08 ms per 256-frame batch with 6 workers, but 1 run in ~50 on the
+    // shared GPU boxes had a worker descheduled in mid-chunk (a multi-millisecond stall of the whole call);
+    // the serial path is deterministic.  Opt in with JDA_POST_THREADS=6 on a quiet host.
+    const long long want = env_ll("JDA_POST_THREADS", 0);
     const unsigned hwc = std::thread::hardware_concurrency();
     const int nw = (int)std::max<long long>(0, std::min<long long>(want, hwc > 1 ? hwc - 1 : 0));
     for (int i = 0; i < nw; i++) workers_.emplace_back([this]() { loop(); });
