@@ -1108,13 +1108,13 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   }
   parallel_for(n, [&](int f) {
     const size_t a = first[f], cnt = first[f + 1] - a;
-    std::vector<int> bb(cnt * 3);
+    static thread_local std::vector<int> bb, keep;          // per-frame scratch, grown once per thread
+    bb.resize(cnt * 3);
     for (size_t i = 0; i < cnt; i++) {
       const WinRef wr = locate(sp, dets.gid[a + i]);
       bb[3 * i] = wr.x; bb[3 * i + 1] = wr.y; bb[3 * i + 2] = wr.win;
     }
-    std::vector<int> keep;
-    if (do_nms) keep = nms_dialect_c(bb.data(), &dets.score[a], (int)cnt, overlap);
+    if (do_nms) nms_dialect_c_into(bb.data(), &dets.score[a], (int)cnt, overlap, &keep);
     else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
     jdaResult& r = out[f];
     r.n = (int)keep.size(); r.landmark_n = L;

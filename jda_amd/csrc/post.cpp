@@ -8,6 +8,12 @@
 namespace jda {
 
 std::vector<int> nms_dialect_c(const int* bb, const float* scores, int n, float overlap) {
+  std::vector<int> out;
+  nms_dialect_c_into(bb, scores, n, overlap, &out);
+  return out;
+}
+
+void nms_dialect_c_into(const int* bb, const float* scores, int n, float overlap, std::vector<int>* keep_out) {
   // scratch reused across calls on this thread (the per-frame lists are short and many)
   static thread_local std::vector<int> order;
   static thread_local std::vector<char> keep;
@@ -56,10 +62,10 @@ std::vector<int> nms_dialect_c(const int* bb, const float* scores, int n, float 
       if (ov > overlap) keep[b] = 0;
     }
   }
-  std::vector<int> out;
+  std::vector<int>& out = *keep_out;
+  out.clear();
   for (int i = 0; i < n; i++)                             // c/jda.c:295-301: scan order
     if (keep[i]) out.push_back(i);
-  return out;
 }
 
 void relocate_dialect_c(float* shape, int landmark_n, int x, int y, int size) {

@@ -9,6 +9,8 @@ namespace jda {
 // Dialect C NMS (reference c/jda.c:237-316). Input: n boxes (x,y,size) in scan
 // order with scores. Returns the indices that survive, in scan order.
 std::vector<int> nms_dialect_c(const int* bboxes3, const float* scores, int n, float overlap);
+// The same into a caller-owned vector (no allocation once it has grown): the per-frame loop of a batch.
+void nms_dialect_c_into(const int* bboxes3, const float* scores, int n, float overlap, std::vector<int>* keep_out);
 
 // Dialect C relocation (reference c/jda.c:465-474): shape = shape*size + origin,
 // a float multiply followed by a float add (never fused).
