@@ -634,3 +634,31 @@ def test_levels_with_a_handful_of_windows(built, gpu, model_file, size, cart_th)
     _compare_trace(c, o, frames, scale=1.25, min_size=40, max_size=-1)
     for i, d in enumerate(c.detect_batch(frames, 1.25, 40, -1, -1.0)):
         _compare_detect(d, o.detect(frames[i], 1.25, 40, -1, -1.0))
+
+
+def test_two_lanes_dialect_cpp_and_dense_mode(built, gpu, model_file, monkeypatch):
+    """The lane split is dialect-agnostic and composes with the dense path and the side stream."""
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=91, cart_th=-0.7, norm_every=11)
+    frames = synth.make_frames(6, 220, 170, seed=92)
+    monkeypatch.setenv("JDA_LANES", "1")
+    monkeypatch.setenv("JDA_SIDE_STREAM", "0")
+    c1 = api.Cascador(p)
+    want = c1.detect_batch_cpp(frames, 20, 5, 1.2)
+    tr1 = c1.trace_cpp(frames, 20, 5, 1.2)
+    for env in ({"JDA_LANES": "2", "JDA_LANES_MIN_WINDOWS": "1"},
+                {"JDA_LANES": "2", "JDA_LANES_MIN_WINDOWS": "1", "JDA_DENSE": "2"},
+                {"JDA_LANES": "1", "JDA_SIDE_STREAM": "1", "JDA_SIDE_SMALL": "1", "JDA_MERGE_BLOCKS": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = api.Cascador(p)
+        got = c2.detect_batch_cpp(frames, 20, 5, 1.2)
+        for a, b in zip(got, want):
+            for k in ("rects", "scores", "shapes"):
+                assert same(a[k], b[k]), (env, k)
+        tr2 = c2.trace_cpp(frames, 20, 5, 1.2)
+        for k in tr1:
+            assert same(tr1[k], tr2[k]), (env, k)
+        for k in env:
+            monkeypatch.delenv(k)
+        monkeypatch.setenv("JDA_SIDE_STREAM", "0")
