@@ -121,10 +121,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the detect path has no CPU fallback")
+    # test hooks (not used by the driver): all ranks on one GPU and a gloo group, to exercise the N>1 control
+    # flow on a 1-GPU box -- RCCL itself needs one GPU per rank
+    backend = os.environ.get("JDA_BENCH_BACKEND", "nccl")
+    if os.environ.get("JDA_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     dims = tuple(int(x) for x in args.dims.split(","))
     T, K, L, D = dims
     W, H, B = args.width, args.height, args.batch
@@ -170,7 +179,7 @@ def main():
                                            frame_offset=rank * B)
             rows, st = out if want_stats else (out, None)
             if world > 1:
-                jdist.gather_detections_fixed(rows, 4096, device=dev)
+                jdist.gather_detections_fixed(rows, 4096, device=gather_dev)
             return len(rows), st
 
         for _ in range(warmup):
@@ -185,7 +194,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=gather_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         st = stats[-1]

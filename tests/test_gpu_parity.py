@@ -662,3 +662,23 @@ def test_two_lanes_dialect_cpp_and_dense_mode(built, gpu, model_file, monkeypatc
         for k in env:
             monkeypatch.delenv(k)
         monkeypatch.setenv("JDA_SIDE_STREAM", "0")
+
+
+def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
+    """bench.py's N>1 path (barriers, max-over-ranks timing, gather of the detections on rank 0) with two
+    ranks that share this GPU over a gloo group -- RCCL itself needs one GPU per rank, the driver runs that."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu", "--no-allpass"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["achieved"] > 0 and d["regimes"]["cascade"]["detections_after_nms"] > 0
