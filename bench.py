@@ -8,7 +8,8 @@ later stages, regression, compaction, D2H of survivors, host NMS+relocation)
 over one batch of synthetic frames that is already resident in HBM.  At N>1
 the driver launches one process per GPU with torch.distributed.run; every rank
 runs its own batch (weak scaling, no data-path collective) and the detections
-are gathered on rank 0 over RCCL inside the timed step.
+are gathered on rank 0 over RCCL inside the timed region (the gather of step i
+overlaps the detection of step i+1; the last one is drained before the clock stops).
 
 Workload = BASELINE.json configs[1]: batch of 256 frames 640x480, synthetic
 model with the shipped dimensions (T=5, K=540, 27 landmarks, depth 4), canonical
@@ -171,19 +172,25 @@ def main():
         mp = model_path(dims, regime, 1, calib)
         casc = api.Cascador(mp, device=local_rank)
 
+        # N>1: one RCCL all_gather of fixed-size blocks brings the (bbox, score, landmarks) rows to rank 0.  It is
+        # pipelined one step behind: the collective of step i runs on the communicator's stream while step i+1
+        # detects and is collected (counts, valid rows -> host on rank 0) by step i+1; the last one is drained
+        # before the closing barrier, so all K gathers complete inside the timed region.
+        gather = jdist.PipelinedGather(4096, 5 + 2 * L, device=gather_dev)
+
         def step(want_stats=False):
-            # every rank: detect its batch, flatten the (bbox, score, landmarks) tuples with one C call;
-            # N>1: one RCCL all_gather of fixed-size blocks brings them to rank 0
+            # every rank: detect its batch, flatten the (bbox, score, landmarks) tuples with one C call
             out = casc.detect_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th,
                                            nms=True, stats=want_stats, keep_results="packed",
                                            frame_offset=rank * B)
             rows, st = out if want_stats else (out, None)
             if world > 1:
-                jdist.gather_detections_fixed(rows, 4096, device=gather_dev)
+                gather.start(rows)
             return len(rows), st
 
         for _ in range(warmup):
             step()
+        gather.drain()
         barrier()
         t0 = time.perf_counter()
         stats = []
@@ -191,6 +198,7 @@ def main():
         for _ in range(steps):
             n_det, st = step(True)
             stats.append(st)
+        gather.drain()
         barrier()
         el = time.perf_counter() - t0
         if world > 1:

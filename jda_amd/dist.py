@@ -110,3 +110,64 @@ def gather_detections_fixed(mat, max_rows, device=None, group=None):
         return None
     parts = [allb[r][1:1 + counts[r]].cpu().numpy() for r in range(world)]
     return np.concatenate(parts) if parts else np.zeros((0, width), np.float32)
+
+
+class PipelinedGather:
+    """gather_detections_fixed split into start() and finish(), with two sets of preallocated buffers:
+    the collective of step i runs on the communicator's stream while step i+1 detects, and is
+    collected (counts read, valid rows copied to the host on rank 0) one step later.  Every gather
+    is still finished inside the region that started it -- call drain() before the closing barrier."""
+
+    def __init__(self, max_rows, width, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group, self.max_rows, self.width = group, max_rows, width
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.pending = None
+        if not self.active:
+            return
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.block = [torch.zeros((1 + max_rows, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.allb = [[torch.empty_like(self.block[0]) for _ in range(self.world)] for _ in range(2)]
+        self.slot = 0
+
+    def start(self, mat):
+        """Launches the collective for this rank's rows; returns what the PREVIOUS start() gathered
+        (rows of every rank on rank 0, None elsewhere; None on the first call)."""
+        import torch
+        import torch.distributed as dist
+        if not self.active:
+            prev, self.pending = self.pending, ("local", mat)
+            return prev[1] if prev else None
+        s = self.slot
+        n = mat.shape[0]
+        blk = self.block[s]
+        blk[0, 0] = float(n)
+        if 0 < n <= self.max_rows:
+            blk[1:1 + n].copy_(torch.from_numpy(np.ascontiguousarray(mat)), non_blocking=False)
+        work = dist.all_gather(self.allb[s], blk, group=self.group, async_op=True)
+        prev, self.pending = self.pending, (work, s, mat)
+        self.slot ^= 1
+        return self._finish(prev) if prev else None
+
+    def drain(self):
+        """Finishes the gather still in flight (rows on rank 0, None elsewhere / when nothing is pending)."""
+        prev, self.pending = self.pending, None
+        if prev is None:
+            return None
+        if not self.active:
+            return prev[1]
+        return self._finish(prev)
+
+    def _finish(self, token):
+        import torch
+        work, s, mat = token
+        work.wait()
+        counts = [int(c) for c in torch.stack([b[0, 0] for b in self.allb[s]]).tolist()]     # one device->host sync
+        if max(counts) > self.max_rows:       # same decision on every rank: the counts were gathered
+            return gather_detections(mat, device=self.dev, group=self.group)
+        if self.rank != 0:
+            return None
+        parts = [self.allb[s][r][1:1 + counts[r]].cpu().numpy() for r in range(self.world)]
+        return np.concatenate(parts) if parts else np.zeros((0, self.width), np.float32)

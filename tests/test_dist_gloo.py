@@ -149,3 +149,57 @@ def test_results_pack_matches_python_packing():
     assert api.lib.jdaResultsPack(arr, 3, 7, out.ctypes.data_as(C.POINTER(C.c_float)), rows) == 5
     assert np.array_equal(out, jd.pack_detections(res_py, L, frame_offset=7))
     assert api.lib.jdaResultsPack(arr, 3, 7, out.ctypes.data_as(C.POINTER(C.c_float)), 4) == -1
+
+
+def _worker_pipelined(rank, world, port, q, max_rows):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from jda_amd import dist as jd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = jd.PipelinedGather(max_rows, 9, device="cpu")
+    outs = []
+    for step in range(4):                                 # step 2 overflows max_rows=16 on rank 1 -> fallback
+        n = 3 + step + (30 * rank if step == 2 else rank)
+        mat = np.full((n, 9), 10 * step + rank + 1, np.float32)
+        mat[:, 0] = np.arange(n) + 1000 * rank
+        outs.append(pg.start(mat))                        # returns the PREVIOUS step's gather
+    outs.append(pg.drain())
+    assert outs[0] is None and pg.drain() is None
+    if rank == 0:
+        q.put(outs[1:])
+    else:
+        assert all(o is None for o in outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("max_rows", [64, 16])
+def test_pipelined_gather_is_one_step_behind_and_complete(max_rows):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, q, max_rows)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len(got) == 4
+    for step, g in enumerate(got):
+        n0 = 3 + step
+        n1 = 3 + step + (30 if step == 2 else 1)
+        assert g.shape == (n0 + n1, 9), (step, g.shape)
+        assert (g[:n0, 1:] == 10 * step + 1).all() and (g[n0:, 1:] == 10 * step + 2).all()
+        assert list(g[:n0, 0]) == list(np.arange(n0)) and list(g[n0:, 0]) == list(1000 + np.arange(n1))
+
+
+def test_pipelined_gather_single_process():
+    from jda_amd import dist as jd
+    pg = jd.PipelinedGather(8, 3)
+    a, b = np.ones((2, 3), np.float32), np.zeros((1, 3), np.float32)
+    assert pg.start(a) is None
+    assert pg.start(b) is a
+    assert pg.drain() is b and pg.drain() is None
