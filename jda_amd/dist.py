@@ -118,11 +118,12 @@ class PipelinedGather:
     collected (counts read, valid rows copied to the host on rank 0) one step later.  Every gather
     is still finished inside the region that started it -- call drain() before the closing barrier."""
 
-    def __init__(self, max_rows, width, device=None, group=None):
+    def __init__(self, max_rows, width, device=None, group=None, force=False):
+        """force: run the collective even in a group of one (tests of the device path on a 1-GPU box)."""
         import torch
         import torch.distributed as dist
         self.group, self.max_rows, self.width = group, max_rows, width
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.pending = None
         if not self.active:
             return
@@ -131,6 +132,10 @@ class PipelinedGather:
         self.block = [torch.zeros((1 + max_rows, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
         self.allb = [[torch.empty_like(self.block[0]) for _ in range(self.world)] for _ in range(2)]
         self.slot = 0
+        # rank 0 copies the valid rows out through pinned memory: one asynchronous copy per rank, one sync
+        self.host = None
+        if self.rank == 0 and self.dev.type == "cuda":
+            self.host = torch.empty((self.world, max_rows, width), dtype=torch.float32).pin_memory()
 
     def start(self, mat):
         """Launches the collective for this rank's rows; returns what the PREVIOUS start() gathered
@@ -169,5 +174,12 @@ class PipelinedGather:
             return gather_detections(mat, device=self.dev, group=self.group)
         if self.rank != 0:
             return None
-        parts = [self.allb[s][r][1:1 + counts[r]].cpu().numpy() for r in range(self.world)]
+        if self.host is not None:
+            for r in range(self.world):
+                if counts[r]:
+                    self.host[r, :counts[r]].copy_(self.allb[s][r][1:1 + counts[r]], non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+            parts = [self.host[r, :counts[r]].numpy() for r in range(self.world)]
+        else:
+            parts = [self.allb[s][r][1:1 + counts[r]].cpu().numpy() for r in range(self.world)]
         return np.concatenate(parts) if parts else np.zeros((0, self.width), np.float32)

@@ -682,3 +682,36 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["achieved"] > 0 and d["regimes"]["cascade"]["detections_after_nms"] > 0
+
+
+def test_pipelined_gather_device_path_over_rccl_group_of_one(built, gpu):
+    """The device side of PipelinedGather (RCCL all_gather issued asynchronously, collected a step later through
+    pinned memory) in a process group of one rank -- all a 1-GPU box can host."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+from jda_amd import dist as jd
+pg = jd.PipelinedGather(16, 7, device=dev, force=True)
+outs = []
+for step in range(4):
+    n = [3, 0, 40, 16][step]                      # empty, overflowing (fallback) and exactly full blocks
+    m = np.full((n, 7), step + 1, np.float32); m[:, 0] = np.arange(n)
+    outs.append(pg.start(m))
+outs.append(pg.drain())
+assert outs[0] is None
+for step, g in enumerate(outs[1:]):
+    n = [3, 0, 40, 16][step]
+    assert g.shape == (n, 7) and (g[:, 1:] == step + 1).all() and list(g[:, 0]) == list(range(n)), (step, g.shape)
+dist.barrier(); dist.destroy_process_group()
+print("OK")
+''' % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
