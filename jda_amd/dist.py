@@ -116,7 +116,9 @@ class PipelinedGather:
     """gather_detections_fixed split into start() and finish(), with two sets of preallocated buffers:
     the collective of step i runs on the communicator's stream while step i+1 detects, and is
     collected (counts read, valid rows copied to the host on rank 0) one step later.  Every gather
-    is still finished inside the region that started it -- call drain() before the closing barrier."""
+    is still finished inside the region that started it -- call drain() before the closing barrier.
+    On a GPU group the rows returned on rank 0 are a view of a pinned buffer that is reused two
+    collections later; copy them if they must live longer."""
 
     def __init__(self, max_rows, width, device=None, group=None, force=False):
         """force: run the collective even in a group of one (tests of the device path on a 1-GPU box)."""
@@ -135,7 +137,7 @@ class PipelinedGather:
         # rank 0 copies the valid rows out through pinned memory: one asynchronous copy per rank, one sync
         self.host = None
         if self.rank == 0 and self.dev.type == "cuda":
-            self.host = torch.empty((self.world, max_rows, width), dtype=torch.float32).pin_memory()
+            self.host = [torch.empty((self.world * max_rows, width), dtype=torch.float32).pin_memory() for _ in range(2)]
 
     def start(self, mat):
         """Launches the collective for this rank's rows; returns what the PREVIOUS start() gathered
@@ -175,11 +177,15 @@ class PipelinedGather:
         if self.rank != 0:
             return None
         if self.host is not None:
+            # valid rows of every rank land back to back in pinned memory: the result is a view of it
+            # (no concatenation), valid until the gather after next is collected
+            off = 0
             for r in range(self.world):
                 if counts[r]:
-                    self.host[r, :counts[r]].copy_(self.allb[s][r][1:1 + counts[r]], non_blocking=True)
+                    self.host[s][off:off + counts[r]].copy_(self.allb[s][r][1:1 + counts[r]], non_blocking=True)
+                off += counts[r]
             torch.cuda.current_stream(self.dev).synchronize()
-            parts = [self.host[r, :counts[r]].numpy() for r in range(self.world)]
+            return self.host[s][:off].numpy()
         else:
             parts = [self.allb[s][r][1:1 + counts[r]].cpu().numpy() for r in range(self.world)]
         return np.concatenate(parts) if parts else np.zeros((0, self.width), np.float32)
