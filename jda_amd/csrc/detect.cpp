@@ -554,6 +554,8 @@ struct Pass {
   const HostModel& hm() const { return c->hm; }
   const DevModelT<Real>& model() const { return Sel<Real>::model(c).m; }
   bool want_trace() const { return trace != nullptr; }
+  // resolved stage-0 tables for k_finish (A/B switch: JDA_FIN_S0=0)
+  const S0Node* s0_tbl() const { return (pe->fast_scan && env_ll("JDA_FIN_S0", 1)) ? pe->table : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {
@@ -711,13 +713,13 @@ struct Pass {
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
-      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", 4), n_tail, st));
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", 4), n_tail, s0_tbl(), st));
       finished = true;
       return true;
     }
     // Two launches so that the few windows that pass stage 0 (and then cost whole stages
     // each) are spread over the machine again.
-    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), st));
     return read_counter(kCntMid);
   }
 
@@ -726,7 +728,7 @@ struct Pass {
     if (finished) return true;
     JDA_HIP(hipStreamSynchronize(st));
     n_mid = (long long)std::min<unsigned long long>(h_cnt[0], cap);
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", 4), n_mid, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", 4), n_mid, nullptr, st));
     finished = true;
     return true;
   }

@@ -163,7 +163,8 @@ hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan
 template <typename Real>
 hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
-                         int groups, long long n_hint, hipStream_t stream);
+                         int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream);
+// s0_table: the plan's resolved stage-0 tables (or null): stage 0 of windows from levels that have one walks from it
 
 // Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
 // pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).

@@ -1104,6 +1104,48 @@ __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
 }
 
+// Stage-0 walks from the resolved tables k_scan uses (S0Node, one 8-byte record per node with both
+// pixel offsets and the threshold): one record load instead of two, no coordinate arithmetic.
+// mode 2: offsets are frame offsets (row pitch = frame width); mode 1: offsets are LDS-tile
+// offsets y*pitch + x, split back into (y, x) with an exact float division ((off + 0.5) / pitch is
+// at least 0.5/pitch away from an integer, the float error is below 1e-4 of that).
+template <int G>
+__device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, const int* k, int depth, int node_n,
+                                              int mode, int pitch, float inv_pitch, const uint8_t* __restrict__ wbase,
+                                              int W, int* leaf) {
+  int node[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) node[g] = 0;
+  for (int d = 0; d < depth - 1; d++) {
+    S0Node r[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) r[g] = tbl[(unsigned)(k[g] * node_n + node[g])];
+    unsigned o1[G], o2[G];
+    int th[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (mode == 2) {
+        o1[g] = r[g].lo & 0x1fffffu;
+        o2[g] = __builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu;
+        th[g] = (int)(r[g].hi >> 10) - 256;
+      } else {
+        const unsigned a = r[g].lo & 0xffffu, b = r[g].lo >> 16;
+        const unsigned ya = (unsigned)(((float)a + 0.5f) * inv_pitch), yb = (unsigned)(((float)b + 0.5f) * inv_pitch);
+        o1[g] = __umul24(ya, (unsigned)W) + (a - __umul24(ya, (unsigned)pitch));
+        o2[g] = __umul24(yb, (unsigned)W) + (b - __umul24(yb, (unsigned)pitch));
+        th[g] = (int)r[g].hi;
+      }
+    }
+    int pa[G], pb[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { pa[g] = wbase[o1[g]]; pb[g] = wbase[o2[g]]; }
+#pragma unroll
+    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (pa[g] - pb[g] <= th[g] ? 1 : 2);   // c/jda.c:391-393
+  }
+#pragma unroll
+  for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
+}
+
 // Score recurrence of c/jda.c:395-399 over the carts held by lanes [jbeg, jend)
 // of one 64-cart group, replayed strictly in cart order.  ls/th_k/mean_k/std_k/lf
 // are per-lane values of cart (group base + lane).  Returns the lane of the
@@ -1158,7 +1200,8 @@ __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real l
 template <typename DL, bool TRACE, int kG, bool MULTI, bool ST>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
-                                               int t_begin, int t_end, int apply_th, typename DL::Real final_th) {
+                                               int t_begin, int t_end, int apply_th, typename DL::Real final_th,
+                                               const S0Node* __restrict__ s0_table) {
   using Real = typename DL::Real;
   using Node = typename DL::Node;
   constexpr bool kCpp = sizeof(Real) == 8;
@@ -1189,6 +1232,19 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     const uint32_t xy = from_scan ? w.q_xy[i] : w.m_xy[i];
     const uint32_t wf = from_scan ? w.q_wf[i] : w.m_wf[i];
     decode_window<Real>(plan, w, xy, wf, inv_sqrt2, &win, &v0, &v1, &v2, multi);
+    // stage 0 of a window whose level has resolved tables (every level k_scan covers): walk from them
+    int s0_mode = 0, s0_pitch = 0;
+    float s0_inv = 0.f;
+    const S0Node* s0_tbl = nullptr;
+    if (!MULTI && s0_table != nullptr && t_begin == 0) {
+      const bool hit = lane < plan->n_levels && plan->lv[lane].win == win;
+      const unsigned long long mh = __ballot(hit);
+      if (mh) {
+        const DevLevel lv = plan->lv[__ffsll((long long)mh) - 1];
+        if (lv.tiled) { s0_mode = lv.tiled; s0_pitch = lv.pitch; s0_inv = 1.0f / (float)lv.pitch; s0_tbl = s0_table + lv.s0_table; }
+      }
+    }
+    const uint8_t* wbase = v0.img + (size_t)v0.oy * v0.w + v0.ox;
     __syncthreads();                       // previous window's readers are done with sh
     {
       const Real* src = from_scan ? m.mean_shape : w.m_shape + (size_t)i * dim;
@@ -1231,7 +1287,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        walk_carts<DL, kG, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        else walk_carts<DL, kG, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
         for (int g = 0; g < kG; g++) {
           const int k = k0 + g * 64 + lane;
@@ -1259,7 +1316,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        walk_carts<DL, 2, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        else walk_carts<DL, 2, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
         if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)dim;
       }
@@ -1331,7 +1389,8 @@ namespace {
 template <typename DL>
 hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th, typename DL::Real th,
                               const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
-                              const WorkT<typename DL::Real>& w, int groups, long long n_hint, hipStream_t stream) {
+                              const WorkT<typename DL::Real>& w, int groups, long long n_hint, const S0Node* s0_table,
+                              hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
   const bool st = sizeof(Real) == 8 && m.similarity != 0;
@@ -1349,7 +1408,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, t_begin, t_end,
-                       apply_th ? 1 : 0, th);
+                       apply_th ? 1 : 0, th, s0_table);
   };
   // groups = 64-cart groups walked speculatively per round: 1 where most windows are
   // rejected within a few carts (throughput), 4 where most pass (latency)
@@ -1372,14 +1431,14 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
 template <>
 hipError_t launch_finish<float>(bool trace, int t_begin, int t_end, bool apply_final_th, float final_th,
                                 const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
-                                int groups, long long n_hint, hipStream_t stream) {
-  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, stream);
+                                int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream) {
+  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, stream);
 }
 template <>
 hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_final_th, double final_th,
                                  const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
-                                 int groups, long long n_hint, hipStream_t stream) {
-  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, stream);
+                                 int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream) {
+  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, stream);
 }
 
 // =============================================================================

@@ -671,7 +671,7 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1")
+    env = dict(os.environ, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1", JDA_DENSE="1")   # the roofline leg needs the scan
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu", "--no-allpass"]
