@@ -5,16 +5,23 @@
 // IEEE division, denormals kept).
 //
 //   k_resize        bilinear pyramid image        reference c/jda.c:203-230
+//   k_resize_cv     cv::resize(INTER_LINEAR) restated (dialect CPP pyramids, cascador.cpp:302,330-331)
 //   k_prep_stage0   stage-0 feature offsets per level (hoisted c/jda.c:370-389)
 //   k_scan          first `handoff` carts of stage 0: LDS pixel tile, lane = window,
-//                   survivors compacted by ballot/prefix-sum every chunk of carts
-//                                                  reference c/jda.c:357-402
+//                   survivors compacted by ballot/prefix-sum every chunk of carts; late
+//                   phases spread (window, cart) pairs over all lanes and replay the scores
+//                   16 carts at a time in registers      reference c/jda.c:357-402
+//   k_enqueue       windows of levels k_scan does not cover -> hand-off queue at cart 0
 //   k_finish        wave = window, for every survivor: lanes = carts for a stage's
 //                   tree walks (c/jda.c:366-400, cart.cpp:392-404), the score
 //                   recurrence replayed in cart order (c/jda.c:395-399), then
 //                   lanes = shape coordinates for the regression gather in cart
 //                   order (c/jda.c:404-411, btcart.cpp:407-424), final cut
 //                   (c/jda.c:414) and emit
+//   k_stage         dense mode: one whole stage for a 16x16 tile of windows per workgroup,
+//                   lane = window, tables and weight rows of a chunk of carts shared in LDS
+//                   (same references as k_finish)
+//   k_trace_fill    per-window trace defaults (parity instrumentation)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
