@@ -554,6 +554,17 @@ struct Pass {
   const HostModel& hm() const { return c->hm; }
   const DevModelT<Real>& model() const { return Sel<Real>::model(c).m; }
   bool want_trace() const { return trace != nullptr; }
+  // 64-cart groups walked per round by a window that is expected to pass whole stages: the count in
+  // 2..4 that wastes the fewest speculative walks past cart K-1 (K = 540: 3 groups, 576 walks, not 768)
+  int stage_groups() const {
+    const int K = hm().K;
+    int best = 4, best_waste = 1 << 30;
+    for (int g = 4; g >= 2; g--) {
+      const int per = 64 * g, waste = ((K + per - 1) / per) * per - K;
+      if (waste < best_waste) { best = g; best_waste = waste; }
+    }
+    return best;
+  }
   // resolved stage-0 tables for k_finish (A/B switch: JDA_FIN_S0=0)
   const S0Node* s0_tbl() const { return (pe->fast_scan && env_ll("JDA_FIN_S0", 1)) ? pe->table : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
@@ -713,7 +724,7 @@ struct Pass {
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
-      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", 4), n_tail, s0_tbl(), st));
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", stage_groups()), n_tail, s0_tbl(), st));
       finished = true;
       return true;
     }
@@ -728,7 +739,7 @@ struct Pass {
     if (finished) return true;
     JDA_HIP(hipStreamSynchronize(st));
     n_mid = (long long)std::min<unsigned long long>(h_cnt[0], cap);
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", 4), n_mid, nullptr, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), n_mid, nullptr, st));
     finished = true;
     return true;
   }

@@ -1423,6 +1423,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
     constexpr bool TR = decltype(trace_tag)::value, MU = decltype(multi_tag)::value;
     constexpr bool STT = decltype(st_tag)::value && sizeof(Real) == 8;
     if (groups >= 4) go(k_finish<DL, TR, 4, MU, STT>);
+    else if (groups == 3) go(k_finish<DL, TR, 3, MU, STT>);
     else if (groups >= 2) go(k_finish<DL, TR, 2, MU, STT>);
     else go(k_finish<DL, TR, 1, MU, STT>);
   };
