@@ -672,8 +672,10 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1", JDA_DENSE="1")   # the roofline leg needs the scan
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu", "--no-allpass"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -690,11 +692,13 @@ def test_pipelined_gather_device_path_over_rccl_group_of_one(built, gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     code = r'''
 import os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", RANK="0", WORLD_SIZE="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)
@@ -712,6 +716,6 @@ for step, g in enumerate(outs[1:]):
     assert g.shape == (n, 7) and (g[:, 1:] == step + 1).all() and list(g[:, 0]) == list(range(n)), (step, g.shape)
 dist.barrier(); dist.destroy_process_group()
 print("OK")
-''' % root
+''' % (root, port)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
