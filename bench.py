@@ -17,10 +17,12 @@ call jdaDetect(.., 1.25, 0.1, 40, -1, -0.5) (reference c/main.cpp:25), in the
 "cascade" threshold regime (mean reject length ~30 carts, ~0.1 % of windows
 finish).  The all-pass regime is measured as a secondary line in "regimes".
 
-By default one caller issues the K timed steps one batch at a time.  --depth D issues them from D host threads
-with a cascador each (D batches in flight per GPU: the host part of one step and its finishing kernels overlap
-the scans of the others); measured 4.2-5.0e9 windows/s at D = 3 against 4.1e9, but not stable from run to run,
-so it is an option, not the default.
+The K timed steps go through the library's submit/wait entry points (jdaDetectBatchSubmit /
+jdaDetectBatchWait): the scan of step i+1 is queued before step i is collected, so two batches are in flight
+per GPU from ONE host thread and the GPU works while the host parts of a step run.  Every step is a complete
+pass over one batch and all K finish inside the timed region.  --depth 1 uses one synchronous
+jdaDetectBatchDevice call per step instead; that figure is reported next to the headline in "config" and
+"regimes".
 
 Prints ONE JSON line on rank 0.
 """
@@ -111,9 +113,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--dims", type=str, default="5,540,27,4")
-    ap.add_argument("--depth", type=int, default=1,
-                    help="batches in flight per rank: host threads with a cascador each (1 = one caller, the default; "
-                         "3 reaches 4.2-5.0e9 windows/s but the gain is not stable from run to run)")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="batches in flight per rank: 2 = submit/wait pipeline from one host thread (default), "
+                         "1 = one synchronous call per step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
     args = ap.parse_args()
@@ -177,17 +179,12 @@ def main():
                     os.environ[k] = v
 
     def _run_regime(regime, steps, warmup, th, depth):
-        """depth > 1: the K steps are issued by `depth` host threads with a cascador each, so up to `depth` batches
-        are in flight: the host part of one step (sync gaps, D2H, NMS, result assembly) and its texture-addresser
-        bound finishing kernels run next to the scans of the others.  Every step is still one complete pass over
-        one batch, and all K are finished inside the timed region."""
-        import itertools
-        import threading
+        """depth 2: the K steps go through the submit/wait entry points, two batches in flight from this one thread.
+        Every step is still one complete pass over one batch, and all K are finished inside the timed region."""
         mp = model_path(dims, regime, 1, calib)
-        depth = max(1, min(depth, steps))
-        cascs = [api.Cascador(mp, device=local_rank) for _ in range(depth)]
+        depth = max(1, min(depth, 2, steps))
+        cascs = [api.Cascador(mp, device=local_rank)]
         casc = cascs[0]
-        glock = threading.Lock()
 
         # N>1: one RCCL all_gather of fixed-size blocks brings the (bbox, score, landmarks) rows to rank 0.  It is
         # pipelined one step behind: the collective of step i runs on the communicator's stream while step i+1
@@ -202,13 +199,23 @@ def main():
                                                   frame_offset=rank * B)
             rows, st = out if want_stats else (out, None)
             if world > 1:
-                with glock:                      # one communicator: collectives are issued one at a time
-                    gather.start(rows)
+                gather.start(rows)
             return len(rows), st
 
-        for c in cascs:
+        def submit():
+            return casc.submit_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th, nms=True)
+
+        if depth == 1:
             for _ in range(warmup):
-                step(c=c)
+                step()
+        elif warmup > 0:                 # warm up the path that is timed (its lanes hold a whole batch each)
+            ticket = submit()
+            for i in range(warmup):
+                nxt = submit() if i + 1 < warmup else None
+                rows = casc.wait_batch(ticket, keep_results="packed", frame_offset=rank * B)
+                if world > 1:
+                    gather.start(rows)
+                ticket = nxt
         gather.drain()
         barrier()
         t0 = time.perf_counter()
@@ -219,33 +226,18 @@ def main():
                 n_det, st = step(True)
                 stats.append(st)
         else:
-            ticket = itertools.count()
-            slock = threading.Lock()
-            errors = []
-
-            def worker(c):
-                nonlocal n_det
-                try:
-                    torch.cuda.set_device(local_rank)
-                    while True:
-                        with slock:
-                            i = next(ticket)
-                        if i >= steps:
-                            return
-                        n, st = step(True, c)
-                        with slock:
-                            stats.append(st)
-                            n_det = n
-                except Exception as e:       # surfaced after the join
-                    errors.append(e)
-
-            threads = [threading.Thread(target=worker, args=(c,)) for c in cascs]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            if errors:
-                raise errors[0]
+            # two batches in flight from this one thread: the scan of step i+1 is queued before step i is
+            # collected (jdaDetectBatchSubmit / jdaDetectBatchWait), so the GPU works on it while the host parts of
+            # step i run (queue-length reads, D2H, sort, NMS, result assembly, gather)
+            ticket = submit()
+            for i in range(steps):
+                nxt = submit() if i + 1 < steps else None
+                rows, st = casc.wait_batch(ticket, stats=True, keep_results="packed", frame_offset=rank * B)
+                if world > 1:
+                    gather.start(rows)
+                n_det = len(rows)
+                stats.append(st)
+                ticket = nxt
         gather.drain()
         barrier()
         el = time.perf_counter() - t0

@@ -180,6 +180,21 @@ JDA_API int jdaDetectBatchDevice(void *cascador, const unsigned char *d_frames,
                                  float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt, jdaResult *out);
 
+/* Two batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
+ * Submit queues the stage-0 scan of a batch of device-resident frames and returns at once with a
+ * ticket (0 or 1; -1 on error: both tickets in use, the workspace would have to grow while the other
+ * batch is pending, multi-scale model); Wait walks that batch through the rest of the pipeline,
+ * post-processes it and fills out[0..n) exactly like jdaDetectBatchDevice.  Submitting batch i+1
+ * before waiting for batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i
+ * (queue-length reads, D2H, sort, NMS, result assembly) run.  The frames must stay valid until Wait
+ * returns; the other entry points refuse to run while a ticket is pending.  opt->stats is ignored by
+ * Submit; Wait takes the stats pointer (gpu_ms = that batch's own device span, call_ms = submit to
+ * the end of wait). */
+JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, size_t frame_stride, int n,
+                                 int width, int height, float scale, float step, int min_size, int max_size,
+                                 float th, const jdaDetectOptions *opt);
+JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaResult *out);
+
 /* Per-window trace of the cascade (parity instrumentation; HOST output
  * arrays of n*windows_per_frame entries in scan order, any may be NULL):
  *   carts_n    number of carts evaluated, counted like `n` in the reference's

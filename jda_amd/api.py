@@ -97,6 +97,9 @@ def _load():
     lib.jdaDetectBatchDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
                                          C.POINTER(jdaResult)]
+    lib.jdaDetectBatchSubmit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions)]
+    lib.jdaDetectBatchWait.argtypes = [C.c_void_p, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResult)]
     lib.jdaTraceBatch.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                   C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint), C.POINTER(C.c_float)]
     lib.jdaBuildPyramid.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -289,6 +292,42 @@ class Cascador:
             raise JdaError(last_error())
         if keep_results == "packed":
             # one C call: rows [frame, x, y, size, score, shape...] of every detection of the batch
+            rows = lib.jdaResultsPack(res, n, frame_offset, None, 0)
+            out = np.empty((max(rows, 0), 5 + self.dim), np.float32)
+            if rows > 0:
+                lib.jdaResultsPack(res, n, frame_offset, out.ctypes.data_as(C.POINTER(C.c_float)), rows)
+            lib.jdaResultsRelease(res, n)
+        elif keep_results:
+            out = [_take(res[i]) for i in range(n)]
+        else:
+            out = [res[i].n for i in range(n)]
+            lib.jdaResultsRelease(res, n)
+        return (out, st.asdict()) if stats else out
+
+    # -- two batches in flight from one thread -----------------------------------
+    def submit_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True):
+        """Queues the scan of a batch and returns a ticket; collect it with wait_batch (the frames are kept
+        alive until then).  Submit batch i+1 before waiting for batch i to overlap host and device work."""
+        assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
+        n, h, w = d_frames.shape
+        o, _ = self._opts(nms, False)
+        t = lib.jdaDetectBatchSubmit(self.h, C.c_void_p(d_frames.data_ptr()), h * w, n, w, h, scale, 0.1,
+                                     min_size, max_size, th, C.byref(o))
+        if t < 0:
+            raise JdaError(last_error())
+        if not hasattr(self, "_pending"):
+            self._pending = {}
+        self._pending[t] = (d_frames, n)
+        return t
+
+    def wait_batch(self, ticket, stats=False, keep_results=True, frame_offset=0):
+        d_frames, n = self._pending.pop(ticket)
+        res = (jdaResult * max(n, 1))()
+        st = jdaStats() if stats else None
+        rc = lib.jdaDetectBatchWait(self.h, ticket, C.byref(st) if stats else None, res)
+        if rc != 0:
+            raise JdaError(last_error())
+        if keep_results == "packed":
             rows = lib.jdaResultsPack(res, n, frame_offset, None, 0)
             out = np.empty((max(rows, 0), 5 + self.dim), np.float32)
             if rows > 0:

@@ -129,6 +129,8 @@ struct Workspace {
   int lanes = 0;
 };
 
+struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
+
 struct Cascador {
   HostModel hm;
   std::mutex mu;
@@ -149,6 +151,7 @@ struct Cascador {
   Workspace<float> wf;
   Workspace<double> wd;
   unsigned long long* h_counters = nullptr;  // pinned
+  PendingBatch* pending = nullptr;           // [kLanes], allocated by the first submit
   // host frames whose H2D copies run_device issues per sub-batch (set by stage_frames(.., defer), consumed
   // by the next run_device): the copies of one sub-batch then overlap the kernels of the other lane
   const unsigned char* const* pending_host = nullptr;
@@ -815,6 +818,19 @@ struct Pass {
   }
 };
 
+struct PendingBatch {
+  bool active = false;
+  Pass<float> pass;
+  RawDets<float> dets;
+  RunStats rs;
+  PlanEntry* pe = nullptr;
+  ScanPlan sp;
+  int n = 0;
+  bool opt_set = false;
+  jdaDetectOptions opt{};
+  double t_submit = 0;
+};
+
 // Runs the device pipeline over n frames resident in device memory.  Large batches are split
 // into sub-batches that alternate between two lanes (streams with their own workspace), see Pass.
 template <typename Real>
@@ -831,6 +847,8 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   const size_t host_fbytes = c->pending_fbytes;
   c->pending_host = nullptr; c->pending_fbytes = 0;
   if (host_frames && d_frames != (const uint8_t*)Sel<Real>::ws(c).frames.p) host_frames = nullptr;   // stale: not this call's staging
+  for (int i = 0; c->pending && i < kLanes; i++)
+    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return false; }
   if (n == 0) return true;
   if (wpf == 0) {     // nothing to scan; still honour the staging contract
     if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(d_frames), stride, host_frames, n, host_fbytes, c->stream[0])) return false;
@@ -1082,31 +1100,12 @@ static jdaResult empty_result(int landmark_n) {
   return r;
 }
 
-// dialect C batch on device-resident frames -> per-frame jdaResult
-static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
-                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
-                           jdaResult* out) {
-  const double t_call = now_ms();
-  // caller holds c->mu
-  if (!c || !out || n < 0) { fail("bad arguments"); return -1; }
-  const int L = c->hm.L, dim = c->hm.dim();
-  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
-  ScanPlan sp;
-  std::string err;
-  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
-  if (stride < (size_t)width * height) { fail("frame_stride smaller than a frame"); return -1; }
-  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
-  unsigned sb; std::memcpy(&sb, &scale, 4);
-  PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
-  PlanEntry* pe = nullptr;
-  if (!get_plan(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
-  RawDets<float> dets;
-  RunStats rs;
-  PostPool::get().prewake(n, env_ll("JDA_POST_PREWAKE_MS", 0));   // per-frame NMS + assembly follows the GPU work
-  if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
-    return -1;
-
+// NMS, relocation and the jdaResult of every frame of a dialect-C batch from its raw detections
+// (sorted by gid = frame, then scan order).  Returns the time it took (ms).
+static double post_c(Cascador* c, const ScanPlan& sp, const RawDets<float>& dets, int n, const jdaDetectOptions* opt,
+                     jdaResult* out) {
   const double t0 = now_ms();
+  const int L = c->hm.L, dim = c->hm.dim();
   const bool do_nms = !opt || opt->nms;
   const float overlap = opt ? opt->nms_overlap : 0.3f;
   // split by frame (dets are sorted by gid)
@@ -1143,8 +1142,107 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
   }, dets.gid.size() < 20000);
-  fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
+  return now_ms() - t0;
+}
+
+// Validation + plan of a dialect-C call (shared by the synchronous and the submit/wait entries).
+static bool plan_c_call(Cascador* c, size_t stride, int width, int height, float scale, int min_size, int max_size,
+                        ScanPlan* sp, PlanEntry** pe) {
+  std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, sp, &err)) { fail(err); return false; }
+  if (stride < (size_t)width * height) { fail("frame_stride smaller than a frame"); return false; }
+  if (!ensure_device(c) || !upload_model<float>(c)) return false;
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
+  return get_plan(c, key, *sp, JDA_DIALECT_C, pe);
+}
+
+// dialect C batch on device-resident frames -> per-frame jdaResult
+static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
+                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
+                           jdaResult* out) {
+  const double t_call = now_ms();
+  // caller holds c->mu
+  if (!c || !out || n < 0) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L;
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  for (int i = 0; c->pending && i < kLanes; i++)
+    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return -1; }
+  ScanPlan sp;
+  PlanEntry* pe = nullptr;
+  if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &sp, &pe)) return -1;
+  RawDets<float> dets;
+  RunStats rs;
+  PostPool::get().prewake(n, env_ll("JDA_POST_PREWAKE_MS", 0));   // per-frame NMS + assembly follows the GPU work
+  if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
+    return -1;
+  const double post_ms = post_c(c, sp, dets, n, opt, out);
+  fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, c->hm.K, post_ms);
   if (opt && opt->stats) opt->stats->call_ms = now_ms() - t_call;
+  return 0;
+}
+
+// ---- submit / wait: two batches in flight on one cascador, driven by one host thread ----
+// Submit queues the scan of a batch (no host wait) on a free lane; Wait walks that batch through the
+// rest of the pipeline and post-processes it.  A caller that submits batch i+1 before it waits for
+// batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i run.
+static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
+                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt) {
+  if (!c || n <= 0 || !d_frames) { fail("bad arguments"); return -1; }
+  if (c->hm.multi_scale()) { fail("submit/wait supports models whose split nodes read the original image only"); return -1; }
+  if (!c->pending) c->pending = new PendingBatch[kLanes];
+  int slot = -1;
+  for (int i = 0; i < kLanes; i++) if (!c->pending[i].active) { slot = i; break; }
+  if (slot < 0) { fail("both submit slots are in use: wait for a batch first"); return -1; }
+  PendingBatch& pb = c->pending[slot];
+  pb = PendingBatch();
+  if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &pb.sp, &pb.pe)) return -1;
+  const long long wpf = pb.sp.windows;
+  if (wpf <= 0) { fail("no candidate window in these frames"); return -1; }
+  if ((long long)n * wpf > 0x7fffffffLL || n > 65535) { fail("batch too large for one submit: split it"); return -1; }
+  const size_t cap = (size_t)n * (size_t)wpf;
+  bool other_active = false;
+  for (int i = 0; i < kLanes; i++) other_active = other_active || (i != slot && c->pending[i].active);
+  Workspace<float>& ws = c->wf;
+  const bool fits = ws.cap >= cap && ws.dim == c->hm.dim() && ws.lanes >= kLanes;
+  if (!fits) {
+    if (other_active) { fail("the workspace must grow for this batch while another one is pending: wait for it first"); return -1; }
+    if (!ensure_workspace<float>(c, cap, false, kLanes)) return -1;
+  }
+  if (!ensure_lane(c, slot)) return -1;
+  pb.n = n; pb.opt_set = opt != nullptr; if (opt) pb.opt = *opt;
+  pb.opt.stats = nullptr;
+  pb.t_submit = now_ms();
+  Pass<float>& p = pb.pass;
+  p.c = c; p.pe = pb.pe; p.trace = nullptr; p.dets = &pb.dets; p.rs = &pb.rs; p.apply_th = true; p.th = th; p.multi = false;
+  p.lane = slot; p.solo = true; p.st = c->stream[slot]; p.ev = c->ev[slot];
+  p.h_cnt = c->h_counters + (size_t)slot * kCntShards * kCntStride;
+  p.w = ws.w[slot]; p.cap = ws.cap;
+  p.f0 = 0; p.nf = n;
+  p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
+  p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
+  p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+  if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) return -1;
+  pb.active = true;
+  return slot;
+}
+
+static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
+  if (!c || slot < 0 || slot >= kLanes || !out || !c->pending || !c->pending[slot].active) { fail("no pending batch in this slot"); return -1; }
+  PendingBatch& pb = c->pending[slot];
+  const int L = c->hm.L, n = pb.n;
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  Pass<float>& p = pb.pass;
+  p.dets = &pb.dets; p.rs = &pb.rs;              // (the PendingBatch may have moved since submit: re-point)
+  pb.active = false;
+  if (!p.after_tail() || !p.after_mid() || !p.issue_counters() || !p.after_counters() || !p.collect()) return -1;
+  float ms_scan = 0, ms_all = 0;
+  (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+  (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+  pb.rs.scan_ms += ms_scan; pb.rs.gpu_ms += ms_all;
+  const double post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
+  fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
+  if (stats) stats->call_ms = now_ms() - pb.t_submit;
   return 0;
 }
 
@@ -1219,6 +1317,7 @@ void jdaCascadorRelease(void* cascador) {
     for (auto& st : c->side) if (st) (void)hipStreamDestroy(st);
     for (auto& l : c->ev_side) for (auto& ev : l) if (ev) (void)hipEventDestroy(ev);
   }
+  delete[] c->pending;
   delete c;
 }
 
@@ -1276,6 +1375,27 @@ int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t f
   std::lock_guard<std::mutex> lock(((Cascador*)cascador)->mu);
   ((Cascador*)cascador)->pending_host = nullptr;      // frames are already on the device
   return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatchSubmit(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
+                         int width, int height, float scale, float step, int min_size, int max_size,
+                         float th, const jdaDetectOptions* opt) {
+  (void)step;
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmit runs dialect C"); return -1; }
+  if (!cascador) { fail("null cascador"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->pending_host = nullptr;
+  return submit_c_device(c, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt);
+}
+
+int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* out) {
+  g_err.clear();
+  if (!cascador) { fail("null cascador"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  std::lock_guard<std::mutex> lock(c->mu);
+  return wait_c_device(c, ticket, stats, out);
 }
 
 int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,

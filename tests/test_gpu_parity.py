@@ -719,3 +719,59 @@ print("OK")
 ''' % (root, port)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------- submit / wait
+
+def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
+    """jdaDetectBatchSubmit / jdaDetectBatchWait: two batches in flight from one thread, any collection order,
+    same detections and counters as jdaDetectBatchDevice."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=101, cart_th=-0.9, norm_every=9)
+    fa = torch.from_numpy(synth.make_frames(5, 240, 180, seed=102)).cuda()
+    fb = torch.from_numpy(synth.make_frames(3, 240, 180, seed=103)).cuda()
+    fc = torch.from_numpy(synth.make_frames(2, 131, 97, seed=104)).cuda()       # another plan, smaller workspace need
+    c = api.Cascador(p)
+    want = {}
+    for name, f in (("a", fa), ("b", fb), ("c", fc)):
+        want[name] = c.detect_batch_device(f, stats=True)
+    def check(got, name):
+        res, st = got
+        for x, y in zip(res, want[name][0]):
+            _compare_detect(x, y)
+        for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n", "handoff_n"):
+            assert st[k] == want[name][1][k], (name, k)
+    ta = c.submit_batch_device(fa)
+    tb = c.submit_batch_device(fb)
+    assert {ta, tb} == {0, 1}
+    with pytest.raises(api.JdaError):                       # both tickets in use
+        c.submit_batch_device(fc)
+    with pytest.raises(api.JdaError):                       # synchronous entries refuse while a ticket is pending
+        c.detect_batch_device(fa)
+    check(c.wait_batch(tb, stats=True), "b")                # collected out of order
+    tc = c.submit_batch_device(fc)
+    check(c.wait_batch(ta, stats=True), "a")
+    check(c.wait_batch(tc, stats=True), "c")
+    assert api.lib.jdaDetectBatchWait(c.h, 0, None, (api.jdaResult * 1)()) != 0      # nothing pending in that slot any more
+    # a stream of batches, one ahead
+    t = c.submit_batch_device(fa)
+    for i in range(4):
+        nxt = c.submit_batch_device(fb if i % 2 == 0 else fa) if i < 3 else None
+        check(c.wait_batch(t, stats=True), "a" if i % 2 == 0 else "b")
+        t = nxt
+    check(c.detect_batch_device(fa, stats=True), "a")      # and the synchronous path works again afterwards
+
+
+def test_submit_wait_all_pass_model_takes_the_dense_path(built, gpu, model_file):
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((2, 40, 5, 4), 8, seed=105)
+    f = torch.from_numpy(synth.make_frames(40, 200, 150, seed=106)).cuda()
+    c = api.Cascador(p)
+    want, sw = c.detect_batch_device(f, stats=True)
+    t = c.submit_batch_device(f)
+    got, sg = c.wait_batch(t, stats=True)
+    for a, b in zip(got, want):
+        _compare_detect(a, b)
+    assert sg["cart_total_n"] == sw["cart_total_n"] and sg["dense_passes"] >= 1
