@@ -33,6 +33,7 @@ REF_DIMS = [
     (1, 4, 3, 2),
     (3, 70, 9, 5),
     (2, 64, 68, 6),    # config-5-like: 68 landmarks, depth 6 (small K)
+    (7, 2000, 68, 6),  # BASELINE.json configs[4] (SURVEY "X"): NODE=31, LEAF=32, W = 243.7 MB
 ]
 
 CFLAGS = ["-std=c99", "-O2", "-fPIC", "-shared", "-w"]

@@ -87,3 +87,19 @@ def test_product_never_touches_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
     deps = subprocess.run(["readelf", "-d", os.path.join(pkg, "libjda.so")], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+def test_cmake_target_builds_the_same_library(tmp_path):
+    """CMakeLists.txt (shape of reference c/CMakeLists.txt:19-22): one shared library exporting c/jda.h
+    plus the demo driver, built without Python."""
+    import shutil
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("cmake or hipcc not available")
+    b = str(tmp_path / "b")
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    subprocess.check_call(["cmake", "-S", ROOT, "-B", b] + gen, stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", b, "-j", "8"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(b, "libjda.so"))
+    for n in declared_symbols():
+        assert hasattr(lib, n), n
+    assert os.path.exists(os.path.join(b, "jda-test"))

@@ -244,6 +244,109 @@ def test_1080p_eight_levels(built, gpu, model_file):
         _compare_detect(dets[i], o.detect(frames[i], scale=1.5))
 
 
+def test_config2_1080p_batch_shipped_dims(built, gpu, tmp_path):
+    """BASELINE.json configs[2] with the shipped model dimensions: a 32-frame 1080p batch (66 MB of
+    frames), 8 window sizes (scale 1.5), S dims in the calibrated cascade regime.  Properties at full
+    size (window accounting, determinism, batch == single-frame call == host-frame entry) and the
+    oracle + the compiled reference on sampled frames (c/jda.c:318-480)."""
+    import torch
+    from jda_amd import api, synth
+    from oracle import pyoracle
+    frames = synth.make_frames(32, 1920, 1080, seed=0)
+    m = synth.make_model(*S_DIMS, seed=1)
+    synth.calibrate_thresholds(m, frames[:4], scale=1.5)
+    p = str(tmp_path / "cfg2.model"); m.save(p, 8)
+    c = api.Cascador(p)
+    d_frames = torch.from_numpy(frames).to(gpu)
+    kw = dict(scale=1.5)
+    res1, st1 = c.detect_batch_device(d_frames, stats=True, **kw)
+    res2, st2 = c.detect_batch_device(d_frames, stats=True, **kw)
+    assert st1["patch_n"] == 32 * 125350                                   # SURVEY.md 8d config 3
+    for k in ("cart_gothrough_n", "cart_total_n", "face_patch_n", "stage_done_n", "scan_cart_n", "scan_patch_n"):
+        assert st1[k] == st2[k], k
+    for a, b in zip(res1, res2):
+        _compare_detect(a, b)
+    assert 10 < st1["average_cart_n"] < 60
+    assert sum(len(r["scores"]) for r in res1) > 0
+    host = c.detect_batch(frames[:3], **kw)
+    for i in range(3):
+        _compare_detect(res1[i], host[i])
+    _compare_detect(res1[5], c.detect(frames[5], 1.5, 0.1, 40, -1, -0.5))
+    o = pyoracle.Oracle(p)
+    ref = pyoracle.Reference(p, S_DIMS, 8) if pyoracle.reference_lib_path(*S_DIMS) else None
+    for i in (0, 31):
+        _compare_detect(res1[i], o.detect(frames[i], **kw))
+        if ref is not None:
+            _compare_detect(res1[i], ref.detect(frames[i], **kw))
+    # carts evaluated over two frames equal the oracle's per-window sum; every window traced
+    sub = [7, 20]
+    _, st = c.detect_batch(frames[sub], stats=True, **kw)
+    trs = [o.trace(frames[i], want_shapes=False, **kw) for i in sub]
+    assert st["cart_total_n"] == sum(int(t["carts_n"].sum()) for t in trs)
+    _compare_trace(c, o, frames[7:8], **kw)
+
+
+X_DIMS = (7, 2000, 68, 6)
+
+
+@pytest.fixture(scope="module")
+def x_model(tmp_path_factory):
+    """BASELINE.json configs[4]: T=7, K=2000, 68 landmarks, depth 6 (NODE=31, LEAF=32; c/jda.c:24-27,130-151)
+    as a float model file (259,560,576 B; W = 243.7 MB).  cart_th=-2: ~1 % of the windows finish all 14,000
+    carts, so k_finish's depth-6 walks and its 34.8 MB-per-stage W gather run for thousands of windows."""
+    from jda_amd import synth
+    p = str(tmp_path_factory.mktemp("x") / "x.model")
+    synth.make_model(*X_DIMS, seed=2, cart_th=-2.0).save(p, 4)
+    assert os.path.getsize(p) == 259560576                                 # SURVEY.md a-8
+    return p
+
+
+def test_config4_deep_model_small_frame(built, gpu, x_model):
+    """configs[4] model on 320x240: every window's trace and the detections vs the oracle and the reference."""
+    from jda_amd import api, synth
+    from oracle import pyoracle
+    c, o = api.Cascador(x_model, "float"), pyoracle.Oracle(x_model)
+    assert (c.T, c.K, c.L, c.D) == X_DIMS
+    frames = synth.make_frames(2, 320, 240, seed=3)
+    _compare_trace(c, o, frames)
+    dets = c.detect_batch(frames)
+    ref = pyoracle.Reference(x_model, X_DIMS, 4) if pyoracle.reference_lib_path(*X_DIMS) else None
+    for i in range(2):
+        _compare_detect(dets[i], o.detect(frames[i]))
+        if ref is not None:
+            _compare_detect(dets[i], ref.detect(frames[i]))
+    assert sum(len(d["scores"]) for d in dets) > 0
+
+
+def test_config4_deep_model_1080p(built, gpu, x_model):
+    """configs[4] at its stated shape: one 1080p frame, canonical call (303,222 windows / 15 sizes).  Window by
+    window vs the oracle (reject position, score bits, leaf-path hash, shape bits) in a regime where a few
+    thousand windows finish every stage; detections vs the compiled reference; counters of a 2-frame batch."""
+    import torch
+    from jda_amd import api, synth
+    from oracle import pyoracle
+    c, o = api.Cascador(x_model, "float"), pyoracle.Oracle(x_model)
+    frames = synth.make_frames(2, 1920, 1080, seed=4)
+    assert api.count_windows(1920, 1080, 1.25, 40, -1) == (303222, 15)
+    g = c.trace(frames[:1])
+    r = o.trace(frames[0])
+    for k in ("carts_n", "score", "path_hash", "shapes"):
+        assert same(r[k], g[k]), (k, int((bits(r[k]) != bits(g[k])).sum()))
+    finished = int((r["carts_n"] == 14000).sum())
+    assert finished > 300                                                  # the W gather is exercised
+    res, st = c.detect_batch_device(torch.from_numpy(frames).to(gpu), stats=True)
+    assert st["patch_n"] == 2 * 303222
+    assert st["stage_done_n"][6] >= finished
+    one, st1 = c.detect_batch(frames[:1], stats=True)
+    assert st1["cart_total_n"] == int(r["carts_n"].sum())
+    assert st1["stage_done_n"][6] == finished
+    _compare_detect(one[0], res[0])
+    _compare_detect(res[0], o.detect(frames[0]))
+    if pyoracle.reference_lib_path(*X_DIMS):
+        ref = pyoracle.Reference(x_model, X_DIMS, 4)
+        _compare_detect(res[0], ref.detect(frames[0]))
+
+
 def test_concurrent_callers_share_one_cascador(built, gpu, model_file):
     """jdaDetect is re-entrant in the reference (no globals); ours serialises internally."""
     from concurrent.futures import ThreadPoolExecutor
