@@ -10,14 +10,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjda.so")
-SOURCES = ["kernels.hip", "detect.cpp", "model.cpp", "plan.cpp", "post.cpp"]
-HEADERS = ["kernels.h", "model.h", "plan.h", "post.h", os.path.join("..", "..", "include", "jda.h")]
+SOURCES = ["k_misc.hip", "k_scan.hip", "k_finish.hip", "k_stage.hip", "detect.cpp", "model.cpp", "plan.cpp", "post.cpp"]
+HEADERS = ["kernels.h", "kernels_common.h", "model.h", "plan.h", "post.h", os.path.join("..", "..", "include", "jda.h")]
+OBJDIR = os.path.join(HERE, "build")
 
 # -ffp-contract=off: the cascade must round like the reference's scalar code
 # (an FMA changes tree paths); denormals are kept; division is IEEE.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-gpu-flush-denormals-to-zero", "-fvisibility=hidden", "-DJDA_EXPORTS",
-         "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+          "-fno-gpu-flush-denormals-to-zero", "-fvisibility=hidden", "-DJDA_EXPORTS",
+          "-Wall", "-Wno-unused-function"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
 
 
 def hipcc():
@@ -27,29 +29,55 @@ def hipcc():
     return "hipcc"
 
 
-def stale():
-    if not os.path.exists(LIB):
+def _deps_mtime():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
+
+
+def stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _build(lib, objdir, extra, force=False, verbose=False):
+    """One object per translation unit, compiled in parallel (only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = _deps_mtime()
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".", "_") + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc()] + CFLAGS + extra + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compile failed: %s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+        if r.stderr.strip() and verbose:
+            print(r.stderr[-4000:])
+    with ThreadPoolExecutor(max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc()] + LDFLAGS + ["-o", lib] + objs)
+    return lib
+
+
 def build_timing():
     """Investigation build with shader-clock stamps in k_scan (tools/scan_timing.py); never the product."""
-    out = os.path.join(HERE, "libjda_timing.so")
-    subprocess.check_call([hipcc()] + FLAGS + ["-DJDA_SCAN_TIMING", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES])
-    return out
+    return _build(os.path.join(HERE, "libjda_timing.so"), OBJDIR + "_timing", ["-DJDA_SCAN_TIMING"])
 
 
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _build(LIB, OBJDIR, [], force, verbose)
 
 
 if __name__ == "__main__":

@@ -65,12 +65,20 @@ static long long env_ll(const char* name, long long dflt) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  // Grow-only.  On failure the buffer is EMPTY (p == nullptr, bytes == 0): callers that carved
+  // pointers out of the old allocation must drop them (ensure_workspace does).
   bool reserve(size_t n) {
     if (n <= bytes) return true;
     if (p) (void)hipFree(p);
     p = nullptr; bytes = 0;
-    JDA_HIP(hipMalloc(&p, n));
-    bytes = n;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();            // clear the sticky out-of-memory error: a smaller request may follow
+      fail("hipMalloc(" + std::to_string(n) + " bytes) failed: " + hipGetErrorString(e));
+      return false;
+    }
+    p = q; bytes = n;
     return true;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -224,7 +232,7 @@ static bool upload_model(Cascador* c) {
   const size_t carts = (size_t)h.carts();
   const int node_n = h.node_n(), leaf_n = h.leaf_n(), dim = h.dim();
   std::vector<Node> nodes(carts * node_n);
-  // stage-0 similarity transform, reference data.cpp:64-114 (see stp_calc in kernels.hip for the
+  // stage-0 similarity transform, reference data.cpp:64-114 (see stp_calc in k_finish.hip for the
   // restated OpenCV details); identity when off
   double stp0[5] = {1., 1., 0., 0., 1.};
   if (sizeof(Real) == 8 && c->similarity) {
@@ -483,7 +491,13 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
   for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);   // nothing may still use the old carving
   Carver sz(nullptr);
   carve(sz);
-  if (!ws.buf.reserve(sz.off + 256)) return false;
+  if (!ws.buf.reserve(sz.off + 256)) {
+    // the old allocation is gone: forget every pointer carved out of it, so that a later, smaller
+    // request carves afresh instead of passing the `ws.cap >= cap` test on dangling pointers
+    ws.cap = 0; ws.lanes = 0; ws.trace = false;
+    for (auto& w : ws.w) w = WorkT<Real>{};
+    return false;
+  }
   Carver cv(ws.buf.p);
   carve(cv);
   for (int l = 0; l < lanes; l++) ws.w[l].cap = (unsigned)cap;
@@ -831,6 +845,13 @@ struct PendingBatch {
   double t_submit = 0;
 };
 
+// test hook: JDA_TEST_WPF_SCALE pretends every frame has that many times more windows (the gid-overflow guard
+// is otherwise only reachable with thousands of 4K frames)
+static bool jda_gid_overflow(long long n, long long wpf) {
+  const long long scale = std::max<long long>(1, env_ll("JDA_TEST_WPF_SCALE", 1));
+  return (double)n * (double)wpf * (double)scale > 4294967295.0;
+}
+
 // Runs the device pipeline over n frames resident in device memory.  Large batches are split
 // into sub-batches that alternate between two lanes (streams with their own workspace), see Pass.
 template <typename Real>
@@ -876,6 +897,13 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
   fpp = std::min<long long>(fpp, 65535);                       // the queues pack the frame index in 16 bits
   if (fpp < 1) { fail("frame too large for 32-bit window ids"); return false; }
+  // detections carry a 32-bit gid over the WHOLE batch (frame * windows-per-frame + scan index): the
+  // frame split in the post-processing divides by windows-per-frame, so a wrapped gid would land in
+  // the wrong frame silently
+  if (jda_gid_overflow(n, wpf)) {
+    fail("batch too large: frames x windows per frame exceeds 2^32 window ids -- split the batch");
+    return false;
+  }
   const size_t cap = (size_t)fpp * (size_t)wpf;
   if (!ensure_workspace<Real>(c, cap, want_trace, lanes)) return false;
   Workspace<Real>& ws = Sel<Real>::ws(c);
@@ -1222,6 +1250,12 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
   p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
   p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+  // opt->hip_stream: the stream the caller produced the frames on -- the scan is ordered behind the work
+  // already queued there (the batch itself still runs on the lane's own stream)
+  if (opt && opt->hip_stream) {
+    if (hipEventRecord(c->ev_user, (hipStream_t)opt->hip_stream) != hipSuccess ||
+        hipStreamWaitEvent(p.st, c->ev_user, 0) != hipSuccess) { fail("cannot order the batch behind opt->hip_stream"); return -1; }
+  }
   if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) return -1;
   pb.active = true;
   return slot;
@@ -1230,6 +1264,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
 static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
   if (!c || slot < 0 || slot >= kLanes || !out || !c->pending || !c->pending[slot].active) { fail("no pending batch in this slot"); return -1; }
   PendingBatch& pb = c->pending[slot];
+  if (!ensure_device(c)) return -1;           // the waiting thread's current device may differ (multi-GPU process)
   const int L = c->hm.L, n = pb.n;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   Pass<float>& p = pb.pass;

@@ -1,0 +1,220 @@
+// HIP kernels of the JDA detect path for gfx950 (MI355X, wave64): pyramid images, stage-0 offset tables,
+// queue fill, trace defaults.
+//   k_resize        bilinear pyramid image        reference c/jda.c:203-230
+//   k_resize_cv     cv::resize(INTER_LINEAR) restated (dialect CPP pyramids, cascador.cpp:302,330-331)
+//   k_prep_stage0   stage-0 feature offsets per level (hoisted c/jda.c:370-389)
+//   k_enqueue       windows of levels k_scan does not cover -> hand-off queue at cart 0
+//   k_trace_fill    per-window trace defaults (parity instrumentation)
+#include "kernels_common.h"
+
+namespace jda {
+
+// =============================================================================
+// pyramid resize
+// =============================================================================
+
+__global__ void k_resize(const uint8_t* __restrict__ src, size_t src_stride, int sw, int sh,
+                         uint8_t* __restrict__ dst, size_t dst_stride, int dw, int dh,
+                         float rx, float ry) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  const int f = blockIdx.z;
+  if (j >= dw || i >= dh) return;
+  const uint8_t* s = src + (size_t)f * src_stride;
+  // c/jda.c:215-226, operation for operation
+  const float fx = rx * (float)j;
+  const float fy = ry * (float)i;
+  const int x = (int)fx;
+  const int y = (int)fy;
+  const float xd = fx - (float)x;
+  const float yd = fy - (float)y;
+  const int idx = y * sw + x;
+  const float a = (float)(int)s[idx], b = (float)(int)s[idx + 1];
+  const float c = (float)(int)s[idx + sw], d = (float)(int)s[idx + sw + 1];
+  const float one_x = 1.f - xd, one_y = 1.f - yd;
+  float v = a * one_x * one_y;
+  v = v + b * xd * one_y;
+  v = v + c * one_x * yd;
+  v = v + d * xd * yd;
+  dst[(size_t)f * dst_stride + (size_t)i * dw + j] = (uint8_t)(int)v;
+}
+
+hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
+                         uint8_t* dst, size_t dst_stride, int dw, int dh, float rx, float ry,
+                         hipStream_t stream) {
+  if (dw <= 0 || dh <= 0 || n <= 0) return hipSuccess;
+  dim3 block(256), grid((dw + 255) / 256, dh, n);
+  hipLaunchKernelGGL(k_resize, grid, block, 0, stream, src, src_stride, sw, sh, dst, dst_stride, dw, dh, rx, ry);
+  return hipGetLastError();
+}
+
+// cv::resize(INTER_LINEAR) for 8-bit single-channel images as dialect CPP uses it for the
+// half/quarter images (cascador.cpp:329-331) and the method-0 pyramid (cascador.cpp:300-303):
+// 11-bit fixed-point bilinear of OpenCV's 2.4/3.x imgwarp.cpp, with its routing of an exact
+// 2x2 down-scale to the box average.  PARITY UNPINNED (no OpenCV here to compare with);
+// bit-exact against the oracle's restatement of the same algorithm.
+__global__ void k_resize_cv(const uint8_t* __restrict__ src, size_t src_stride, int sw, int sh,
+                            uint8_t* __restrict__ dst, size_t dst_stride, int dw, int dh,
+                            double scale_x, double scale_y, int area_fast) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y;
+  const int f = blockIdx.z;
+  if (dx >= dw || dy >= dh) return;
+  const uint8_t* s = src + (size_t)f * src_stride;
+  uint8_t* d = dst + (size_t)f * dst_stride;
+  if (area_fast) {
+    const uint8_t* p = s + (size_t)(2 * dy) * sw + 2 * dx;
+    d[(size_t)dy * dw + dx] = (uint8_t)((p[0] + p[1] + p[sw] + p[sw + 1] + 2) >> 2);
+    return;
+  }
+  float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  const bool edge = sx + 1 >= sw;            // dx >= xmax in OpenCV's loop
+  if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+  float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  auto sat_short = [](float v) { int i = __float2int_rn(v); return i < -32768 ? -32768 : (i > 32767 ? 32767 : i); };
+  const int a0 = sat_short((1.f - fx) * 2048.f), a1 = sat_short(fx * 2048.f);
+  const int b0 = sat_short((1.f - fy) * 2048.f), b1 = sat_short(fy * 2048.f);
+  const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+  const uint8_t* S0 = s + (size_t)y0 * sw;
+  const uint8_t* S1 = s + (size_t)y1 * sw;
+  int r0, r1;
+  if (!edge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
+  else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }
+  d[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
+                            uint8_t* dst, size_t dst_stride, int dw, int dh, hipStream_t stream) {
+  if (dw <= 0 || dh <= 0 || n <= 0) return hipSuccess;
+  const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+  const int area = (fabs(scale_x - 2.) < 2.220446049250313e-16 && fabs(scale_y - 2.) < 2.220446049250313e-16) ? 1 : 0;
+  dim3 block(256), grid((dw + 255) / 256, dh, n);
+  hipLaunchKernelGGL(k_resize_cv, grid, block, 0, stream, src, src_stride, sw, sh, dst, dst_stride, dw, dh,
+                     scale_x, scale_y, area);
+  return hipGetLastError();
+}
+
+// =============================================================================
+// stage-0 offset table
+// =============================================================================
+
+template <typename DL>
+__global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename DL::Node* __restrict__ nodes,
+                              const typename DL::Real* __restrict__ mean_shape, int K, int node_n,
+                              S0Node* __restrict__ table) {
+  const int l = blockIdx.y;
+  const DevLevel lv = plan->lv[l];
+  if (!lv.tiled) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * node_n) return;
+  const typename DL::Node nd = nodes[i];  // stage 0 occupies the first K*node_n nodes
+  const int win = lv.win;
+  int x1 = clamp_win(DL::coord(mean_shape[nd.lm1x2], nd.o1x, win), win);
+  int y1 = clamp_win(DL::coord(mean_shape[nd.lm1x2 + 1], nd.o1y, win), win);
+  int x2 = clamp_win(DL::coord(mean_shape[nd.lm2x2], nd.o2x, win), win);
+  int y2 = clamp_win(DL::coord(mean_shape[nd.lm2x2 + 1], nd.o2y, win), win);
+  // feature is a difference of two bytes: thresholds beyond [-256,255] behave like the ends
+  const int th = nd.th < -256 ? -256 : (nd.th > 255 ? 255 : nd.th);
+  S0Node o;
+  if (lv.tiled == 1) {
+    o.lo = (uint32_t)(y1 * lv.pitch + x1) | ((uint32_t)(y2 * lv.pitch + x2) << 16);
+    o.hi = (uint32_t)th;
+  } else {
+    const unsigned long long v = (unsigned long long)(uint32_t)(y1 * lv.pitch + x1) |
+                                 ((unsigned long long)(uint32_t)(y2 * lv.pitch + x2) << kS0GlobalOffBits) |
+                                 ((unsigned long long)(uint32_t)(th + 256) << (2 * kS0GlobalOffBits));
+    o.lo = (uint32_t)v; o.hi = (uint32_t)(v >> 32);
+  }
+  table[lv.s0_table + i] = o;
+}
+
+hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,
+                              const void* nodes, const void* mean_shape, int K, int node_n,
+                              S0Node* table, hipStream_t stream) {
+  dim3 block(256), grid((K * node_n + 255) / 256, h_plan.n_levels);
+  if (dialect == 0)
+    hipLaunchKernelGGL(k_prep_stage0<DialectC>, grid, block, 0, stream, d_plan, (const NodeF*)nodes,
+                       (const float*)mean_shape, K, node_n, table);
+  else
+    hipLaunchKernelGGL(k_prep_stage0<DialectCPP>, grid, block, 0, stream, d_plan, (const NodeD*)nodes,
+                       (const double*)mean_shape, K, node_n, table);
+  return hipGetLastError();
+}
+
+// =============================================================================
+// windows k_scan does not cover -> head of the hand-off queue (k_start = 0)
+// =============================================================================
+
+template <typename Real>
+__global__ void k_enqueue(const DevPlan* __restrict__ plan, WorkT<Real> w, int per_frame, int all_levels) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)per_frame * w.n_frames;
+  if (idx == 0) w.counters[kCntTail] = (unsigned long long)total;   // k_scan appends behind these
+  if (idx >= total) return;
+  const int frame = (int)(idx / per_frame);
+  int r = (int)(idx - (long long)frame * per_frame);
+  int wid = -1, lvl = 0, rel = 0;
+  for (int i = 0; i < plan->n_levels; i++) {
+    const DevLevel* c = &plan->lv[i];
+    if (!all_levels && c->tiled) continue;
+    const int cnt = c->nx * c->ny;
+    if (wid < 0 && r < cnt) { wid = c->base + r; lvl = i; rel = r; }
+    r -= cnt;
+  }
+  {
+    const DevLevel* c = &plan->lv[lvl];
+    const int iy = rel / c->nx, ix = rel - iy * c->nx;
+    w.q_xy[idx] = (uint32_t)(ix * c->step) | ((uint32_t)(iy * c->step) << 16);
+    w.q_wf[idx] = (uint32_t)c->win | ((uint32_t)frame << 16);
+  }
+  w.q_gid[idx] = (uint32_t)(frame * plan->windows + wid);
+  w.q_score[idx] = (Real)0;
+  w.q_kstart[idx] = 0u;
+  if (w.q_hash) w.q_hash[idx] = kFnvSeed;
+}
+
+template <typename Real>
+hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
+                          const WorkT<Real>& w, hipStream_t stream) {
+  long long per_frame = 0;
+  for (int i = 0; i < h_plan.n_levels; i++)
+    if (all_levels || !h_plan.lv[i].tiled) per_frame += (long long)h_plan.lv[i].nx * h_plan.lv[i].ny;
+  const long long total = per_frame * w.n_frames;
+  if (total == 0) return hipSuccess;
+  dim3 block(256), grid((unsigned)((total + 255) / 256));
+  hipLaunchKernelGGL(k_enqueue<Real>, grid, block, 0, stream, d_plan, w, (int)per_frame, all_levels ? 1 : 0);
+  return hipGetLastError();
+}
+template hipError_t launch_enqueue<float>(const DevPlan*, const DevPlan&, bool, const WorkT<float>&, hipStream_t);
+template hipError_t launch_enqueue<double>(const DevPlan*, const DevPlan&, bool, const WorkT<double>&, hipStream_t);
+
+// =============================================================================
+// trace defaults: every window starts as "0 carts, mean shape"
+// =============================================================================
+
+template <typename Real>
+__global__ void k_trace_fill(DevModelT<Real> m, WorkT<Real> w, unsigned n_windows) {
+  const unsigned long long total = (unsigned long long)n_windows * m.dim;
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (unsigned long long)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % m.dim);
+    w.tr_shape[idx] = m.mean_shape[d];
+  }
+}
+
+template <typename Real>
+hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows, hipStream_t stream) {
+  hipLaunchKernelGGL(k_trace_fill<Real>, dim3(1024), dim3(256), 0, stream, m, w, n_windows);
+  return hipGetLastError();
+}
+template hipError_t launch_trace_fill<float>(const DevModelT<float>&, const WorkT<float>&, unsigned, hipStream_t);
+template hipError_t launch_trace_fill<double>(const DevModelT<double>&, const WorkT<double>&, unsigned, hipStream_t);
+
+
+}  // namespace jda

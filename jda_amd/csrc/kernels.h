@@ -126,7 +126,7 @@ enum Counter : int {
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
-// ---- launchers (kernels.hip) ------------------------------------------------
+// ---- launchers (k_misc.hip, k_scan.hip, k_finish.hip, k_stage.hip) ------------------------------------------------
 
 // Pyramid images of reference c/jda.c:450-457 for n frames.
 hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, int sh,

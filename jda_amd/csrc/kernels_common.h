@@ -1,0 +1,230 @@
+// Device-side helpers shared by the kernel translation units (k_*.hip): numeric dialects, wave
+// primitives, global -> LDS staging (LDS-DMA), per-cart parameter record.
+//
+// Built with -ffp-contract=off -fno-gpu-flush-denormals-to-zero: every fp operation must round
+// exactly like the reference's scalar C/C++ (no FMA, IEEE division, denormals kept).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace jda {
+
+namespace {
+
+constexpr unsigned kFnvSeed = 2166136261u;
+__device__ __forceinline__ unsigned fnv_step(unsigned h, int v) { return (h ^ (unsigned)v) * 16777619u; }
+
+// float/double -> int the way the reference build does it (x86 cvttss2si /
+// cvttsd2si: truncation, and INT_MIN for NaN or out-of-range values; the GPU
+// conversion saturates instead).
+__device__ __forceinline__ int to_int_x86(float v) {
+  const int r = (int)v;
+  return (fabsf(v) < 2147483648.f) ? r : INT_MIN;
+}
+__device__ __forceinline__ int to_int_x86(double v) {
+  const int r = (int)v;
+  return (v > -2147483649.0 && v < 2147483648.0) ? r : INT_MIN;
+}
+
+__device__ __forceinline__ int clamp_win(int v, int win) { return v < 0 ? 0 : (v >= win ? win - 1 : v); }
+
+// ---- numeric dialects ---------------------------------------------------------
+
+struct DialectC {           // reference c/jda.c
+  using Real = float;
+  using Node = NodeF;
+  // c/jda.c:373-381: fp32 add, fp32 multiply by the window side, truncate
+  static __device__ __forceinline__ int coord(float s, float o, int win) {
+    const float v = (s + o) * (float)win;
+    return to_int_x86(v);
+  }
+  // clamp_win(coord(s, o, win), win) in 4 instructions instead of 8 (the walks are VALU bound).
+  // v_cvt_i32_f32 saturates: NaN -> 0, v >= 2^31 -> INT_MAX, v <= -2^31 -> INT_MIN, where x86
+  // gives INT_MIN for all three, which the clamp then turns into 0.  No float below 2^31
+  // converts to INT_MAX (the largest is 2^31 - 128), so INT_MAX marks exactly the positive
+  // overflow; r + 1 wraps it to INT_MIN, and median(r + 1, 1, win) - 1 is the clamped pixel:
+  // NaN -> 0, either overflow -> 0, r < 0 -> 0, r >= win -> win - 1.
+  static __device__ __forceinline__ int pixel(float s, float o, int win) {
+    const float v = (s + o) * (float)win;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    const int r1 = (int)((unsigned)r + 1u);
+    int m;
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(m) : "v"(r1), "v"(win));
+    return m - 1;
+  }
+  // The same for an (x, y) pair, returned 1-BASED (kBias): the caller folds the -1s into its
+  // tile base address.  The add and the multiply are packed (two independent IEEE operations).
+  static constexpr int kBias = 1;
+  static __device__ __forceinline__ void pixel_pair(float sx, float sy, float ox, float oy, int win, int* x, int* y) {
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    const float fw = (float)win;
+    const V2 v = (V2{sx, sy} + V2{ox, oy}) * V2{fw, fw};
+    int rx, ry;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(rx) : "v"(v.x));
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ry) : "v"(v.y));
+    const int rx1 = (int)((unsigned)rx + 1u), ry1 = (int)((unsigned)ry + 1u);
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(*x) : "v"(rx1), "v"(win));
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(*y) : "v"(ry1), "v"(win));
+  }
+};
+
+struct DialectCPP {         // reference src/jda (Validate / CalcFeatureValue)
+  using Real = double;
+  using Node = NodeD;
+  // data.cpp:40-47: fp64, round half away from zero
+  static __device__ __forceinline__ int coord(double s, double o, int win) {
+    const double v = (s + o) * (double)win;
+    return to_int_x86(round(v));
+  }
+  static __device__ __forceinline__ int pixel(double s, double o, int win) { return clamp_win(coord(s, o, win), win); }
+  static constexpr int kBias = 0;
+  static __device__ __forceinline__ void pixel_pair(double sx, double sy, double ox, double oy, int win, int* x, int* y) {
+    *x = clamp_win(coord(sx, ox, win), win); *y = clamp_win(coord(sy, oy, win), win);
+  }
+};
+
+__device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
+
+// value of lane j (wave-uniform j), for any lane mask
+__device__ __forceinline__ int rl(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float rl(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ double rl(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ unsigned long long lanes_below(int lane) {
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+__device__ __forceinline__ unsigned long long* shard_counter(unsigned long long* counters, int idx) {
+  return counters + (size_t)(blockIdx.x % kCntShards) * kCntStride + idx;
+}
+
+
+template <typename Real>
+struct CartPar {          // per-cart parameters as k_scan / k_stage read them from LDS
+  Real th, mean, std;
+  Real norm;              // != 0 where (mean,std) != (0,1)
+};
+
+// global -> LDS copy of n elements by the whole workgroup with all loads of a
+// thread in flight before its first store (one memory latency, not one per element)
+template <typename T, int BLOCK, int UNROLL>
+__device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __restrict__ src, int n, int tid) {
+  for (int i0 = 0; i0 < n; i0 += BLOCK * UNROLL) {
+    T v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i = i0 + u * BLOCK + tid;
+      if (i < n) v[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i = i0 + u * BLOCK + tid;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
+// Stages the pw x ph pixel tile whose origin in the frame is (x0, y0) into LDS at row pitch
+// `pitch` (a multiple of 16).  Returns the x offset of the tile origin inside the LDS rows.
+//  * frame 16-byte aligned (base, stride, width, x0): LDS-DMA -- `global_load_lds_dwordx4` moves
+//    16 bytes per lane straight from the frame into LDS (no VGPR round trip); a wave instruction
+//    fills 1 KiB of consecutive LDS = 64 consecutive chunks of the row-major tile; all of a
+//    wave's loads are in flight together.  The CALLER waits vmcnt(0) before its barrier.
+//  * 4-byte aligned: coalesced dword rows, 8 rows in flight per wave;  * else: byte rows.
+template <int BLOCK>
+__device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* frames, size_t frame_stride,
+                                         const uint8_t* img, int W, int x0, int y0, int pw, int ph, int pitch,
+                                         int tid) {
+  constexpr int NW = BLOCK / 64;
+  const int lane = tid & 63, wv = tid >> 6;
+  if (((W & 15) | (x0 & 15) | (int)(frame_stride & 15) | (int)(((uintptr_t)frames) & 15)) == 0) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const int cpr = pitch >> 4;                          // chunks per tile row
+    const int nchunks = ph * cpr;
+    const int maxcol = ((W - x0) >> 4) - 1;              // last chunk that ends inside the frame row
+    int i = wv * 64 + lane;
+    int row = i / cpr, col = i - row * cpr;
+    const int dr = BLOCK / cpr, dc = BLOCK - dr * cpr;
+    const uint8_t* g0 = img + (size_t)y0 * W + x0;
+    for (int base = wv * 64; base < nchunks; base += BLOCK) {
+      if (i < nchunks) {
+        const uint8_t* g = g0 + (size_t)row * W + (min(col, maxcol) << 4);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(lds_pix + (base << 4)), 16, 0, 0);
+      }
+      i += BLOCK; row += dr; col += dc;
+      if (col >= cpr) { col -= cpr; row++; }
+    }
+    return 0;
+  }
+  const bool al4 = ((W & 3) == 0) && ((frame_stride & 3) == 0) && ((((uintptr_t)frames) & 3) == 0);
+  if (al4) {
+    const int x0a = x0 & ~3, xshift = x0 - x0a;
+    const int ndw = (xshift + pw + 3) >> 2;
+    const int w4 = W >> 2, p4 = pitch >> 2;
+    const uint32_t* g = (const uint32_t*)(img + (size_t)y0 * W + x0a);
+    uint32_t* d = (uint32_t*)lds_pix;
+    for (int c0 = 0; c0 < ndw; c0 += 64) {
+      const int c = c0 + lane;
+      const bool cok = c < ndw;
+      for (int r0 = wv * 8; r0 < ph; r0 += NW * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * w4 + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) d[(r0 + u) * p4 + c] = v[u];
+      }
+    }
+    return xshift;
+  }
+  const uint8_t* g = img + (size_t)y0 * W + x0;
+  for (int c0 = 0; c0 < pw; c0 += 64) {
+    const int c = c0 + lane;
+    const bool cok = c < pw;
+    for (int r0 = wv * 8; r0 < ph; r0 += NW * 8) {
+      uint8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * W + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) lds_pix[(r0 + u) * pitch + c] = v[u];
+    }
+  }
+  return 0;
+}
+
+// global -> LDS by LDS-DMA (16 bytes per lane, no VGPR round trip); falls back to stage_to_lds
+// for sources that are not 16-byte aligned and for the tail.  The caller waits vmcnt(0) + barrier.
+template <int BLOCK>
+__device__ __forceinline__ void dma_to_lds(unsigned char* lds_dst, const void* __restrict__ src, int nbytes, int tid) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const unsigned char* g = (const unsigned char*)src;
+  int done = 0;
+  if ((((uintptr_t)g) & 15) == 0) {
+    const int chunks = nbytes >> 4;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = wv * 64; base < chunks; base += BLOCK) {
+      if (base + lane < chunks)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + ((size_t)(base + lane) << 4)), (lds_ptr_t)(lds_dst + (base << 4)), 16, 0, 0);
+    }
+    done = chunks << 4;
+  }
+  stage_to_lds<unsigned char, BLOCK, 4>(lds_dst + done, g + done, nbytes - done, tid);
+}
+
+}  // namespace
+
+}  // namespace jda
