@@ -270,6 +270,12 @@ JDA_API int jdaNmsC(const int *bboxes, const float *scores, int n, float overlap
 JDA_API int jdaNmsCpp(const int *rects, const double *scores, int n, double overlap, int *picked);
 JDA_API long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes);
 
+/* The tile plan k_scan would use for a dialect-C call (no GPU needed; tests and tools): per pyramid level
+ * 10 ints {win, step, nx, ny, mode, tw, th, pitch, tiles_x, tiles_y}; mode 1/3 = windows share an LDS pixel
+ * tile of tw x th windows, 2 = pixels through L1/L2, 0 = not scanned.  Returns the number of levels. */
+JDA_API int jdaDebugPlanTiles(void *cascador, int width, int height, float scale, int min_size, int max_size,
+                              int *out, int cap_levels);
+
 /* Flattens n per-frame results into rows of (5 + 2*landmark_n) floats:
  * [frame_offset + i, x, y, size, score, shape...] -- the (bbox, score, landmarks)
  * tuple that is gathered across GPUs.  rows may be NULL to query the row count.

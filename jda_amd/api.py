@@ -77,6 +77,8 @@ def _load():
     lib.jdaCascadorCreateFloat.argtypes = [C.c_char_p]
     lib.jdaCascadorCreate.restype = C.c_void_p
     lib.jdaCascadorCreate.argtypes = [C.c_char_p]
+    lib.jdaDebugPlanTiles.restype = C.c_int
+    lib.jdaDebugPlanTiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     lib.jdaCascadorSerializeTo.restype = None
     lib.jdaCascadorSerializeTo.argtypes = [C.c_void_p, C.c_char_p]
     lib.jdaCascadorRelease.restype = None
@@ -339,6 +341,16 @@ class Cascador:
             out = [res[i].n for i in range(n)]
             lib.jdaResultsRelease(res, n)
         return (out, st.asdict()) if stats else out
+
+    def plan_tiles(self, width, height, scale=1.25, min_size=40, max_size=-1):
+        """How k_scan would tile each pyramid level of a dialect-C call (no GPU needed)."""
+        out = np.zeros((64, 10), np.int32)
+        n = lib.jdaDebugPlanTiles(self.h, width, height, scale, min_size, max_size,
+                                  out.ctypes.data_as(C.POINTER(C.c_int)), 64)
+        if n < 0:
+            raise JdaError(last_error())
+        keys = ("win", "step", "nx", "ny", "mode", "tw", "th", "pitch", "tiles_x", "tiles_y")
+        return [dict(zip(keys, (int(v) for v in row))) for row in out[:n]]
 
     # -- parity instrumentation ---------------------------------------------------
     def trace(self, frames, scale=1.25, min_size=40, max_size=-1):

@@ -123,6 +123,7 @@ struct PlanEntry {
   unsigned long long last_use = 0;
 };
 
+constexpr int kDefaultHandoff = 256;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
 constexpr int kLanes = 2;     // sub-batches in flight at once, each on its own stream + workspace
 
 template <typename Real>
@@ -344,45 +345,104 @@ static bool upload_model(Cascador* c) {
 
 // ---------------------------------------------------------------- tiling of levels
 
-// Chooses, per level, whether k_scan covers it and how many windows share one
-// LDS pixel tile (DESIGN.md "LDS tiles").  A 256-thread workgroup shares a tile
-// of up to 512 windows; levels whose tile would not leave room for several
-// workgroups per CU (large windows, few of them) skip the scan and enter
-// k_finish at cart 0.
-static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan, PlanEntry* pe) {
-  static const int opts[][2] = {{32, 16}, {16, 16}};
-  const int budget = (int)env_ll("JDA_PIX_MAX", 48 * 1024);     // hard cap of a pixel tile
-  const int pref = (int)env_ll("JDA_PIX_PREF", 24 * 1024);      // prefer the biggest tile under this
+// Chooses, per level, how k_scan covers it (DESIGN.md "LDS tiles"): the tile of windows (tw x th, at most
+// 512) that share one LDS pixel tile, or the global-pixel mode for windows that do not fit LDS.
+//
+// Candidates are every tile shape whose workgroup fits LDS; each is priced with a small throughput model
+// (CU clocks per frame, constants from the r02 kernel traces) and the cheapest wins:
+//   per workgroup   c_fix + pix_bytes / c_bw + slots * c_win        (table load + barriers, tile load, cart walks)
+//   per CU          divided by min(1, (waves per CU / w_sat)^alpha)  (latency hiding needs resident waves)
+// slots = lanes the tile occupies in phase 0: windows rounded up to whole waves, or to the power of two the
+// pair phases pad to for tiles of few windows.  Tile origins need not be multiples of 16 pixels: the
+// LDS-DMA loader starts at the 16-byte chunk below and the pitch covers the lead-in.
+// JDA_TILES="win:twxth,win:twxth" forces shapes (experiments); JDA_DEBUG_TILES=1 prints the choice.
+struct TileChoice { int mode = 0, tw = 1, th = 1, pitch = 0, pix = 0, lds = 0, block = 256; double cost = 0; };
+
+static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, int real_bytes, int chunk, int cp_max) {
+  static const double c_win = (double)env_ll("JDA_TILE_CWIN", 23), c_bw = (double)env_ll("JDA_TILE_CBW", 32),
+                      c_fix = (double)env_ll("JDA_TILE_CFIX", 1500), w_sat = (double)env_ll("JDA_TILE_WSAT", 20),
+                      alpha = (double)env_ll("JDA_TILE_ALPHA_PCT", 70) / 100.0;
+  const int lds_cu = 160 * 1024;
+  const int lds_max = (int)std::min<long long>(lds_cu, env_ll("JDA_SCAN_LDS_MAX", lds_cu));
+  int force_tw = 0, force_th = 0;
+  if (const char* e = std::getenv("JDA_TILES")) {
+    for (const char* p = e; p && *p;) {
+      int w = 0, a = 0, b = 0;
+      if (std::sscanf(p, "%d:%dx%d", &w, &a, &b) == 3 && w == s.win) { force_tw = a; force_th = b; }
+      p = std::strchr(p, ',');
+      if (p) p++;
+    }
+  }
+  TileChoice best;
+  const int fixed256 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, true, 256);
+  const int fixed512 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, true, 512);
+  const int tw_hi = std::min(s.nx, 128), th_hi = std::min(s.ny, 128);
+  for (int th = 1; th <= th_hi; th++) {
+    for (int tw = 1; tw <= tw_hi; tw++) {
+      if (force_tw && (tw != force_tw || th != force_th)) continue;
+      const int n_tile = tw * th;
+      if (n_tile > 512) break;
+      // no point in tiles smaller than a pair-phase round unless the level itself is that small
+      if (!force_tw && n_tile < 16 && n_tile < s.nx * s.ny && (long long)s.win * s.win < 64 * 1024) continue;
+      const int tiles_x = (s.nx + tw - 1) / tw, tiles_y = (s.ny + th - 1) / th;
+      const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
+      int xs = 0;
+      for (int tx = 0; tx < tiles_x; tx++) xs = std::max(xs, (tx * tw * s.step) & 15);
+      int pitch = (xs + pw + 15) & ~15;
+      if ((pitch & 127) == 0) pitch += 16;          // keep tile rows off a 32-bank multiple
+      const long long pix = (long long)pitch * ph;
+      const int block = n_tile > 256 ? 512 : 256;
+      const long long lds = (block == 512 ? fixed512 : fixed256) + ((pix + 15) & ~15LL);
+      if (lds > lds_max) break;                      // wider tiles of this height are larger still
+      const long long max_off = (long long)(s.win - 1) * pitch + s.win - 1 + 15;
+      if (max_off >= (1LL << kS0GlobalOffBits)) continue;
+      const int mode = max_off <= 65535 ? 1 : 3;
+      const int wgs = (int)std::min<long long>(lds_cu / lds, 32 / (block / 64));
+      const double waves = (double)wgs * (block / 64);
+      int slots = (n_tile + 63) & ~63;
+      if (n_tile <= cp_max) { slots = 16; while (slots < n_tile) slots *= 2; }
+      const double eff = std::min(1.0, std::pow(waves / w_sat, alpha));
+      const double cost = (double)tiles_x * tiles_y * (c_fix + (double)pix / c_bw + (double)slots * c_win) / eff;
+      if (best.mode == 0 || cost < best.cost) {
+        best.mode = mode; best.tw = tw; best.th = th; best.pitch = pitch; best.pix = (int)pix; best.lds = (int)lds;
+        best.block = block; best.cost = cost;
+      }
+    }
+  }
+  (void)width;
+  return best;
+}
+
+static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan, int real_bytes, PlanEntry* pe) {
   DevPlan& hp = pe->hp;
   hp.n_levels = (int)sp.levels.size();
   hp.width = sp.width; hp.height = sp.height; hp.windows = (int)sp.windows;
   int table = 0;
   pe->any_untiled = false;
+  const int handoff = (int)env_ll("JDA_HANDOFF", kDefaultHandoff);
+  const int chunk = std::min(std::min(hm.K, handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), real_bytes));
+  const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, env_ll("JDA_CP_MAX", 128)));
+  // a level's cost per window in global-pixel mode, in the units of choose_tile (r01: 0.38 ms for 952 k windows)
+  const double glb_per_window = (double)env_ll("JDA_TILE_CGLB", 800);
   for (int i = 0; i < hp.n_levels; i++) {
     const Level& s = sp.levels[i];
     DevLevel& d = hp.lv[i];
     d.win = s.win; d.step = s.step; d.nx = s.nx; d.ny = s.ny; d.base = (int)s.base;
     d.tiled = 0; d.tw = d.th = 1; d.tiles_x = d.tiles_y = 0; d.pitch = 0; d.s0_table = 0;
-    auto try_tile = [&](int tw, int th, int limit) {
-      if (d.tiled) return;
-      const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
-      // rows are whole 16-byte chunks so that the tile can be filled by LDS-DMA loads; tile
-      // origins are multiples of 16 pixels (tw is 16 or 32), so no extra lead-in is needed
-      int pitch = (pw + 15) & ~15;
-      if ((pitch & 127) == 0) pitch += 16;    // keep tile rows off a 32-bank multiple
-      const long long bytes = (long long)pitch * ph;
-      if (bytes > limit || bytes > 65535) return;   // S0Node offsets are 16-bit
-      d.tiled = 1; d.tw = tw; d.th = th; d.pitch = pitch;
-    };
-    if (fast_scan && (long long)s.nx * s.ny >= 128) {
-      for (auto& o : opts) try_tile(o[0], o[1], pref);
-      try_tile(16, 16, budget);
-      if (env_ll("JDA_TILE_16x8", 0)) try_tile(16, 8, budget);
-    }
-    // no LDS tile: k_scan reads the frame through L1/L2 if its offsets fit the packed node
-    if (fast_scan && !d.tiled && env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
-        (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits)) {
-      d.tiled = 2; d.tw = 32; d.th = 16; d.pitch = sp.width;
+    const bool glb_ok = env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
+                        (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits);
+    if (fast_scan) {
+      const TileChoice t = (env_ll("JDA_NO_LDS_SCAN", 0) || s.win > env_ll("JDA_LDS_WIN_MAX", 1 << 30)) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
+      if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
+        d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
+      } else if (glb_ok) {
+        // no LDS tile: k_scan reads the frame through L1/L2 (the offsets fit the packed node)
+        d.tiled = 2; d.tw = 32; d.th = 16; d.pitch = sp.width;
+      }
+      if (env_ll("JDA_DEBUG_TILES", 0))
+        std::fprintf(stderr, "[jda] level %d win %d step %d windows %dx%d: mode %d tile %dx%d pitch %d pix %d lds %d block %d cost/window %.0f\n",
+                     i, s.win, s.step, s.nx, s.ny, d.tiled, d.tw, d.th, d.pitch, t.pix, t.lds, t.block,
+                     t.mode ? t.cost / ((double)s.nx * s.ny) : 0.0);
     }
     if (!d.tiled) { pe->any_untiled = true; continue; }
     d.tiles_x = (s.nx + d.tw - 1) / d.tw;
@@ -415,7 +475,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
   for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
   pe.fast_scan = s0_plain && env_ll("JDA_NO_FAST_SCAN", 0) == 0;
-  assign_tiles(sp, c->hm, pe.fast_scan, &pe);
+  assign_tiles(sp, c->hm, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe);
   size_t entries = 0;
   for (int i = 0; i < pe.hp.n_levels; i++)
     if (pe.hp.lv[i].tiled) entries += n0;
@@ -659,62 +719,56 @@ struct Pass {
     if (scan_after) JDA_HIP(hipStreamWaitEvent(st, scan_after, 0));
     JDA_HIP(hipEventRecord(ev[1], st));
     if (pe->fast_scan) {
-      const int handoff = (int)env_ll("JDA_HANDOFF", 128);
-      bool any_glb = false, side_pending = false;
+      const int handoff = (int)env_ll("JDA_HANDOFF", kDefaultHandoff);
+      const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, env_ll("JDA_CP_MAX", 128)));
+      bool any_glb = false, any_wide = false, side_pending = false;
       long long lds_blocks = 0;
       for (int l = 0; l < pe->hp.n_levels; l++) {
         if (pe->hp.lv[l].tiled == 2) any_glb = true;
+        if (pe->hp.lv[l].tiled == 3) any_wide = true;
         if (pe->hp.lv[l].tiled == 1) lds_blocks += (long long)pe->hp.lv[l].tiles_x * pe->hp.lv[l].tiles_y * nf;
       }
-      if (lds_blocks > 0 && lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048)) {
-        // small job (a frame or a few): all LDS-tiled levels in one launch -- every workgroup
-        // is resident at once anyway, so per-level launches would only serialise their latency
-        if (any_glb && solo && env_ll("JDA_SIDE_SMALL", 0) && ensure_side(c, lane)) {
-          hipStream_t sd = c->side[lane];
-          JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
-          JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
-          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, sd));
-          JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
-          rs->scan_launches++;
-          any_glb = false;
-          side_pending = true;
-        }
-        JDA_HIP(launch_scan<Real>(-2, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
+      auto scan = [&](int mode, int level, hipStream_t s) -> bool {
+        JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, pe->dp, pe->hp, m, pe->table, w, s));
         rs->scan_launches++;
+        return true;
+      };
+      // the global-pixel launch of a lone lane goes to a side stream, forked here and joined before the
+      // hand-off count is read, so that it runs next to the LDS-tiled launches (with two lanes the other
+      // lane already provides that mix; measured slower there)
+      auto fork_glb = [&]() -> bool {
+        hipStream_t sd = c->side[lane];
+        JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
+        JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
+        if (!scan(2, -1, sd)) return false;
+        JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
+        any_glb = false;
+        side_pending = true;
+        return true;
+      };
+      const bool small = lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048);
+      if (small) {
+        // small job (a frame or a few): all levels of a pixel mode in one launch -- every workgroup
+        // is resident at once anyway, so per-level launches would only serialise their latency
+        if (any_glb && solo && env_ll("JDA_SIDE_SMALL", 0) && ensure_side(c, lane) && !fork_glb()) return false;
+        if (lds_blocks > 0 && !scan(1, -1, st)) return false;
+        if (any_wide && !scan(3, -1, st)) return false;
       } else {
-        // odd lanes go through the levels in the opposite order (global-pixel launch first): the
-        // texture-addresser-bound launch of one lane then runs next to the LDS/VALU-bound launches
-        // of the other instead of next to its twin
+        // odd lanes go through the levels in the opposite order (big windows first): the launches of
+        // one lane then run next to different ones of the other instead of next to their twins
         const bool rev = (lane & 1) && env_ll("JDA_LANES_REVERSE", 1);
-        if (any_glb && solo && env_ll("JDA_SIDE_STREAM", 1) && ensure_side(c, lane)) {
-          // one lane only: the global-pixel launch goes to a side stream, forked here and joined
-          // before the hand-off count is read, so that it runs next to the LDS-tiled launches
-          // (with two lanes the other lane already provides that mix; measured slower there)
-          hipStream_t sd = c->side[lane];
-          JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
-          JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
-          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, sd));
-          JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
-          rs->scan_launches++;
-          any_glb = false;
-          side_pending = true;
-        }
-        if (rev && any_glb) {
-          JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
-          rs->scan_launches++;
-          any_glb = false;
-        }
+        if (any_glb && solo && env_ll("JDA_SIDE_STREAM", 1) && ensure_side(c, lane) && !fork_glb()) return false;
+        if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
-          if (pe->hp.lv[l].tiled != 1) continue;
-          JDA_HIP(launch_scan<Real>(l, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
-          rs->scan_launches++;
+          const int mode = pe->hp.lv[l].tiled;
+          if (mode != 1 && mode != 3) continue;
+          // big-window levels of a batch are short launches: merge all of them into one (at the first one met)
+          if (mode == 3) { if (any_wide) { if (!scan(3, -1, st)) return false; any_wide = false; } continue; }
+          if (!scan(1, l, st)) return false;
         }
       }
-      if (any_glb) {
-        JDA_HIP(launch_scan<Real>(-1, want_trace(), handoff, pe->dp, pe->hp, m, pe->table, w, st));
-        rs->scan_launches++;
-      }
+      if (any_glb && !scan(2, -1, st)) return false;
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
@@ -1700,6 +1754,27 @@ void jdaResultsRelease(jdaResult* results, int n) {
     std::free(results[i].bboxes); std::free(results[i].shapes); std::free(results[i].scores);
     results[i].bboxes = nullptr; results[i].shapes = nullptr; results[i].scores = nullptr; results[i].n = 0;
   }
+}
+
+// Tile plan of a dialect-C call without touching a device (tests, tools): per level 10 ints
+// {win, step, nx, ny, mode, tw, th, pitch, tiles_x, tiles_y}.  Returns the number of levels.
+int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int min_size, int max_size, int* out, int cap_levels) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
+  if ((int)sp.levels.size() > kMaxLevels) return -1;
+  PlanEntry pe;
+  bool s0_plain = true;
+  const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
+  for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
+  assign_tiles(sp, c->hm, s0_plain, 4, &pe);
+  for (int i = 0; i < pe.hp.n_levels && i < cap_levels && out; i++) {
+    const DevLevel& d = pe.hp.lv[i];
+    const int v[10] = {d.win, d.step, d.nx, d.ny, d.tiled, d.tw, d.th, d.pitch, d.tiles_x, d.tiles_y};
+    std::memcpy(out + 10 * i, v, sizeof v);
+  }
+  return pe.hp.n_levels;
 }
 
 long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {

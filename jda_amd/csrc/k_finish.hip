@@ -162,9 +162,10 @@ __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__
 
 // Stage-0 walks from the resolved tables k_scan uses (S0Node, one 8-byte record per node with both
 // pixel offsets and the threshold): one record load instead of two, no coordinate arithmetic.
-// mode 2: offsets are frame offsets (row pitch = frame width); mode 1: offsets are LDS-tile
+// mode 2: offsets are frame offsets (row pitch = frame width); modes 1 and 3: offsets are LDS-tile
 // offsets y*pitch + x, split back into (y, x) with an exact float division ((off + 0.5) / pitch is
-// at least 0.5/pitch away from an integer, the float error is below 1e-4 of that).
+// at least 0.5/pitch away from an integer; offsets stay below 2^18 and pitches below 2^10, so the
+// float error of the quotient is below 1e-4, a tenth of that margin).
 template <int G>
 __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, const int* k, int depth, int node_n,
                                               int mode, int pitch, float inv_pitch, const uint8_t* __restrict__ wbase,
@@ -185,11 +186,13 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, co
         o2[g] = __builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu;
         th[g] = (int)(r[g].hi >> 10) - 256;
       } else {
-        const unsigned a = r[g].lo & 0xffffu, b = r[g].lo >> 16;
+        // LDS-tile offsets y*pitch + x (16-bit packing in mode 1, 21-bit in mode 3) -> frame offsets
+        const unsigned a = mode == 1 ? (r[g].lo & 0xffffu) : (r[g].lo & 0x1fffffu);
+        const unsigned b = mode == 1 ? (r[g].lo >> 16) : (__builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu);
         const unsigned ya = (unsigned)(((float)a + 0.5f) * inv_pitch), yb = (unsigned)(((float)b + 0.5f) * inv_pitch);
         o1[g] = __umul24(ya, (unsigned)W) + (a - __umul24(ya, (unsigned)pitch));
         o2[g] = __umul24(yb, (unsigned)W) + (b - __umul24(yb, (unsigned)pitch));
-        th[g] = (int)r[g].hi;
+        th[g] = mode == 1 ? (int)r[g].hi : (int)(r[g].hi >> 10) - 256;
       }
     }
     int pa[G], pb[G];

@@ -25,8 +25,9 @@ constexpr int kMaxStages = 16;
 struct DevLevel {
   int win, step, nx, ny;
   int base;              // first window of the level inside a frame (scan order)
-  int tiled;             // 1: k_scan with an LDS pixel tile; 2: k_scan reading pixels through L1/L2
-                         // (windows too large for a tile); 0: k_finish takes its windows from cart 0
+  int tiled;             // k_scan pixel mode -- 1: LDS pixel tile, 16-bit node offsets; 3: LDS pixel tile, 21-bit
+                         // node offsets (big windows, few per tile); 2: pixels through L1/L2 (windows that do
+                         // not fit LDS); 0: not scanned, k_finish takes its windows from cart 0
   int tw, th;            // windows per tile in x / y
   int tiles_x, tiles_y;
   int pitch;             // LDS bytes per tile row
@@ -59,8 +60,9 @@ struct NodeD {         // dialect CPP: fp64 offsets (already passed through the 
 // "stage-0 hoist"): in stage 0 every window holds the mean shape, so the
 // feature coordinates depend only on (node, window size).
 // Two packings of the same 8 bytes:
-//   tiled == 1 : lo = off1 | off2 << 16 (byte offsets inside the LDS tile), hi = th in [-256,255]
-//   tiled == 2 : off1 : 21 | off2 : 21 | th + 256 : 10 (byte offsets inside the frame, row pitch = width)
+//   tiled == 1    : lo = off1 | off2 << 16 (byte offsets inside the LDS tile), hi = th in [-256,255]
+//   tiled == 2, 3 : off1 : 21 | off2 : 21 | th + 256 : 10 (byte offsets inside the frame, row pitch = width,
+//                   or inside a big LDS tile)
 struct S0Node {
   uint32_t lo;
   uint32_t hi;
@@ -142,21 +144,21 @@ hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan&
                               const void* nodes, const void* mean_shape, int K, int node_n,
                               S0Node* table, hipStream_t stream);
 
-int scan_handoff_cap(int node_n, int leaf_n, int real_bytes);   // most carts k_scan can stage in LDS
-size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real_bytes, bool trace);
+int scan_handoff_cap(int node_n, int leaf_n, int real_bytes);   // carts per LDS table chunk of k_scan
+size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real_bytes, bool trace, int block);
 
 // Windows of untiled levels (or of every level) -> head of the hand-off queue, k_start = 0.
 template <typename Real>
 hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all_levels,
                           const WorkT<Real>& w, hipStream_t stream);
 
-// Stage-0 scan, carts [0, handoff) of stage 0: level >= 0 = that LDS-tiled level (tiled == 1);
-// level == -1 = every global-pixel level (tiled == 2) in one launch; level == -2 = every LDS-tiled
-// level in one launch (small batches).
+// Stage-0 scan, carts [0, handoff) of stage 0, for the levels of pixel mode `mode` (DevLevel::tiled):
+// level >= 0 = that level; level < 0 = every level of the mode in one launch (small batches).
+// cp_max = windows per tile at or below which a phase spreads (window, cart) pairs over the lanes.
 template <typename Real>
-hipError_t launch_scan(int level, bool trace, int handoff, const DevPlan* d_plan, const DevPlan& h_plan,
-                       const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,
-                       hipStream_t stream);
+hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, const DevPlan* d_plan,
+                       const DevPlan& h_plan, const DevModelT<Real>& m, const S0Node* table,
+                       const WorkT<Real>& w, hipStream_t stream);
 
 // Stages [t_begin, t_end) for every queued window: t_begin == 0 reads the hand-off queue,
 // t_begin > 0 the mid queue; survivors go to the mid queue (t_end < T) or the detection list.

@@ -138,7 +138,8 @@ __device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __res
 }
 
 // Stages the pw x ph pixel tile whose origin in the frame is (x0, y0) into LDS at row pitch
-// `pitch` (a multiple of 16).  Returns the x offset of the tile origin inside the LDS rows.
+// `pitch` (a multiple of 16, at least (x0 & 15) + pw).  Returns the x offset of the tile origin
+// inside the LDS rows.
 //  * frame 16-byte aligned (base, stride, width, x0): LDS-DMA -- `global_load_lds_dwordx4` moves
 //    16 bytes per lane straight from the frame into LDS (no VGPR round trip); a wave instruction
 //    fills 1 KiB of consecutive LDS = 64 consecutive chunks of the row-major tile; all of a
@@ -150,16 +151,19 @@ __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* 
                                          int tid) {
   constexpr int NW = BLOCK / 64;
   const int lane = tid & 63, wv = tid >> 6;
-  if (((W & 15) | (x0 & 15) | (int)(frame_stride & 15) | (int)(((uintptr_t)frames) & 15)) == 0) {
+  if (((W & 15) | (int)(frame_stride & 15) | (int)(((uintptr_t)frames) & 15)) == 0) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    // a tile origin that is not a multiple of 16 pixels starts at the 16-byte chunk below it; the
+    // caller's pitch covers the lead-in (x0 & 15) + pw
+    const int xa = x0 & ~15;
     const int cpr = pitch >> 4;                          // chunks per tile row
     const int nchunks = ph * cpr;
-    const int maxcol = ((W - x0) >> 4) - 1;              // last chunk that ends inside the frame row
+    const int maxcol = ((W - xa) >> 4) - 1;              // last chunk that ends inside the frame row
     int i = wv * 64 + lane;
     int row = i / cpr, col = i - row * cpr;
     const int dr = BLOCK / cpr, dc = BLOCK - dr * cpr;
-    const uint8_t* g0 = img + (size_t)y0 * W + x0;
+    const uint8_t* g0 = img + (size_t)y0 * W + xa;
     for (int base = wv * 64; base < nchunks; base += BLOCK) {
       if (i < nchunks) {
         const uint8_t* g = g0 + (size_t)row * W + (min(col, maxcol) << 4);
@@ -168,7 +172,7 @@ __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* 
       i += BLOCK; row += dr; col += dc;
       if (col >= cpr) { col -= cpr; row++; }
     }
-    return 0;
+    return x0 - xa;
   }
   const bool al4 = ((W & 3) == 0) && ((frame_stride & 3) == 0) && ((((uintptr_t)frames) & 3) == 0);
   if (al4) {

@@ -45,3 +45,30 @@ def test_cpp_counts(built):
     # model/config.json fddb params on 640x480 -> 140,215 windows / 19 levels
     lv, tot = synth.levels_cpp(640, 480, 20, 5, 1.2)
     assert (tot, len(lv)) == (140215, 19)
+
+
+@pytest.mark.parametrize("w,h,scale", [(640, 480, 1.25), (1920, 1080, 1.5), (1920, 1080, 1.25), (131, 97, 1.2), (450, 337, 1.25)])
+def test_scan_tiles_cover_every_window_and_fit_lds(built, model_file, w, h, scale):
+    """k_scan's tile plan (host side, no GPU): every window of a tiled level belongs to exactly one tile of at most
+    512 windows, the LDS rows cover the tile plus the 16-byte lead-in of unaligned tile origins, node offsets
+    fit their packing (16 bits in mode 1, 21 bits in modes 2/3) and a pixel tile fits the 160 KiB of a CU."""
+    from jda_amd import api
+    p, _ = model_file((2, 8, 5, 3), 8)
+    c = api.Cascador(p)
+    levels = c.plan_tiles(w, h, scale, 24, -1)
+    assert len(levels) == api.count_windows(w, h, scale, 24, -1)[1]
+    for lv in levels:
+        assert lv["mode"] in (1, 2, 3)
+        assert lv["tiles_x"] * lv["tw"] >= lv["nx"] and (lv["tiles_x"] - 1) * lv["tw"] < lv["nx"]
+        assert lv["tiles_y"] * lv["th"] >= lv["ny"] and (lv["tiles_y"] - 1) * lv["th"] < lv["ny"]
+        assert lv["tw"] * lv["th"] <= 512
+        if lv["mode"] == 2:
+            assert lv["pitch"] == w and (lv["win"] - 1) * w + lv["win"] - 1 < 2 ** 21
+            continue
+        pw = lv["win"] + (lv["tw"] - 1) * lv["step"]
+        ph = lv["win"] + (lv["th"] - 1) * lv["step"]
+        lead = max((tx * lv["tw"] * lv["step"]) & 15 for tx in range(lv["tiles_x"]))
+        assert lv["pitch"] % 16 == 0 and lv["pitch"] >= lead + pw
+        assert lv["pitch"] * ph <= 160 * 1024
+        top = (lv["win"] - 1) * lv["pitch"] + lv["win"] - 1 + 15
+        assert top <= 65535 if lv["mode"] == 1 else top < 2 ** 21
