@@ -120,10 +120,11 @@ struct PlanEntry {
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
+  bool regime_known = false;    // a pass on this plan has read the hand-off count on the host (sparse / dense decided)
   unsigned long long last_use = 0;
 };
 
-constexpr int kDefaultHandoff = 256;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
+constexpr int kDefaultHandoff = 128;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
 constexpr int kLanes = 2;     // sub-batches in flight at once, each on its own stream + workspace
 
 template <typename Real>
@@ -145,6 +146,7 @@ struct Cascador {
   std::mutex mu;
   int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
+  int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
   bool dev_init = false;
   hipStream_t stream[kLanes] = {nullptr, nullptr};                  // one per lane, see Pass / run_device
   hipEvent_t ev[kLanes][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
@@ -200,6 +202,7 @@ static bool ensure_device(Cascador* c) {
   }
   if (c->device >= n) { fail("device ordinal out of range"); return false; }
   JDA_HIP(hipSetDevice(c->device));
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
   // lane 0 now; the second lane's stream and events when a batch first needs them (ensure_lane):
   // cascadors that only see single frames (one per host thread in the FDDB harness) keep one stream
   JDA_HIP(hipStreamCreateWithFlags(&c->stream[0], hipStreamNonBlocking));
@@ -305,12 +308,27 @@ static bool upload_model(Cascador* c) {
   }
   std::vector<uint8_t> cnorm(carts);
   for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
-  std::vector<Real> par0(carts * 4);             // {th, mean, std, norm} per cart, packed for LDS staging
-  for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cmean[k]; par0[4 * k + 2] = cstd[k]; par0[4 * k + 3] = cnorm[k] ? (Real)1 : (Real)0; }
+  // compact split nodes for k_walk (dialect C only): 16 bytes of offsets + a packed word per node
+  std::vector<float> off4;
+  std::vector<uint32_t> meta;
+  const bool compact = sizeof(Real) == 4 && !h.multi_scale() && h.L <= 127;
+  if (compact) {
+    off4.resize(nodes.size() * 4); meta.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+      const SplitNode& sn = h.nodes[i];
+      for (int j = 0; j < 4; j++) off4[4 * i + j] = (float)sn.off[j];          // plain narrowing, c/jda.c:525-532
+      // the feature is a difference of two bytes: thresholds beyond [-256,255] behave like the ends
+      const int thc = sn.th < -256 ? -256 : (sn.th > 255 ? 255 : sn.th);
+      meta[i] = (uint32_t)(sn.lm1 * 2) | ((uint32_t)(sn.lm2 * 2) << 8) | ((uint32_t)(thc + 256) << 16);
+    }
+  }
+  std::vector<Real> par0(carts * 4);             // {th, norm, mean, std} per cart (CartPar), packed for LDS staging
+  for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cnorm[k] ? (Real)1 : (Real)0; par0[4 * k + 2] = cmean[k]; par0[4 * k + 3] = cstd[k]; }
 
   Carver sz(nullptr);
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
   sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
+  sz.take<float>(off4.size()); sz.take<uint32_t>(meta.size());
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
   Node* d_nodes = cv.take<Node>(nodes.size());
@@ -323,6 +341,8 @@ static bool upload_model(Cascador* c) {
   Real* d_ms = cv.take<Real>(dim);
   Real* d_ms_raw = cv.take<Real>(dim);
   Real* d_par0 = cv.take<Real>(par0.size());
+  float* d_off4 = cv.take<float>(off4.size());
+  uint32_t* d_meta = cv.take<uint32_t>(meta.size());
   JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
@@ -333,12 +353,17 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
+  if (compact) {
+    JDA_HIP(hipMemcpy(d_off4, off4.data(), off4.size() * sizeof(float), hipMemcpyHostToDevice));
+    JDA_HIP(hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   m.par0 = d_par0;
+  m.off4 = compact ? d_off4 : nullptr; m.meta = compact ? d_meta : nullptr; m.wpitch = dim;
   mo.ready = true;
   return true;
 }
@@ -432,7 +457,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
     const bool glb_ok = env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
                         (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits);
     if (fast_scan) {
-      const TileChoice t = (env_ll("JDA_NO_LDS_SCAN", 0) || s.win > env_ll("JDA_LDS_WIN_MAX", 1 << 30)) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
+      const TileChoice t = (env_ll("JDA_NO_LDS_SCAN", 0) || s.win > env_ll("JDA_LDS_WIN_MAX", 100)) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
       if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
         d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
       } else if (glb_ok) {
@@ -536,6 +561,18 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
     w.out_gid = cv.take<uint32_t>(cap);
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
+    w.la = WalkList{}; w.lb = WalkList{}; w.list_stride = 0;
+    if (sizeof(Real) == 4) {
+      // k_walk's survivor lists: a slice per workgroup, at most 4096 windows of the hand-off queue at a time
+      const size_t stride = std::min<size_t>(4096, (cap + (size_t)c->n_cus - 1) / (size_t)c->n_cus + 1);
+      const size_t entries = stride * (size_t)c->n_cus;
+      w.list_stride = (int)stride;
+      for (WalkList* l : {&w.la, &w.lb}) {
+        l->gid = cv.take<uint32_t>(entries); l->score = cv.take<float>(entries); l->xy = cv.take<uint32_t>(entries);
+        l->wf = cv.take<uint32_t>(entries); l->hash = trace ? cv.take<uint32_t>(entries) : nullptr;
+        l->shape = cv.take<float>(entries * dim);
+      }
+    }
     w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
 #ifdef JDA_SCAN_TIMING
     w.dbg = cv.take<unsigned long long>(65536 * 32);
@@ -623,7 +660,7 @@ struct Pass {
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
   // state between the steps
-  bool dense = false, finished = false;
+  bool dense = false, finished = false, walked = false;
   long long n_tail = -1, n_mid = -1;
   size_t n_out = 0;
   std::vector<uint32_t> g; std::vector<Real> sc, sh;
@@ -646,6 +683,24 @@ struct Pass {
   const S0Node* s0_tbl() const { return (pe->fast_scan && env_ll("JDA_FIN_S0", 1)) ? pe->table : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
+  // k_walk finishing path: dialect C, split nodes on the original image only, the stage's tables fit LDS
+  bool walk_ok() const {
+    if constexpr (sizeof(Real) != 4) return false;
+    else {
+      const DevModelT<Real>& m = model();
+      return m.off4 != nullptr && !multi && env_ll("JDA_WALK", 0) != 0 &&
+             w.la.gid != nullptr && walk_lds_bytes(m.K, m.node_n, m.leaf_n, m.dim) <= 160 * 1024;
+    }
+  }
+  // the whole finishing path in one persistent launch (queue lengths stay on the device)
+  bool launch_walks() {
+    if constexpr (sizeof(Real) == 4) {
+      JDA_HIP(launch_walk(want_trace(), (int)env_ll("JDA_FIN_G2", stage_groups()), apply_th, th, pe->dp, model(), w, c->n_cus,
+                          (int)env_ll("JDA_WALK_NWIN", 2), st));
+      walked = true;
+    }
+    return true;
+  }
   bool dense_ok(int* pix_cap, int* lds_max) const {
     constexpr int dialect = Sel<Real>::dialect;
     const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
@@ -729,7 +784,15 @@ struct Pass {
         if (pe->hp.lv[l].tiled == 1) lds_blocks += (long long)pe->hp.lv[l].tiles_x * pe->hp.lv[l].tiles_y * nf;
       }
       auto scan = [&](int mode, int level, hipStream_t s) -> bool {
-        JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, pe->dp, pe->hp, m, pe->table, w, s));
+        // 8 trees in flight per lane where a level's pixel tile leaves room for few waves per CU (JDA_ILP8_LDS:
+        // LDS bytes per workgroup above which; the kernel is latency bound there, LDS-pipe bound below)
+        int opts = (int)(std::max<long long>(4, std::min<long long>(64, env_ll("JDA_FIRST_PHASE", 16))) & ~3LL) << 8;
+        if (level >= 0 && mode == 1) {
+          const DevLevel& lv = pe->hp.lv[level];
+          if ((long long)lv.pitch * (lv.win + (lv.th - 1) * lv.step) >= env_ll("JDA_ILP8_LDS", 1 << 30)) opts |= 1;
+        }
+        if (mode == 3 && env_ll("JDA_ILP8_WIDE", 0)) opts |= 1;
+        JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, s));
         rs->scan_launches++;
         return true;
       };
@@ -772,7 +835,10 @@ struct Pass {
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
-    // the hand-off queue length sizes the finishing launches (one workgroup per window)
+    // once a pass on this plan has seen the hand-off count (sparse regime confirmed), the finishing stages are
+    // queued right behind the scan: no host round trip inside the pipeline
+    if (walk_ok() && pe->regime_known) { finished = true; return launch_walks(); }
+    // the hand-off queue length decides sparse / dense and sizes the old finishing launches
     return read_counter(kCntTail);
   }
 
@@ -792,6 +858,8 @@ struct Pass {
       if (!clear_counters()) return false;
       return run_dense();
     }
+    pe->regime_known = true;
+    if (walk_ok()) { finished = true; return launch_walks(); }
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
@@ -838,6 +906,14 @@ struct Pass {
       // fall back to the sparse pipeline when stage 0 rejects most windows after all
       const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
       if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * (double)windows()) pe->dense_hint = false;
+    }
+    if (walked) {
+      // the finishing stages ran without looking at the hand-off count: if most windows turn out to be alive
+      // after the scan, the next pass on this plan goes dense
+      int pix_cap, lds_max;
+      const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
+      const double tail = (double)h_cnt[kCntTail];
+      if (dense_ok(&pix_cap, &lds_max) && tail >= dense_frac * (double)windows() && tail > 4096) pe->dense_hint = true;
     }
     n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;

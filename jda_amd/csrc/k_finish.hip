@@ -205,54 +205,6 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, co
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
 }
 
-// Score recurrence of c/jda.c:395-399 over the carts held by lanes [jbeg, jend)
-// of one 64-cart group, replayed strictly in cart order.  ls/th_k/mean_k/std_k/lf
-// are per-lane values of cart (group base + lane).  Returns the lane of the
-// rejecting cart or -1; score/hash are left as they stood at that cart.
-template <typename Real, bool TRACE>
-__device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real ls, Real th_k, Real mean_k, Real std_k,
-                                             unsigned long long normmask, int lf, int jbeg, int jend) {
-  if (jbeg == 0 && jend == 64 && normmask == 0ull) {
-    // Common case, branch-free: the running score is wave-uniform; after every
-    // add ALL lanes compare it with their own cart's threshold and only bit j
-    // of that ballot is kept.  Same adds in the same order as the scalar loop.
-    Real s = score;
-    unsigned long long rej = 0ull;
-    for (int j0 = 0; j0 < 64 && rej == 0ull; j0 += 16) {      // stop at the 16-cart block that rejects
-#pragma unroll
-      for (int jj = 0; jj < 16; jj++) {
-        const int j = j0 + jj;
-        s = s + rl(ls, j);                                     // c/jda.c:396
-        rej |= __ballot(s < th_k) & (1ull << j);               // c/jda.c:399
-      }
-    }
-    if (rej == 0ull) {
-      if (TRACE) {
-#pragma unroll 8
-        for (int j = 0; j < 64; j++) hash = fnv_step(hash, rl(lf, j));
-      }
-      score = s;
-      return -1;
-    }
-    const int jr = __ffsll((long long)rej) - 1;
-    Real s2 = score;
-    for (int j = 0; j <= jr; j++) {                            // the score as it stood at the rejecting cart
-      s2 = s2 + rl(ls, j);
-      if (TRACE) hash = fnv_step(hash, rl(lf, j));
-    }
-    score = s2;
-    return jr;
-  }
-  for (int j = jbeg; j < jend; j++) {
-    Real s = score + rl(ls, j);                                                     // c/jda.c:396
-    if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);             // c/jda.c:397
-    score = s;
-    if (TRACE) hash = fnv_step(hash, rl(lf, j));
-    if (s < rl(th_k, j)) return j;                                                  // c/jda.c:399
-  }
-  return -1;
-}
-
 // Stages [t_begin, t_end) for every window of the input queue.  Windows that are
 // still alive after stage t_end-1 go to the mid queue (t_end < T) or, after the
 // final threshold, to the detection list (t_end == T).

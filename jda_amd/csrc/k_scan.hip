@@ -28,6 +28,9 @@ namespace {
 
 constexpr int kScanMaxWindows = 512;     // windows per tile at most (queue capacity)
 
+template <typename Real>
+struct ThNorm { Real th, norm; };        // first half of CartPar: all the common case needs
+
 template <typename Real, bool TRACE>
 struct ScanLds {
   // byte offsets inside dynamic LDS
@@ -100,7 +103,7 @@ template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                                 const S0Node* __restrict__ table, WorkT<Real> w,
                                                 int level, int tiles_total, int pix_bytes, int handoff, int chunk,
-                                                int cp_max) {
+                                                int cp_max, int opts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr bool GLB = MODE == 2;
   constexpr bool WIDE = MODE != 1;
@@ -109,6 +112,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
   constexpr int LF = BLOCK * 8;          // bytes of lfbuf: 8 trees per lane and round in the pair phases
   const int node_n = m.node_n, leaf_n = m.leaf_n;
   const int K = min(m.K, handoff);     // this kernel stops here and hands survivors to k_finish
+  const bool ilp8 = GLB || (opts & 1);   // 8 instead of 4 trees in flight per lane (levels with few resident waves)
+  const int first_phase = (opts >> 8) & 0xff;   // carts before the first compaction (8 or 16)
   const ScanLds<Real, TRACE> L(pix_bytes, chunk, node_n, leaf_n, M_MAX, LF);
   const uint8_t* pix = lds + L.pix;
   Real* q_score = (Real*)(lds + L.q_score);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
     // the survivors are compacted so that later phases run on full waves.
     for (int c0 = kb; c0 < ke && n_items > 0;) {
       const bool cart_parallel = queued && n_items <= cp_max && leaf_n <= 256;
-      int plen = c0 < 8 ? 8 : min(c0, c0 >= 128 ? 128 : 64);
+      int plen = c0 < first_phase ? first_phase - c0 : min(c0, c0 >= 128 ? 128 : 64);
       if (cart_parallel && plen < 16) plen = 16;
       const int c1 = min(ke, c0 + plen);
 
@@ -237,10 +242,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
         constexpr int CNT = decltype(cnt_tag)::value;
         // all table reads first and unconditionally (they depend on the leaves only), so that
         // their LDS round trips overlap; the dependent part below is pure arithmetic
-        CartPar<Real> p[CNT];
+        ThNorm<Real> p[CNT];
         Real lsv[CNT];
 #pragma unroll
-        for (int u = 0; u < CNT; u++) { p[u] = t_par[k + u]; lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; }
+        for (int u = 0; u < CNT; u++) { p[u] = *(const ThNorm<Real>*)&t_par[k + u]; lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]]; }
         Real s = score;
         bool dead = false;
         int kd = k;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
         for (int u = 0; u < CNT; u++) {
           if (!dead) {
             s = s + lsv[u];                                                  // c/jda.c:396
-            if (p[u].norm != (Real)0) s = (s - p[u].mean) / p[u].std;        // c/jda.c:397
+            if (p[u].norm != (Real)0) { const CartPar<Real> q = t_par[k + u]; s = (s - q.mean) / q.std; }   // c/jda.c:397 (rare)
             if (TRACE) hash = fnv_step(hash, lf[u]);
             kd = k + u;
             dead = s < p[u].th;                                              // c/jda.c:399
@@ -285,8 +290,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
           const int gid = gid0 + (wy0 + wy) * lv.nx + wx0 + wx;
 
           int k = c0;
-          if (GLB) {
-            // pixels come through L1/L2 here: each tree level is a global-load round trip, so
+          if (ilp8) {
+            // global pixels (each tree level is a global-load round trip) or few resident waves per CU:
             // twice as many independent trees are kept in flight
             for (; k + 8 <= c1; k += 8) {
               if (__ballot(alive) == 0ull) break;
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
             // then the recurrence runs in registers, strictly in cart order (c/jda.c:395-399)
             for (; k + 16 <= r1; k += 16) {
               if (__ballot(alive) == 0ull) break;
-              const CartPar<Real> pm = t_par[k + (lane & 15)];       // lane u (mod 16): cart k+u
+              const ThNorm<Real> pm = *(const ThNorm<Real>*)&t_par[k + (lane & 15)];   // lane u (mod 16): cart k+u
               if (__ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
               // thresholds: lane u holds cart k+u's; broadcast with readlane HERE, with the whole wave
               // active -- inside the divergent block below the lanes without a live window would not
@@ -533,7 +538,7 @@ namespace {
 
 template <typename Real, bool TRACE, int MODE, int BLOCK>
 hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const DevModelT<Real>& m,
-                            const S0Node* table, const WorkT<Real>& w, int level, int handoff, int cp_max,
+                            const S0Node* table, const WorkT<Real>& w, int level, int handoff, int cp_max, int opts,
                             hipStream_t stream) {
   // level >= 0: that level; level < 0: every level of pixel mode MODE in one launch, sized for the
   // largest tile (small batches, where one launch per level would only add launch latency)
@@ -554,7 +559,7 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
     if (L.total > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
-                       pix_bytes, handoff, chunk, cp_max);
+                       pix_bytes, handoff, chunk, cp_max, opts);
   };
   if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);
   else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK>);
@@ -565,7 +570,7 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
 }  // namespace
 
 template <typename Real>
-hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, const DevPlan* d_plan,
+hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
                        const DevPlan& h_plan, const DevModelT<Real>& m, const S0Node* table,
                        const WorkT<Real>& w, hipStream_t stream) {
   if (w.n_frames == 0) return hipSuccess;
@@ -578,19 +583,19 @@ hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max,
     constexpr bool TR = decltype(trace_tag)::value;
     switch (mode) {
       case 1:
-        return big ? launch_scan_mode<Real, TR, 1, 512>(d_plan, h_plan, m, table, w, level, handoff, cp_max, stream)
-                   : launch_scan_mode<Real, TR, 1, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, stream);
-      case 2: return launch_scan_mode<Real, TR, 2, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, stream);
-      case 3: return launch_scan_mode<Real, TR, 3, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, stream);
+        return big ? launch_scan_mode<Real, TR, 1, 512>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream)
+                   : launch_scan_mode<Real, TR, 1, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
+      case 2: return launch_scan_mode<Real, TR, 2, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
+      case 3: return launch_scan_mode<Real, TR, 3, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
       default: return hipErrorInvalidValue;
     }
   };
   return trace ? pick(std::true_type{}) : pick(std::false_type{});
 }
 
-template hipError_t launch_scan<float>(int, int, bool, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
+template hipError_t launch_scan<float>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
                                        const S0Node*, const WorkT<float>&, hipStream_t);
-template hipError_t launch_scan<double>(int, int, bool, int, int, const DevPlan*, const DevPlan&, const DevModelT<double>&,
+template hipError_t launch_scan<double>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<double>&,
                                         const S0Node*, const WorkT<double>&, hipStream_t);
 
 }  // namespace jda

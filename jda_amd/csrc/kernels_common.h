@@ -103,6 +103,14 @@ __device__ __forceinline__ double rl(double v, int j) {
   return __hiloint2double(hi, lo);
 }
 
+// Orders this wave's LDS writes before its later LDS reads by OTHER lanes of the same wave (a wave's DS
+// operations execute in order, so no instruction is needed -- only the compiler must not move them).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
   return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
@@ -114,8 +122,9 @@ __device__ __forceinline__ unsigned long long* shard_counter(unsigned long long*
 
 template <typename Real>
 struct CartPar {          // per-cart parameters as k_scan / k_stage read them from LDS
-  Real th, mean, std;
-  Real norm;              // != 0 where (mean,std) != (0,1)
+  Real th;
+  Real norm;              // != 0 where (mean,std) != (0,1); next to th: the common case reads only this half
+  Real mean, std;
 };
 
 // global -> LDS copy of n elements by the whole workgroup with all loads of a
@@ -227,6 +236,54 @@ __device__ __forceinline__ void dma_to_lds(unsigned char* lds_dst, const void* _
     done = chunks << 4;
   }
   stage_to_lds<unsigned char, BLOCK, 4>(lds_dst + done, g + done, nbytes - done, tid);
+}
+
+// Score recurrence of c/jda.c:395-399 over the carts held by lanes [jbeg, jend)
+// of one 64-cart group, replayed strictly in cart order.  ls/th_k/mean_k/std_k/lf
+// are per-lane values of cart (group base + lane).  Returns the lane of the
+// rejecting cart or -1; score/hash are left as they stood at that cart.
+template <typename Real, bool TRACE>
+__device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real ls, Real th_k, Real mean_k, Real std_k,
+                                             unsigned long long normmask, int lf, int jbeg, int jend) {
+  if (jbeg == 0 && jend == 64 && normmask == 0ull) {
+    // Common case, branch-free: the running score is wave-uniform; after every
+    // add ALL lanes compare it with their own cart's threshold and only bit j
+    // of that ballot is kept.  Same adds in the same order as the scalar loop.
+    Real s = score;
+    unsigned long long rej = 0ull;
+    for (int j0 = 0; j0 < 64 && rej == 0ull; j0 += 16) {      // stop at the 16-cart block that rejects
+#pragma unroll
+      for (int jj = 0; jj < 16; jj++) {
+        const int j = j0 + jj;
+        s = s + rl(ls, j);                                     // c/jda.c:396
+        rej |= __ballot(s < th_k) & (1ull << j);               // c/jda.c:399
+      }
+    }
+    if (rej == 0ull) {
+      if (TRACE) {
+#pragma unroll 8
+        for (int j = 0; j < 64; j++) hash = fnv_step(hash, rl(lf, j));
+      }
+      score = s;
+      return -1;
+    }
+    const int jr = __ffsll((long long)rej) - 1;
+    Real s2 = score;
+    for (int j = 0; j <= jr; j++) {                            // the score as it stood at the rejecting cart
+      s2 = s2 + rl(ls, j);
+      if (TRACE) hash = fnv_step(hash, rl(lf, j));
+    }
+    score = s2;
+    return jr;
+  }
+  for (int j = jbeg; j < jend; j++) {
+    Real s = score + rl(ls, j);                                                     // c/jda.c:396
+    if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);             // c/jda.c:397
+    score = s;
+    if (TRACE) hash = fnv_step(hash, rl(lf, j));
+    if (s < rl(th_k, j)) return j;                                                  // c/jda.c:399
+  }
+  return -1;
 }
 
 }  // namespace
