@@ -5,7 +5,11 @@
 
 A *step* is one pass of the detect path (jdaDetectBatchDevice: stage-0 scan,
 later stages, regression, compaction, D2H of survivors, host NMS+relocation)
-over one batch of synthetic frames that is already resident in HBM.  At N>1
+over one batch of synthetic frames that is already resident in HBM.  The steps
+cycle through --rotate (4) distinct resident batches (314 MB of frames), so a
+step does not find its frames in the 256 MB Infinity Cache from the step before.
+The PCIe-inclusive rate (frames in host memory, jdaDetectBatchSubmitHost) is
+reported in config.host_frames_windows_per_s and is never `value`.  At N>1
 the driver launches one process per GPU with torch.distributed.run; every rank
 runs its own batch (weak scaling, no data-path collective) and the detections
 are gathered on rank 0 over RCCL inside the timed region (the gather of step i
@@ -39,6 +43,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# LDS: 64 banks x 4 B per CU and clock, but a 4-byte-or-narrower read is served 32 lanes per clock (128 B/clk/CU);
+# 256 CUs at 2.4 GHz (same guide, section LDS: "~75 TB/s for ds_read_b32")
+LDS_PEAK_GBPS = 128 * 256 * 2.4
+# what 64 lanes reading random bytes reach on this part: 8.2 LDS clocks per wave instruction instead of 2
+# (measured, tools/lds_bench.hip -> profiles/r02_lds_bench.txt)
+LDS_RANDOM_GATHER_GBPS = LDS_PEAK_GBPS * 2.0 / 8.2
 
 
 def algorithmic_bytes(dims, carts, stage_done, windows, accepted):
@@ -107,8 +117,10 @@ def cpu_baseline(model_file, dims, frames, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct device-resident batches the steps cycle through (4 x 78.6 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -151,8 +163,13 @@ def main():
     call = dict(scale=1.25, min_size=40, max_size=-1, th=-0.5)
 
     calib = synth.make_frames(8, W, H, seed=0, first=10_000_000)
-    frames = synth.make_frames(B, W, H, seed=0, first=rank * B)     # this rank's shard of the job
-    d_frames = torch.from_numpy(frames).to(dev)
+    R = max(1, args.rotate)
+    # this rank's shard of the job: R distinct batches, so that a step does not re-read frames the previous step left
+    # in the Infinity Cache
+    frames_all = [synth.make_frames(B, W, H, seed=0, first=(rank * R + j) * B) for j in range(R)]
+    frames = frames_all[0]
+    d_batches = [torch.from_numpy(f).to(dev) for f in frames_all]
+    d_frames = d_batches[0]
     wpf, n_levels = api.count_windows(W, H, call["scale"], call["min_size"], call["max_size"])
     windows_step = wpf * B
 
@@ -192,9 +209,15 @@ def main():
         # before the closing barrier, so all K gathers complete inside the timed region.
         gather = jdist.PipelinedGather(4096, 5 + 2 * L, device=gather_dev)
 
+        counter = [0]
+
+        def next_batch():
+            counter[0] += 1
+            return d_batches[counter[0] % R]
+
         def step(want_stats=False, c=None):
             # every rank: detect its batch, flatten the (bbox, score, landmarks) tuples with one C call
-            out = (c or casc).detect_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th,
+            out = (c or casc).detect_batch_device(next_batch(), call["scale"], call["min_size"], call["max_size"], th,
                                                   nms=True, stats=want_stats, keep_results="packed",
                                                   frame_offset=rank * B)
             rows, st = out if want_stats else (out, None)
@@ -203,7 +226,7 @@ def main():
             return len(rows), st
 
         def submit():
-            return casc.submit_batch_device(d_frames, call["scale"], call["min_size"], call["max_size"], th, nms=True)
+            return casc.submit_batch_device(next_batch(), call["scale"], call["min_size"], call["max_size"], th, nms=True)
 
         if depth == 1:
             for _ in range(warmup):
@@ -247,6 +270,8 @@ def main():
             el = float(t.item())
         st = stats[-1]
         scan_ms = float(np.mean([s["scan_ms"] for s in stats]))
+        scan_lds_ms = float(np.mean([s["scan_lds_ms"] for s in stats]))
+        scan_lds_carts = float(np.mean([s["scan_lds_cart_n"] for s in stats]))
         gpu_ms = float(np.mean([s["gpu_ms"] for s in stats]))
         host_ms = float(np.mean([s["host_ms"] for s in stats]))
         call_ms = float(np.mean([s["call_ms"] for s in stats]))
@@ -257,6 +282,8 @@ def main():
             "images_per_s": B * world * steps / el,
             "ms_per_step": el / steps * 1e3,
             "gpu_ms_per_step": gpu_ms, "scan_ms_per_step": scan_ms, "host_post_ms_per_step": host_ms,
+            "scan_lds_ms_per_step": scan_lds_ms, "scan_lds_carts_per_step": scan_lds_carts,
+            "scan_carts_per_step": float(np.mean([s["scan_cart_n"] for s in stats])),
             "call_ms_per_step": call_ms,
             "average_cart_n": st["average_cart_n"], "finish_fraction": st["stage_done_n"][T - 1] / max(1, st["patch_n"]),
             "detections_after_nms": n_det,
@@ -272,13 +299,42 @@ def main():
 
     casc_info, casc_model = run_regime("cascade", args.steps, args.warmup, call["th"], depth=args.depth)
     # one caller, one batch at a time (what a single jdaDetectBatchDevice loop sees)
-    single_info = casc_info if args.depth <= 1 else run_regime("cascade", max(1, min(10, args.steps)), 1, call["th"])[0]
+    single_info = casc_info if args.depth <= 1 else run_regime("cascade", max(1, min(20, args.steps)), 2, call["th"])[0]
     # roofline leg: the same workload with the k_scan launches of a step back to back on one stream
-    roof_info, _ = run_regime("cascade", max(1, min(10, args.steps)), 1, call["th"], lanes=1)
+    roof_info, _ = run_regime("cascade", max(1, min(20, args.steps)), 2, call["th"], lanes=1)
     allpass_info = None
     if not args.no_allpass:
         # every window walks all T*K carts; final th=+inf so NMS sees nothing
         allpass_info, _ = run_regime("allpass", max(1, min(2, args.steps)), 1, float("inf"))
+
+    # PCIe-inclusive leg (never `value`): the same steps with the frames in HOST memory, through
+    # jdaDetectBatchSubmitHost / jdaDetectBatchWait (two batches in flight: the H2D copy of step i+1 runs next to the
+    # kernels of step i), once from pageable numpy arrays and once from pinned ones
+    def host_leg(pinned, steps):
+        casc = api.Cascador(casc_model, device=local_rank)
+        srcs = frames_all[:2]
+        keep = []
+        if pinned:
+            keep = [torch.from_numpy(f).pin_memory() for f in srcs]
+            srcs = [k.numpy() for k in keep]
+        kw = dict(scale=call["scale"], min_size=call["min_size"], max_size=call["max_size"], th=call["th"])
+        t = casc.submit_batch_host(srcs[0], **kw)
+        for i in range(2):
+            nxt = casc.submit_batch_host(srcs[(i + 1) % 2], **kw)
+            casc.wait_batch(t, keep_results="packed"); t = nxt
+        barrier(); t0 = time.perf_counter()
+        for i in range(steps):
+            nxt = casc.submit_batch_host(srcs[i % 2], **kw) if i + 1 < steps else None
+            casc.wait_batch(t, keep_results="packed"); t = nxt
+        barrier(); el = time.perf_counter() - t0
+        casc.close()
+        return windows_step * steps / el
+
+    host_info = None
+    if world == 1:
+        hs = max(2, min(30, args.steps))
+        host_info = {"pageable_windows_per_s": host_leg(False, hs), "pinned_windows_per_s": host_leg(True, hs), "steps": hs,
+                     "entry": "jdaDetectBatchSubmitHost / jdaDetectBatchWait, two batches in flight"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -288,15 +344,28 @@ def main():
             cpu = {"value": None, "unit": "windows/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
 
     if rank == 0:
-        scan_s = roof_info["scan_ms_per_step"] * 1e-3
-        achieved = roof_info["scan_algorithmic_bytes"] / scan_s / 1e9 if scan_s > 0 else 0.0
-        traffic = None
+        # ---- roofline of the dominant kernel: the LDS-tiled k_scan launches of one step ----
+        # Bound: the LDS pipe.  Every tree node costs three lane-reads from LDS (one 8-byte resolved node record, two
+        # pixel bytes), every cart two more (leaf score, threshold): (D-1)*3 + 2 lane-reads per window-cart; a lane-read
+        # moves one 4-byte bank word at most.  achieved = lane-reads of the carts the launches evaluated (device counter)
+        # x 4 B / the HIP-event span of those launches (on their own stream, back to back).
+        lane_reads_per_cart = (D - 1) * 3 + 2
+        lds_s = roof_info["scan_lds_ms_per_step"] * 1e-3
+        lane_reads = roof_info["scan_lds_carts_per_step"] * lane_reads_per_cart
+        achieved = lane_reads * 4 / lds_s / 1e9 if lds_s > 0 else 0.0
+        traffic, traffic_src, hbm_frac = None, None, None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("k_scan_bytes_per_step")
+                tj = json.load(open(tp))
+                traffic = tj.get("k_scan_lds_bytes_per_step", tj.get("k_scan_bytes_per_step"))
+                traffic_src = ("profiles/hbm_traffic.json: %s -- builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "this command, NOT measured in this run" % tj.get("source", "r01"))
+                if traffic and lds_s > 0:
+                    hbm_frac = traffic / lds_s / 1e9 / HBM_PEAK_GBPS
             except Exception:
                 traffic = None
+        scan_bytes_alg = roof_info["scan_lds_carts_per_step"] * ((D - 1) * 34 + 16)
         line = {
             "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path)",
             "value": casc_info["windows_per_s"], "unit": "windows/s",
@@ -309,23 +378,37 @@ def main():
                                    % (B, W, H, T, K, L, D),
                        "batch_per_gpu": B, "width": W, "height": H, "windows_per_frame": wpf, "levels": n_levels,
                        "model_dims_TKLD": list(dims), "regime": "cascade", "sharding": "frames, %d rank(s)" % world,
+                       "distinct_resident_batches": R, "resident_frame_bytes": R * B * W * H,
                        "batches_in_flight_per_gpu": casc_info["batches_in_flight"],
                        "single_caller_ms_per_step": single_info["ms_per_step"],
-                       "single_caller_windows_per_s": single_info["windows_per_s"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_scan (stage-0 LDS-tiled scan; one launch per tiled pyramid level, "
-                                   "'launch' here = the %d launches of one step)" % roof_info["scan_launches"],
-                         "algorithmic_bytes_per_step": roof_info["scan_algorithmic_bytes"],
-                         "kernel_ms_per_step": roof_info["scan_ms_per_step"],
-                         "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0 (launches serialised on one stream: the HIP-event span "
-                                          "around the k_scan launches is the sum of their durations; the throughput "
-                                          "legs overlap two sub-batches on two streams)",
-                         "note": "algorithmic bytes = SURVEY 8(d) per-window figure; they are served from LDS/L2 by "
-                                 "design, HBM traffic is the frames + model once"},
+                       "single_caller_windows_per_s": single_info["windows_per_s"],
+                       "host_frames_windows_per_s": host_info["pageable_windows_per_s"] if host_info else None,
+                       "host_frames_pinned_windows_per_s": host_info["pinned_windows_per_s"] if host_info else None},
+            "roofline": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_scan, the LDS-tiled launches of one step (one per tiled pyramid level)",
+                         "what": "LDS crossbar bytes: (D-1)*3+2 = %d lane-reads of 4 B per window-cart x carts evaluated "
+                                 "(device counter) / HIP-event span of the launches; peak = 128 B/clk/CU x 256 CUs x 2.4 GHz "
+                                 "(conflict-free ds_read_b32/u8 rate)" % lane_reads_per_cart,
+                         "lane_reads_per_cart": lane_reads_per_cart,
+                         "carts_per_step": roof_info["scan_lds_carts_per_step"],
+                         "kernel_ms_per_step": roof_info["scan_lds_ms_per_step"],
+                         "frac_of_random_gather_rate": achieved / LDS_RANDOM_GATHER_GBPS,
+                         "random_gather_rate_GBps": LDS_RANDOM_GATHER_GBPS,
+                         "hbm_side": {"algorithmic_bytes_per_step": scan_bytes_alg,
+                                      "algorithmic_GBps": scan_bytes_alg / lds_s / 1e9 if lds_s > 0 else None,
+                                      "measured_frac_of_hbm_peak": hbm_frac,
+                                      "note": "SURVEY 8(d)'s 34 B per node are served from LDS (tile and tables staged once "
+                                              "per workgroup), so this figure exceeds what HBM delivers and is not a "
+                                              "roofline; the kernel's HBM-side traffic is the frames once + the tables"},
+                         "all_scan_launches_ms_per_step": roof_info["scan_ms_per_step"],
+                         "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0: the launches of a step run back to back on one "
+                                          "stream, HIP events recorded on that stream before the first and after the last "
+                                          "LDS-tiled launch (jdaStats.scan_lds_ms); the throughput legs overlap two batches"},
             "cpu_baseline": cpu,
             "regimes": {"cascade": casc_info, "cascade_single_caller": single_info, "cascade_one_lane": roof_info,
-                        "allpass": allpass_info},
+                        "allpass": allpass_info, "host_frames": host_info},
         }
         print(json.dumps(line))
     if world > 1:

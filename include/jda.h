@@ -150,6 +150,9 @@ typedef struct {
   long long cart_total_n;     /* carts evaluated over ALL windows (roofline accounting) */
   double call_ms;             /* wall clock of the whole C call                 */
   int dense_passes;           /* passes that ran in dense mode (whole stages per window tile, k_stage) */
+  double scan_lds_ms;         /* HIP-event span of the LDS-tiled k_scan launches alone; only meaningful when the launches of
+                                 a call run back to back on one stream (JDA_LANES=1 JDA_SIDE_STREAM=0), 0 otherwise */
+  long long scan_lds_cart_n;  /* carts evaluated by the LDS-tiled k_scan launches (scan_cart_n minus the global-pixel levels) */
 } jdaStats;
 
 typedef struct {
@@ -194,6 +197,14 @@ JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, 
                                  int width, int height, float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt);
 JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaResult *out);
+
+/* Submit for frames in HOST memory (frames[i] is width*height bytes): the batch is copied to a staging buffer
+ * of its ticket on that ticket's stream, then scanned like jdaDetectBatchSubmit.  With pageable frames the
+ * copy blocks this call but still overlaps the kernels of the other ticket's batch; with pinned frames
+ * (hipHostMalloc / hipHostRegister) it is asynchronous and the frames must stay valid until Wait returns. */
+JDA_API int jdaDetectBatchSubmitHost(void *cascador, const unsigned char *const *frames, int n,
+                                     int width, int height, float scale, float step, int min_size, int max_size,
+                                     float th, const jdaDetectOptions *opt);
 
 /* Per-window trace of the cascade (parity instrumentation; HOST output
  * arrays of n*windows_per_frame entries in scan order, any may be NULL):

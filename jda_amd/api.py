@@ -46,7 +46,8 @@ class jdaStats(C.Structure):
                 ("average_cart_n", C.c_double), ("gpu_ms", C.c_double), ("scan_ms", C.c_double),
                 ("host_ms", C.c_double), ("scan_cart_n", C.c_longlong), ("scan_patch_n", C.c_longlong),
                 ("scan_launches", C.c_int), ("handoff_n", C.c_longlong), ("cart_total_n", C.c_longlong),
-                ("call_ms", C.c_double), ("dense_passes", C.c_int)]
+                ("call_ms", C.c_double), ("dense_passes", C.c_int), ("scan_lds_ms", C.c_double),
+                ("scan_lds_cart_n", C.c_longlong)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_done_n"}
@@ -101,6 +102,8 @@ def _load():
                                          C.POINTER(jdaResult)]
     lib.jdaDetectBatchSubmit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions)]
+    lib.jdaDetectBatchSubmitHost.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float,
+                                             C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions)]
     lib.jdaDetectBatchWait.argtypes = [C.c_void_p, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResult)]
     lib.jdaTraceBatch.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                   C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint), C.POINTER(C.c_float)]
@@ -320,6 +323,20 @@ class Cascador:
         if not hasattr(self, "_pending"):
             self._pending = {}
         self._pending[t] = (d_frames, n)
+        return t
+
+    def submit_batch_host(self, frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True):
+        """Submit for frames in host memory (numpy uint8 [n,h,w]; kept alive until wait_batch)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        o, _ = self._opts(nms, False)
+        t = lib.jdaDetectBatchSubmitHost(self.h, ptrs, n, w, h, scale, 0.1, min_size, max_size, th, C.byref(o))
+        if t < 0:
+            raise JdaError(last_error())
+        if not hasattr(self, "_pending"):
+            self._pending = {}
+        self._pending[t] = ((frames, ptrs), n)
         return t
 
     def wait_batch(self, ticket, stats=False, keep_results=True, frame_offset=0):

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjda.so")
-SOURCES = ["k_misc.hip", "k_scan.hip", "k_finish.hip", "k_walk.hip", "k_stage.hip", "detect.cpp", "model.cpp", "plan.cpp", "post.cpp"]
+SOURCES = ["k_misc.hip", "k_scan.hip", "k_finish.hip", "k_stage.hip", "detect.cpp", "model.cpp", "plan.cpp", "post.cpp"]
 HEADERS = ["kernels.h", "kernels_common.h", "model.h", "plan.h", "post.h", os.path.join("..", "..", "include", "jda.h")]
 OBJDIR = os.path.join(HERE, "build")
 

@@ -120,7 +120,6 @@ struct PlanEntry {
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
-  bool regime_known = false;    // a pass on this plan has read the hand-off count on the host (sparse / dense decided)
   unsigned long long last_use = 0;
 };
 
@@ -149,7 +148,7 @@ struct Cascador {
   int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
   bool dev_init = false;
   hipStream_t stream[kLanes] = {nullptr, nullptr};                  // one per lane, see Pass / run_device
-  hipEvent_t ev[kLanes][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t ev[kLanes][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t ev_user = nullptr;
   hipStream_t side[kLanes] = {nullptr, nullptr};            // global-pixel scan launch of a lane, next to its LDS-tiled launches
   hipEvent_t ev_side[kLanes][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -165,6 +164,7 @@ struct Cascador {
   PendingBatch* pending = nullptr;           // [kLanes], allocated by the first submit
   // host frames whose H2D copies run_device issues per sub-batch (set by stage_frames(.., defer), consumed
   // by the next run_device): the copies of one sub-batch then overlap the kernels of the other lane
+  DevBuf submit_frames[kLanes];              // staging of jdaDetectBatchSubmitHost, one per ticket
   const unsigned char* const* pending_host = nullptr;
   size_t pending_fbytes = 0;
 };
@@ -308,27 +308,12 @@ static bool upload_model(Cascador* c) {
   }
   std::vector<uint8_t> cnorm(carts);
   for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
-  // compact split nodes for k_walk (dialect C only): 16 bytes of offsets + a packed word per node
-  std::vector<float> off4;
-  std::vector<uint32_t> meta;
-  const bool compact = sizeof(Real) == 4 && !h.multi_scale() && h.L <= 127;
-  if (compact) {
-    off4.resize(nodes.size() * 4); meta.resize(nodes.size());
-    for (size_t i = 0; i < nodes.size(); i++) {
-      const SplitNode& sn = h.nodes[i];
-      for (int j = 0; j < 4; j++) off4[4 * i + j] = (float)sn.off[j];          // plain narrowing, c/jda.c:525-532
-      // the feature is a difference of two bytes: thresholds beyond [-256,255] behave like the ends
-      const int thc = sn.th < -256 ? -256 : (sn.th > 255 ? 255 : sn.th);
-      meta[i] = (uint32_t)(sn.lm1 * 2) | ((uint32_t)(sn.lm2 * 2) << 8) | ((uint32_t)(thc + 256) << 16);
-    }
-  }
   std::vector<Real> par0(carts * 4);             // {th, norm, mean, std} per cart (CartPar), packed for LDS staging
   for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cnorm[k] ? (Real)1 : (Real)0; par0[4 * k + 2] = cmean[k]; par0[4 * k + 3] = cstd[k]; }
 
   Carver sz(nullptr);
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
   sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
-  sz.take<float>(off4.size()); sz.take<uint32_t>(meta.size());
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
   Node* d_nodes = cv.take<Node>(nodes.size());
@@ -341,8 +326,6 @@ static bool upload_model(Cascador* c) {
   Real* d_ms = cv.take<Real>(dim);
   Real* d_ms_raw = cv.take<Real>(dim);
   Real* d_par0 = cv.take<Real>(par0.size());
-  float* d_off4 = cv.take<float>(off4.size());
-  uint32_t* d_meta = cv.take<uint32_t>(meta.size());
   JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
@@ -353,17 +336,12 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
-  if (compact) {
-    JDA_HIP(hipMemcpy(d_off4, off4.data(), off4.size() * sizeof(float), hipMemcpyHostToDevice));
-    JDA_HIP(hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   m.par0 = d_par0;
-  m.off4 = compact ? d_off4 : nullptr; m.meta = compact ? d_meta : nullptr; m.wpitch = dim;
   mo.ready = true;
   return true;
 }
@@ -561,18 +539,6 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
     w.out_gid = cv.take<uint32_t>(cap);
     w.out_score = cv.take<Real>(cap);
     w.out_shape = cv.take<Real>(cap * dim);
-    w.la = WalkList{}; w.lb = WalkList{}; w.list_stride = 0;
-    if (sizeof(Real) == 4) {
-      // k_walk's survivor lists: a slice per workgroup, at most 4096 windows of the hand-off queue at a time
-      const size_t stride = std::min<size_t>(4096, (cap + (size_t)c->n_cus - 1) / (size_t)c->n_cus + 1);
-      const size_t entries = stride * (size_t)c->n_cus;
-      w.list_stride = (int)stride;
-      for (WalkList* l : {&w.la, &w.lb}) {
-        l->gid = cv.take<uint32_t>(entries); l->score = cv.take<float>(entries); l->xy = cv.take<uint32_t>(entries);
-        l->wf = cv.take<uint32_t>(entries); l->hash = trace ? cv.take<uint32_t>(entries) : nullptr;
-        l->shape = cv.take<float>(entries * dim);
-      }
-    }
     w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
 #ifdef JDA_SCAN_TIMING
     w.dbg = cv.take<unsigned long long>(65536 * 32);
@@ -617,9 +583,9 @@ struct TraceOut {              // host arrays, may be null
 };
 
 struct RunStats {
-  long long carts = 0, out = 0, carts_scan = 0, win_scan = 0, tail = 0;
+  long long carts = 0, out = 0, carts_scan = 0, carts_scan_glb = 0, win_scan = 0, tail = 0;
   long long stage_done[kMaxStages] = {0};
-  double gpu_ms = 0, scan_ms = 0;
+  double gpu_ms = 0, scan_ms = 0, scan_lds_ms = 0;
   int scan_launches = 0;
   int dense_passes = 0;
 };
@@ -660,8 +626,8 @@ struct Pass {
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
   // state between the steps
-  bool dense = false, finished = false, walked = false;
-  long long n_tail = -1, n_mid = -1;
+  bool dense = false, finished = false, lds_span = false;
+  long long n_tail = -1;
   size_t n_out = 0;
   std::vector<uint32_t> g; std::vector<Real> sc, sh;
 
@@ -683,24 +649,6 @@ struct Pass {
   const S0Node* s0_tbl() const { return (pe->fast_scan && env_ll("JDA_FIN_S0", 1)) ? pe->table : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
-  // k_walk finishing path: dialect C, split nodes on the original image only, the stage's tables fit LDS
-  bool walk_ok() const {
-    if constexpr (sizeof(Real) != 4) return false;
-    else {
-      const DevModelT<Real>& m = model();
-      return m.off4 != nullptr && !multi && env_ll("JDA_WALK", 0) != 0 &&
-             w.la.gid != nullptr && walk_lds_bytes(m.K, m.node_n, m.leaf_n, m.dim) <= 160 * 1024;
-    }
-  }
-  // the whole finishing path in one persistent launch (queue lengths stay on the device)
-  bool launch_walks() {
-    if constexpr (sizeof(Real) == 4) {
-      JDA_HIP(launch_walk(want_trace(), (int)env_ll("JDA_FIN_G2", stage_groups()), apply_th, th, pe->dp, model(), w, c->n_cus,
-                          (int)env_ll("JDA_WALK_NWIN", 2), st));
-      walked = true;
-    }
-    return true;
-  }
   bool dense_ok(int* pix_cap, int* lds_max) const {
     constexpr int dialect = Sel<Real>::dialect;
     const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
@@ -831,14 +779,13 @@ struct Pass {
           if (!scan(1, l, st)) return false;
         }
       }
+      lds_span = !side_pending && !(((lane & 1) && env_ll("JDA_LANES_REVERSE", 1)) && !small);   // LDS launches first, back to back
+      if (lds_span) JDA_HIP(hipEventRecord(ev[4], st));
       if (any_glb && !scan(2, -1, st)) return false;
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
-    // once a pass on this plan has seen the hand-off count (sparse regime confirmed), the finishing stages are
-    // queued right behind the scan: no host round trip inside the pipeline
-    if (walk_ok() && pe->regime_known) { finished = true; return launch_walks(); }
-    // the hand-off queue length decides sparse / dense and sizes the old finishing launches
+    // the hand-off queue length sizes the finishing launches (one workgroup per window)
     return read_counter(kCntTail);
   }
 
@@ -858,8 +805,6 @@ struct Pass {
       if (!clear_counters()) return false;
       return run_dense();
     }
-    pe->regime_known = true;
-    if (walk_ok()) { finished = true; return launch_walks(); }
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
@@ -867,21 +812,17 @@ struct Pass {
       finished = true;
       return true;
     }
-    // Two launches so that the few windows that pass stage 0 (and then cost whole stages
-    // each) are spread over the machine again.
+    // Two launches so that the few windows that pass stage 0 (and then cost whole stages each) are spread over
+    // the machine again.  The second is queued right behind the first: a window that passes stage 0 stays in its
+    // slot of the queue (the others are marked dead), so no count has to come back to the host in between.
     JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), st));
-    return read_counter(kCntMid);
-  }
-
-  // step 3: stages 1..T-1 of the windows that passed stage 0
-  bool after_mid() {
-    if (finished) return true;
-    JDA_HIP(hipStreamSynchronize(st));
-    n_mid = (long long)std::min<unsigned long long>(h_cnt[0], cap);
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, hm().T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), n_mid, nullptr, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), n_tail, nullptr, st));
     finished = true;
     return true;
   }
+
+  // step 3: (nothing left to wait for between the two finishing launches)
+  bool after_mid() { return true; }
 
   // step 4: counters -> host (asynchronous)
   bool issue_counters() {
@@ -898,6 +839,7 @@ struct Pass {
       for (int i = 0; i < kCntTotal; i++) h_cnt[i] += h_cnt[shd * kCntStride + i];
     rs->carts += (long long)h_cnt[kCntCarts];
     rs->carts_scan += (long long)h_cnt[kCntCartsScan];
+    rs->carts_scan_glb += (long long)h_cnt[kCntCartsScanGlb];
     rs->win_scan += (long long)h_cnt[kCntWinScan];
     for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)h_cnt[kCntStage0 + t];
     rs->tail += (long long)h_cnt[kCntTail];
@@ -906,14 +848,6 @@ struct Pass {
       // fall back to the sparse pipeline when stage 0 rejects most windows after all
       const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
       if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * (double)windows()) pe->dense_hint = false;
-    }
-    if (walked) {
-      // the finishing stages ran without looking at the hand-off count: if most windows turn out to be alive
-      // after the scan, the next pass on this plan goes dense
-      int pix_cap, lds_max;
-      const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
-      const double tail = (double)h_cnt[kCntTail];
-      if (dense_ok(&pix_cap, &lds_max) && tail >= dense_frac * (double)windows() && tail > 4096) pe->dense_hint = true;
     }
     n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;
@@ -973,6 +907,12 @@ struct PendingBatch {
   bool opt_set = false;
   jdaDetectOptions opt{};
   double t_submit = 0;
+  // host-frame submits: the H2D copy (blocking for pageable memory) and the scan launches run on the cascador's
+  // copier thread, so that the submitting thread is free to collect the other ticket meanwhile
+  std::thread issuer;
+  bool issue_ok = true;
+  std::string issue_err;
+  void join_issuer() { if (issuer.joinable()) issuer.join(); }
 };
 
 // test hook: JDA_TEST_WPF_SCALE pretends every frame has that many times more windows (the gid-overflow guard
@@ -1105,6 +1045,10 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       if (hipEventElapsedTime(&ms, ps[0].ev[1], p.ev[2]) == hipSuccess) ms_scan = std::max(ms_scan, ms);
     }
     rs->scan_ms += ms_scan;
+    if (ps.size() == 1 && ps[0].lds_span) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ps[0].ev[1], ps[0].ev[4]) == hipSuccess) rs->scan_lds_ms += ms;
+    }
     // device time of the round: first lane's start to the last lane's end
     float ms_all = 0;
     for (auto& p : ps) {
@@ -1117,7 +1061,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
         float a = 0, b = 0, d = 0;
         (void)hipEventElapsedTime(&a, p.ev[0], p.ev[1]); (void)hipEventElapsedTime(&b, p.ev[1], p.ev[2]);
         (void)hipEventElapsedTime(&d, p.ev[2], p.ev[3]);
-        fprintf(stderr, "[jda] lane %d frames %d: pre %.3f scan %.3f finish %.3f ms (n_tail %lld n_mid %lld)\n", p.lane, p.nf, a, b, d, p.n_tail, p.n_mid);
+        fprintf(stderr, "[jda] lane %d frames %d: pre %.3f scan %.3f finish %.3f ms (n_tail %lld)\n", p.lane, p.nf, a, b, d, p.n_tail);
       }
     }
   }
@@ -1247,6 +1191,7 @@ static void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int 
   st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
   st->handoff_n = rs.tail;
   st->dense_passes = rs.dense_passes;
+  st->scan_lds_ms = rs.scan_lds_ms; st->scan_lds_cart_n = rs.carts_scan - rs.carts_scan_glb;
 }
 
 static jdaResult empty_result(int landmark_n) {
@@ -1345,14 +1290,17 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
 // rest of the pipeline and post-processes it.  A caller that submits batch i+1 before it waits for
 // batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i run.
 static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
-                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt) {
-  if (!c || n <= 0 || !d_frames) { fail("bad arguments"); return -1; }
+                           float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
+                           const unsigned char* const* host_frames = nullptr) {
+  if (!c || n <= 0 || (!d_frames && !host_frames)) { fail("bad arguments"); return -1; }
+  if (host_frames) stride = (((size_t)width * height) + 255) & ~(size_t)255;      // frames of the staging buffer
   if (c->hm.multi_scale()) { fail("submit/wait supports models whose split nodes read the original image only"); return -1; }
   if (!c->pending) c->pending = new PendingBatch[kLanes];
   int slot = -1;
   for (int i = 0; i < kLanes; i++) if (!c->pending[i].active) { slot = i; break; }
   if (slot < 0) { fail("both submit slots are in use: wait for a batch first"); return -1; }
   PendingBatch& pb = c->pending[slot];
+  pb.join_issuer();
   pb = PendingBatch();
   if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &pb.sp, &pb.pe)) return -1;
   const long long wpf = pb.sp.windows;
@@ -1368,6 +1316,13 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
     if (!ensure_workspace<float>(c, cap, false, kLanes)) return -1;
   }
   if (!ensure_lane(c, slot)) return -1;
+  if (host_frames) {
+    // frames still on the host: this ticket's own staging buffer, filled on this ticket's stream (the copy of
+    // batch i+1 then runs next to the kernels of batch i, which live on the other ticket's stream)
+    for (int i = 0; i < n; i++) if (!host_frames[i]) { fail("null frame pointer"); return -1; }
+    if (!c->submit_frames[slot].reserve(stride * (size_t)n)) return -1;
+    d_frames = (const uint8_t*)c->submit_frames[slot].p;
+  }
   pb.n = n; pb.opt_set = opt != nullptr; if (opt) pb.opt = *opt;
   pb.opt.stats = nullptr;
   pb.t_submit = now_ms();
@@ -1380,11 +1335,28 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
   p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
   p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+  if (host_frames) { p.host_frames = host_frames; p.host_fbytes = (size_t)width * height; }
   // opt->hip_stream: the stream the caller produced the frames on -- the scan is ordered behind the work
   // already queued there (the batch itself still runs on the lane's own stream)
   if (opt && opt->hip_stream) {
     if (hipEventRecord(c->ev_user, (hipStream_t)opt->hip_stream) != hipSuccess ||
         hipStreamWaitEvent(p.st, c->ev_user, 0) != hipSuccess) { fail("cannot order the batch behind opt->hip_stream"); return -1; }
+  }
+  if (host_frames && env_ll("JDA_HOST_SUBMIT_THREAD", 1)) {
+    // the copy + scan launches of this ticket on their own thread (joined by Wait): a pageable H2D copy blocks
+    // its caller for the whole transfer (1.8 ms per 256 frames 640x480), time in which the submitting thread can
+    // already collect and post-process the other ticket
+    pb.active = true;
+    pb.issue_ok = true; pb.issue_err.clear();
+    PendingBatch* pbp = &pb;
+    const int dev = c->device;
+    pb.issuer = std::thread([pbp, dev]() {
+      if (hipSetDevice(dev) != hipSuccess || !pbp->pass.issue_scan(nullptr, 0, nullptr, 0, nullptr)) {
+        pbp->issue_ok = false;
+        pbp->issue_err = g_err.empty() ? std::string("issuing the batch failed") : g_err;
+      }
+    });
+    return slot;
   }
   if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) return -1;
   pb.active = true;
@@ -1398,13 +1370,16 @@ static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out)
   const int L = c->hm.L, n = pb.n;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   Pass<float>& p = pb.pass;
-  p.dets = &pb.dets; p.rs = &pb.rs;              // (the PendingBatch may have moved since submit: re-point)
+  pb.join_issuer();
   pb.active = false;
+  if (!pb.issue_ok) { fail(pb.issue_err); return -1; }
+  p.dets = &pb.dets; p.rs = &pb.rs;              // (the PendingBatch may have moved since submit: re-point)
   if (!p.after_tail() || !p.after_mid() || !p.issue_counters() || !p.after_counters() || !p.collect()) return -1;
   float ms_scan = 0, ms_all = 0;
   (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
   (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
   pb.rs.scan_ms += ms_scan; pb.rs.gpu_ms += ms_all;
+  if (p.lds_span) { float ms = 0; if (hipEventElapsedTime(&ms, p.ev[1], p.ev[4]) == hipSuccess) pb.rs.scan_lds_ms += ms; }
   const double post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
   fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
   if (stats) stats->call_ms = now_ms() - pb.t_submit;
@@ -1467,6 +1442,7 @@ void jdaCascadorSerializeTo(void* cascador, const char* model) {
 void jdaCascadorRelease(void* cascador) {
   Cascador* c = (Cascador*)cascador;
   if (!c) return;
+  for (int i = 0; c->pending && i < kLanes; i++) c->pending[i].join_issuer();    // a submitted batch nobody waited for
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
     for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
@@ -1475,6 +1451,7 @@ void jdaCascadorRelease(void* cascador) {
     c->mf.buf.release(); c->md.buf.release();
     c->wf.buf.release(); c->wf.frames.release(); c->wf.pyr.release();
     c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
+    for (auto& b : c->submit_frames) b.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
@@ -1553,6 +1530,21 @@ int jdaDetectBatchSubmit(void* cascador, const unsigned char* d_frames, size_t f
   std::lock_guard<std::mutex> lock(c->mu);
   c->pending_host = nullptr;
   return submit_c_device(c, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt);
+}
+
+int jdaDetectBatchSubmitHost(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                             float scale, float step, int min_size, int max_size, float th,
+                             const jdaDetectOptions* opt) {
+  (void)step;
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmitHost runs dialect C"); return -1; }
+  if (!cascador || !frames) { fail("null cascador or frames"); return -1; }
+  if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->pending_host = nullptr;
+  if (!ensure_device(c)) return -1;
+  return submit_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, frames);
 }
 
 int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* out) {

@@ -522,6 +522,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan
     for (int i = 0; i < NW; i++) { sv += (unsigned)misc[4 + i]; sh += (unsigned)misc[4 + NW + i]; }
     if (sv) atomicAdd(shard_counter(w.counters, kCntCarts), sv);
     atomicAdd(shard_counter(w.counters, kCntCartsScan), sv + sh);
+    if (GLB) atomicAdd(shard_counter(w.counters, kCntCartsScanGlb), sv + sh);
     atomicAdd(shard_counter(w.counters, kCntWinScan), (unsigned long long)(twe * the));
   }
 #ifdef JDA_SCAN_TIMING

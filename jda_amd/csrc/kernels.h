@@ -21,6 +21,7 @@ namespace jda {
 
 constexpr int kMaxLevels = 64;
 constexpr int kMaxStages = 16;
+constexpr uint32_t kDeadSlot = 0xffffffffu;   // gid of a mid-queue slot whose window did not pass stage 0
 
 struct DevLevel {
   int win, step, nx, ny;
@@ -83,17 +84,6 @@ struct DevModelT {
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
   int similarity;          // dialect CPP: Config::with_similarity_transform
-  // compact split nodes for k_walk (dialect C, scale == 0 models; null otherwise): 20 bytes per node
-  const float* off4;       // [T*K*node_n][4]  o1x, o1y, o2x, o2y
-  const uint32_t* meta;    // [T*K*node_n]     lm1*2 | lm2*2 << 8 | (th clamped to [-256,255]) + 256 << 16
-  int wpitch;              // elements between rows of w (= dim)
-};
-
-// A list of windows between two stages of the finishing path (k_walk): every workgroup owns the slice
-// [blockIdx * list_stride, (blockIdx + 1) * list_stride) of it.
-struct WalkList {
-  uint32_t* gid; float* score; uint32_t* xy; uint32_t* wf; uint32_t* hash;
-  float* shape;              // [entries][dim]
 };
 
 // Device buffers of one pass over a sub-batch of frames.
@@ -113,8 +103,6 @@ struct WorkT {
   int* st_carts;
   // final detections: windows that passed every cart and the final threshold
   uint32_t* out_gid; Real* out_score; Real* out_shape;
-  // k_walk's two survivor lists (dialect C only; null otherwise): n_cus * list_stride entries each
-  WalkList la, lb; int list_stride;
   // per-window trace (all null when off), indexed by gid
   int* tr_carts; Real* tr_score; uint32_t* tr_hash; Real* tr_shape;
   unsigned cap;                                                // capacity of every per-window array
@@ -136,7 +124,7 @@ enum Counter : int {
   kCntCarts = kMaxStages + 2,      // carts evaluated, reference counting (Validate's n)
   kCntCartsScan = kMaxStages + 3,  // carts evaluated inside k_scan
   kCntWinScan = kMaxStages + 4,    // windows k_scan covered
-  kCntMid = kMaxStages + 5,        // length of the mid queue (allocator, shard 0 only)
+  kCntCartsScanGlb = kMaxStages + 5,  // carts evaluated inside k_scan's global-pixel launches
   kCntTotal = kMaxStages + 6
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
@@ -181,14 +169,6 @@ hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
                          int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream);
 // s0_table: the plan's resolved stage-0 tables (or null): stage 0 of windows from levels that have one walks from it
-
-// Finishing path of dialect C (k_walk): every window of the hand-off queue through the rest of the cascade,
-// n_blocks persistent workgroups (one per CU; must equal the n_cus the lists of `w` were carved for).
-// groups = 64-cart groups walked per round by a window that has passed its first round; nwin = windows of the
-// hand-off queue a wave walks in lockstep (2 or 4).
-hipError_t launch_walk(bool trace, int groups, bool apply_final_th, float final_th, const DevPlan* d_plan,
-                       const DevModelT<float>& m, const WorkT<float>& w, int n_blocks, int nwin, hipStream_t stream);
-size_t walk_lds_bytes(int K, int node_n, int leaf_n, int dim);   // LDS a k_walk workgroup needs (<= 160 KiB or the old path runs)
 
 // Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
 // pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).

@@ -878,3 +878,44 @@ def test_submit_wait_all_pass_model_takes_the_dense_path(built, gpu, model_file)
     for a, b in zip(got, want):
         _compare_detect(a, b)
     assert sg["cart_total_n"] == sw["cart_total_n"] and sg["dense_passes"] >= 1
+
+
+def test_submit_host_frames_pageable_and_pinned(built, gpu, model_file):
+    """jdaDetectBatchSubmitHost: frames in host memory staged per ticket (pageable: the copy blocks the submit;
+    pinned: asynchronous), two batches in flight, same detections as the synchronous host-frame entry."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=111, cart_th=-0.9, norm_every=9)
+    frames = synth.make_frames(8, 240, 180, seed=112)
+    c = api.Cascador(p)
+    want = c.detect_batch(frames)
+    pinned = torch.from_numpy(frames[4:]).pin_memory()
+    ta = c.submit_batch_host(frames[:4])
+    tb = c.submit_batch_host(pinned.numpy())
+    got = c.wait_batch(ta) + c.wait_batch(tb)
+    assert len(got) == 8
+    for x, y in zip(got, want):
+        _compare_detect(x, y)
+    # a stream of host batches, one ahead, alternating with a device-resident one
+    d = torch.from_numpy(frames[:4]).cuda()
+    t = c.submit_batch_host(frames[4:])
+    t2 = c.submit_batch_device(d)
+    for x, y in zip(c.wait_batch(t), want[4:]):
+        _compare_detect(x, y)
+    for x, y in zip(c.wait_batch(t2), want[:4]):
+        _compare_detect(x, y)
+
+
+def test_batch_too_large_for_32bit_window_ids_is_refused(built, gpu, model_file, monkeypatch):
+    """Detections carry a 32-bit window id over the whole batch; a batch whose frames x windows exceeds 2^32
+    must fail loudly instead of wrapping (JDA_TEST_WPF_SCALE inflates the count the guard sees)."""
+    from jda_amd import api, synth
+    p, _ = model_file((2, 8, 5, 3), 8, seed=5)
+    frames = synth.make_frames(2, 100, 80, seed=6)
+    c = api.Cascador(p)
+    assert len(c.detect_batch(frames)) == 2
+    monkeypatch.setenv("JDA_TEST_WPF_SCALE", "1000000000")
+    with pytest.raises(api.JdaError, match="batch too large"):
+        c.detect_batch(frames)
+    monkeypatch.delenv("JDA_TEST_WPF_SCALE")
+    assert len(c.detect_batch(frames)) == 2
