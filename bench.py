@@ -179,6 +179,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gather_kind = ["none (one rank)"]
+
+    def make_gather():
+        """The gather of (bbox, score, landmarks) rows on rank 0, one collective per step, pipelined one step behind the
+        detection.  N > 1 over RCCL: the C entry points of libjda_dist.so (include/jda_dist.h: jdaDistGatherStart /
+        jdaDistGatherCollect on the library's own communicator); if that library cannot be set up on every rank, the
+        same exchange through torch.distributed (jda_amd/dist.py:PipelinedGather)."""
+        width = 5 + 2 * L
+        if world > 1 and backend == "nccl" and os.environ.get("JDA_BENCH_GATHER", "c") == "c":
+            ok = 1
+            try:
+                jdist.dist_lib()
+            except Exception:
+                ok = 0
+            head = torch.zeros(129, dtype=torch.uint8, device=dev)
+            if rank == 0 and ok:
+                try:
+                    head[1:] = torch.frombuffer(bytearray(jdist.unique_id()), dtype=torch.uint8).to(dev)
+                    head[0] = 1
+                except Exception:
+                    pass
+            dist.broadcast(head, 0)
+            flag = torch.tensor([ok if int(head[0].item()) == 1 else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                g = jdist.CGather(rank, world, head[1:].cpu().numpy().tobytes(), local_rank, width, 4096)
+                return g, "libjda_dist.so: jdaDistGatherStart/Collect (ncclAllGather of fixed blocks on the library's communicator)"
+        kind = "torch.distributed all_gather (%s)" % backend if world > 1 else "none (one rank)"
+        return jdist.PipelinedGather(4096, width, device=gather_dev), kind
+
     def run_regime(regime, steps, warmup, th, lanes=None, depth=1):
         """lanes=1 serialises the library's two sub-batch lanes and keeps the global-pixel launch on the lane's own
         stream (JDA_LANES=1, JDA_SIDE_STREAM=0): the k_scan launches then run back to back and the HIP-event span
@@ -207,7 +237,7 @@ def main():
         # pipelined one step behind: the collective of step i runs on the communicator's stream while step i+1
         # detects and is collected (counts, valid rows -> host on rank 0) by step i+1; the last one is drained
         # before the closing barrier, so all K gathers complete inside the timed region.
-        gather = jdist.PipelinedGather(4096, 5 + 2 * L, device=gather_dev)
+        gather, gather_kind[0] = make_gather()
 
         counter = [0]
 
@@ -295,6 +325,8 @@ def main():
         }
         for c in cascs:
             c.close()
+        if hasattr(gather, "close"):
+            gather.close()
         return info, mp
 
     casc_info, casc_model = run_regime("cascade", args.steps, args.warmup, call["th"], depth=args.depth)
@@ -378,6 +410,7 @@ def main():
                                    % (B, W, H, T, K, L, D),
                        "batch_per_gpu": B, "width": W, "height": H, "windows_per_frame": wpf, "levels": n_levels,
                        "model_dims_TKLD": list(dims), "regime": "cascade", "sharding": "frames, %d rank(s)" % world,
+                       "gather": gather_kind[0],
                        "distinct_resident_batches": R, "resident_frame_bytes": R * B * W * H,
                        "batches_in_flight_per_gpu": casc_info["batches_in_flight"],
                        "single_caller_ms_per_step": single_info["ms_per_step"],

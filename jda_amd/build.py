@@ -69,6 +69,21 @@ def _build(lib, objdir, extra, force=False, verbose=False):
     return lib
 
 
+DIST_LIB = os.path.join(HERE, "libjda_dist.so")
+
+
+def build_dist(force=False):
+    """libjda_dist.so: the RCCL gather of detection rows (include/jda_dist.h), its own library so that
+    libjda.so depends on the HIP runtime only."""
+    src = os.path.join(CSRC, "dist.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "jda_dist.h"), os.path.join(HERE, "..", "include", "jda.h")]
+    if not force and os.path.exists(DIST_LIB) and all(os.path.getmtime(DIST_LIB) >= os.path.getmtime(d) for d in deps):
+        return DIST_LIB
+    subprocess.check_call([hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DJDA_EXPORTS", "-Wall",
+                           "-o", DIST_LIB, src, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+    return DIST_LIB
+
+
 def build_timing():
     """Investigation build with shader-clock stamps in k_scan (tools/scan_timing.py); never the product."""
     return _build(os.path.join(HERE, "libjda_timing.so"), OBJDIR + "_timing", ["-DJDA_SCAN_TIMING"])
@@ -84,3 +99,4 @@ if __name__ == "__main__":
     if "--timing" in sys.argv:
         print(build_timing()); sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_dist(force="--force" in sys.argv))

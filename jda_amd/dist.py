@@ -189,3 +189,105 @@ class PipelinedGather:
         else:
             parts = [self.allb[s][r][1:1 + counts[r]].cpu().numpy() for r in range(self.world)]
         return np.concatenate(parts) if parts else np.zeros((0, self.width), np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# the C entry (include/jda_dist.h, jda_amd/libjda_dist.so): the same gather for C callers, over RCCL
+# ---------------------------------------------------------------------------------------------
+
+_dist_lib = None
+
+
+def dist_lib():
+    """ctypes handle of libjda_dist.so (raises when it is not built: `python -m jda_amd.build`)."""
+    global _dist_lib
+    if _dist_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjda_dist.so")
+        if not os.path.exists(path):
+            raise ImportError("jda_amd: %s is missing -- build it with `python -m jda_amd.build`" % path)
+        L = C.CDLL(path)
+        fpp = C.POINTER(C.POINTER(C.c_float))
+        L.jdaDistUniqueId.argtypes = [C.c_char_p]
+        L.jdaDistCreate.restype = C.c_void_p
+        L.jdaDistCreate.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.jdaDistDestroy.argtypes = [C.c_void_p]
+        L.jdaDistLastError.restype = C.c_char_p
+        L.jdaDistGatherRows.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, fpp, C.POINTER(C.c_int)]
+        L.jdaDistGatherStart.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.jdaDistGatherCollect.argtypes = [C.c_void_p, fpp, C.POINTER(C.c_int)]
+        L.jdaDistPending.argtypes = [C.c_void_p]
+        L.jdaDistFree.argtypes = [C.POINTER(C.c_float)]
+        _dist_lib = L
+    return _dist_lib
+
+
+def unique_id():
+    """128 rendezvous bytes made on rank 0 (ncclGetUniqueId); hand them to the other ranks."""
+    import ctypes as C
+    buf = C.create_string_buffer(128)
+    if dist_lib().jdaDistUniqueId(buf) != 0:
+        raise RuntimeError("jdaDistUniqueId: %s" % dist_lib().jdaDistLastError().decode())
+    return buf.raw
+
+
+class CGather:
+    """PipelinedGather's interface on top of the C entry points: start(mat) launches this rank's gather
+    (jdaDistGatherStart) and returns what the previous start gathered; drain() finishes the one in flight."""
+
+    def __init__(self, rank, world, id_bytes, device, width, max_rows):
+        self.L = dist_lib()
+        self.width = width
+        self.h = self.L.jdaDistCreate(rank, world, id_bytes, device, width, max_rows)
+        if not self.h:
+            raise RuntimeError("jdaDistCreate: %s" % self.L.jdaDistLastError().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jdaDistDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _take(self, rc, out, n):
+        import ctypes as C
+        if rc != 0:
+            raise RuntimeError("libjda_dist: %s" % self.L.jdaDistLastError().decode())
+        if not out:
+            return None
+        mat = np.ctypeslib.as_array(out, (max(n.value, 0), self.width)).copy() if n.value else np.zeros((0, self.width), np.float32)
+        self.L.jdaDistFree(out)
+        return mat
+
+    def gather(self, mat):
+        """Blocking exact gather (jdaDistGatherRows): all rows on rank 0, None elsewhere."""
+        import ctypes as C
+        mat = np.ascontiguousarray(mat, np.float32)
+        out, n = C.POINTER(C.c_float)(), C.c_int()
+        rc = self.L.jdaDistGatherRows(self.h, mat.ctypes.data_as(C.POINTER(C.c_float)), mat.shape[0], C.byref(out), C.byref(n))
+        return self._take(rc, out, n)
+
+    def start(self, mat):
+        import ctypes as C
+        prev = self._collect() if self.L.jdaDistPending(self.h) >= 1 else None
+        mat = np.ascontiguousarray(mat, np.float32)
+        if self.L.jdaDistGatherStart(self.h, mat.ctypes.data_as(C.POINTER(C.c_float)), mat.shape[0]) != 0:
+            raise RuntimeError("libjda_dist: %s" % self.L.jdaDistLastError().decode())
+        return prev
+
+    def _collect(self):
+        import ctypes as C
+        out, n = C.POINTER(C.c_float)(), C.c_int()
+        rc = self.L.jdaDistGatherCollect(self.h, C.byref(out), C.byref(n))
+        return self._take(rc, out, n)
+
+    def drain(self):
+        last = None
+        while self.L.jdaDistPending(self.h) > 0:
+            last = self._collect()
+        return last

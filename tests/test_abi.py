@@ -103,3 +103,20 @@ def test_cmake_target_builds_the_same_library(tmp_path):
     for n in declared_symbols():
         assert hasattr(lib, n), n
     assert os.path.exists(os.path.join(b, "jda-test"))
+
+
+def test_dist_library_exports_its_header(built):
+    """libjda_dist.so (RCCL gather of detection rows): loads without a GPU and exports every symbol of include/jda_dist.h;
+    libjda.so itself does not depend on RCCL."""
+    from jda_amd import build as lib_build
+    from jda_amd import dist as jd
+    lib_build.build_dist()
+    src = open(os.path.join(ROOT, "include", "jda_dist.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"JDA_API\s+[^;(]*?\b(jda\w+)\s*\(", src)
+    assert len(names) >= 9
+    L = jd.dist_lib()
+    for n in names:
+        assert hasattr(L, n), n
+    deps = subprocess.run(["readelf", "-d", os.path.join(ROOT, "jda_amd", "libjda.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in deps and "torch" not in deps

@@ -919,3 +919,50 @@ def test_batch_too_large_for_32bit_window_ids_is_refused(built, gpu, model_file,
         c.detect_batch(frames)
     monkeypatch.delenv("JDA_TEST_WPF_SCALE")
     assert len(c.detect_batch(frames)) == 2
+
+
+def test_c_gather_entry_over_rccl_group_of_one(built, gpu, model_file):
+    """include/jda_dist.h through libjda_dist.so on its own RCCL communicator (a group of one rank -- all a 1-GPU box
+    can host): the exact gather, the pipelined one (empty, full and overflowing blocks -> exact fallback) and the
+    gather of jdaResult arrays straight from a detect call."""
+    import ctypes as C
+    from jda_amd import api, synth, dist as jd
+    from jda_amd import build as lib_build
+    lib_build.build_dist()
+    g = jd.CGather(0, 1, jd.unique_id(), 0, 7, 16)
+    m = np.arange(5 * 7, dtype=np.float32).reshape(5, 7)
+    assert np.array_equal(g.gather(m), m)
+    assert g.gather(np.zeros((0, 7), np.float32)).shape == (0, 7)
+    outs = []
+    for step in range(4):
+        n = [3, 0, 40, 16][step]
+        mm = np.full((n, 7), step + 1, np.float32); mm[:, 0] = np.arange(n)
+        outs.append(g.start(mm))
+    outs.append(g.drain())
+    assert outs[0] is None
+    for step, got in enumerate(outs[1:]):
+        n = [3, 0, 40, 16][step]
+        assert got.shape == (n, 7) and (got[:, 1:] == step + 1).all() and list(got[:, 0]) == list(range(n)), (step, got.shape)
+    g.close()
+    # jdaGatherResults: per-frame results of a detect call -> rows on rank 0 == jdaResultsPack's rows
+    p, _ = model_file((3, 20, 5, 4), 8, seed=3, cart_th=-1.0)
+    frames = synth.make_frames(3, 200, 150, seed=9)
+    c = api.Cascador(p)
+    n = len(frames)
+    ptrs = (C.POINTER(C.c_ubyte) * n)(*[frames[i].ctypes.data_as(C.POINTER(C.c_ubyte)) for i in range(n)])
+    res = (api.jdaResult * n)()
+    o = api.jdaDetectOptions(); api.lib.jdaDetectOptionsInit(C.byref(o))
+    assert api.lib.jdaDetectBatch(c.h, ptrs, n, 200, 150, 1.25, 0.1, 40, -1, -0.5, C.byref(o), res) == 0
+    rows = api.lib.jdaResultsPack(res, n, 100, None, 0)
+    want = np.empty((rows, 5 + c.dim), np.float32)
+    api.lib.jdaResultsPack(res, n, 100, want.ctypes.data_as(C.POINTER(C.c_float)), rows)
+    L = jd.dist_lib()
+    L.jdaGatherResults.argtypes = [C.c_void_p, C.POINTER(api.jdaResult), C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+    h = L.jdaDistCreate(0, 1, jd.unique_id(), 0, 5 + c.dim, 64)
+    assert h
+    out, cnt = C.POINTER(C.c_float)(), C.c_int()
+    assert L.jdaGatherResults(h, res, n, 100, C.byref(out), C.byref(cnt)) == 0
+    got = np.ctypeslib.as_array(out, (cnt.value, 5 + c.dim)).copy()
+    L.jdaDistFree(out); L.jdaDistDestroy(h)
+    api.lib.jdaResultsRelease(res, n)
+    assert rows > 0 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
