@@ -152,6 +152,7 @@ struct Cascador {
   hipEvent_t ev_user = nullptr;
   hipStream_t side[kLanes] = {nullptr, nullptr};            // global-pixel scan launch of a lane, next to its LDS-tiled launches
   hipEvent_t ev_side[kLanes][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipStream_t fin[kLanes] = {nullptr, nullptr};             // high-priority stream of a lane's finishing kernels (JDA_FIN_PRIO)
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -220,9 +221,24 @@ static bool ensure_lane(Cascador* c, int lane) {
   return true;
 }
 
+// a stream of the highest priority the device offers: the texture-addresser-bound kernels (global-pixel scan,
+// finishing kernels) get their workgroups placed first whenever the LDS-bound scan of the other batch frees slots
+static hipError_t create_priority_stream(hipStream_t* s, bool high) {
+  int least = 0, greatest = 0;
+  if (!high || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
+static bool ensure_fin(Cascador* c, int lane) {
+  if (c->fin[lane]) return true;
+  JDA_HIP(create_priority_stream(&c->fin[lane], true));
+  return true;
+}
+
 static bool ensure_side(Cascador* c, int lane) {
   if (c->side[lane]) return true;
-  JDA_HIP(hipStreamCreateWithFlags(&c->side[lane], hipStreamNonBlocking));
+  JDA_HIP(create_priority_stream(&c->side[lane], env_ll("JDA_SIDE_PRIO", 0) != 0));
   for (auto& ev : c->ev_side[lane]) JDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   return true;
 }
@@ -805,6 +821,9 @@ struct Pass {
       if (!clear_counters()) return false;
       return run_dense();
     }
+    // the scan is done (the host has just waited for it): the finishing kernels, the counters and the results
+    // may go to the lane's high-priority stream
+    if (env_ll("JDA_FIN_PRIO", 0) && ensure_fin(c, lane)) st = c->fin[lane];
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
@@ -813,10 +832,13 @@ struct Pass {
       return true;
     }
     // Two launches so that the few windows that pass stage 0 (and then cost whole stages each) are spread over
-    // the machine again.  The second is queued right behind the first: a window that passes stage 0 stays in its
-    // slot of the queue (the others are marked dead), so no count has to come back to the host in between.
+    // the machine again.  The second is queued right behind the first, without a host round trip for the length
+    // of the mid queue (the kernel reads it from the device counter): its grid is a quarter of the hand-off count
+    // -- one workgroup per window as long as fewer than 25 % pass stage 0 (6.7 % in the cascade regime), a grid-stride
+    // loop beyond that; the surplus workgroups exit at once (an empty workgroup costs ~1.3 ns of dispatcher time).
     JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), st));
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), n_tail, nullptr, st));
+    const long long wg2 = std::min<long long>(n_tail, std::max<long long>(2048, n_tail / std::max<long long>(1, env_ll("JDA_FIN_GRID_DIV", 4))));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), wg2, nullptr, st));
     finished = true;
     return true;
   }
@@ -1457,6 +1479,7 @@ void jdaCascadorRelease(void* cascador) {
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
     for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
     for (auto& st : c->side) if (st) (void)hipStreamDestroy(st);
+    for (auto& st : c->fin) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& l : c->ev_side) for (auto& ev : l) if (ev) (void)hipEventDestroy(ev);
   }
   delete[] c->pending;

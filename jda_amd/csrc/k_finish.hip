@@ -229,15 +229,11 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   const int lane = threadIdx.x;
   if (lane < kMaxStages) stage_cnt[lane] = 0;
   const bool from_scan = t_begin == 0;
-  // the mid queue has the hand-off queue's index space: a window that passes stage 0 is parked in ITS OWN slot
-  // (no allocator: a same-address device atomic per survivor serialises at 13-40 ns each, and the host would
-  // have to read the count before it could size the next launch); the other slots are marked dead
-  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)w.cap);
   unsigned long long carts_acc = 0;
 
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
     const uint32_t gid = from_scan ? w.q_gid[i] : w.m_gid[i];
-    if (!from_scan && gid == kDeadSlot) continue;       // (workgroup-uniform)
     Real score = from_scan ? w.q_score[i] : w.m_score[i];
     const int kstart = from_scan ? (int)w.q_kstart[i] : 0;
     unsigned hash = kFnvSeed;
@@ -385,12 +381,15 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         }
       }
     } else {
-      // alive with stages left: park it in its slot of the mid queue for the next launch
-      const unsigned o = i;
-      if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; w.m_xy[o] = xy; w.m_wf[o] = wf; if (TRACE) w.m_hash[o] = hash; }
-      for (int d = lane; d < dim; d += 64) w.m_shape[(size_t)o * dim + d] = sh[d];
+      // alive with stages left: park it in the mid queue for the next launch
+      unsigned o = 0;
+      if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
+      o = (unsigned)__shfl((int)o, 0);
+      if (o < w.cap) {
+        if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; w.m_xy[o] = xy; w.m_wf[o] = wf; if (TRACE) w.m_hash[o] = hash; }
+        for (int d = lane; d < dim; d += 64) w.m_shape[(size_t)o * dim + d] = sh[d];
+      }
     }
-    if (from_scan && t_end < T && !alive && lane == 0) w.m_gid[i] = kDeadSlot;
   }
   __syncthreads();
   if (lane < T && stage_cnt[lane]) atomicAdd(shard_counter(w.counters, kCntStage0 + lane), (unsigned long long)stage_cnt[lane]);

@@ -556,10 +556,14 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
   if (L.total > 160 * 1024) return hipErrorInvalidValue;
   const int groups = (w.n_frames + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * tiles)), block(BLOCK);
+  // JDA_SCAN_LDS_PAD (experiment): ask for at least that much LDS per workgroup of an LDS-tiled launch, i.e. cap
+  // its workgroups per CU, leaving wave slots and LDS to the kernels of the other batch in flight
+  int lds_req = L.total;
+  if (MODE == 1) if (const char* e = getenv("JDA_SCAN_LDS_PAD")) lds_req = std::min(160 * 1024, std::max(lds_req, atoi(e)));
   auto go = [&](auto kern) {
-    if (L.total > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-    hipLaunchKernelGGL(kern, grid, block, L.total, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
+    if (lds_req > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+    hipLaunchKernelGGL(kern, grid, block, lds_req, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
                        pix_bytes, handoff, chunk, cp_max, opts);
   };
   if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);

@@ -21,7 +21,6 @@ namespace jda {
 
 constexpr int kMaxLevels = 64;
 constexpr int kMaxStages = 16;
-constexpr uint32_t kDeadSlot = 0xffffffffu;   // gid of a mid-queue slot whose window did not pass stage 0
 
 struct DevLevel {
   int win, step, nx, ny;
@@ -124,8 +123,9 @@ enum Counter : int {
   kCntCarts = kMaxStages + 2,      // carts evaluated, reference counting (Validate's n)
   kCntCartsScan = kMaxStages + 3,  // carts evaluated inside k_scan
   kCntWinScan = kMaxStages + 4,    // windows k_scan covered
-  kCntCartsScanGlb = kMaxStages + 5,  // carts evaluated inside k_scan's global-pixel launches
-  kCntTotal = kMaxStages + 6
+  kCntMid = kMaxStages + 5,        // length of the mid queue (allocator, shard 0 only)
+  kCntCartsScanGlb = kMaxStages + 6,  // carts evaluated inside k_scan's global-pixel launches
+  kCntTotal = kMaxStages + 7
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
