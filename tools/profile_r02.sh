@@ -9,6 +9,7 @@ cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --no-cpu --no-allpass > $O/bench_run2.json 2>> $O/bench.err
 python bench.py --no-cpu --no-allpass > $O/bench_run3.json 2>> $O/bench.err
+[ -x tools/lds_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/lds_bench tools/lds_bench.hip
 tools/lds_bench > $O/lds_bench.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 V="python $R/tools/variants.py"
