@@ -1,0 +1,31 @@
+"""PCIe-inclusive step of BASELINE.json configs[1] (frames in host memory, jdaDetectBatchSubmitHost / Wait, two batches
+in flight) under several settings:  python tools/host_variants.py "NAME=V NAME=V" ...   (pageable and pinned sources)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from jda_amd import synth, api
+import bench
+dims = (5, 540, 27, 4)
+mp = bench.model_path(dims, "cascade", 1, synth.make_frames(8, 640, 480, seed=0, first=10_000_000))
+src = [synth.make_frames(256, 640, 480, seed=0, first=j * 256) for j in range(2)]
+pin = [torch.from_numpy(f).pin_memory() for f in src]
+wpf = api.count_windows(640, 480, 1.25, 40, -1)[0]
+base = dict(os.environ)
+for spec in (sys.argv[1:] or [""]):
+    os.environ.clear(); os.environ.update(base)
+    for kv in spec.split():
+        k, v = kv.split("=", 1); os.environ[k] = v
+    out = []
+    for name, frames in (("pageable", src), ("pinned", [p.numpy() for p in pin])):
+        c = api.Cascador(mp)
+        t = c.submit_batch_host(frames[0])
+        for i in range(3):
+            nxt = c.submit_batch_host(frames[(i + 1) % 2]); c.wait_batch(t, keep_results="packed"); t = nxt
+        torch.cuda.synchronize(); t0 = time.perf_counter(); steps = 30
+        for i in range(steps):
+            nxt = c.submit_batch_host(frames[i % 2]) if i + 1 < steps else None
+            c.wait_batch(t, keep_results="packed"); t = nxt
+        el = (time.perf_counter() - t0) / steps
+        out.append("%s %.3f ms %.2e win/s" % (name, el * 1e3, wpf * 256 / el))
+        c.close()
+    print("%-50s %s" % (spec or "(defaults)", "   ".join(out)), flush=True)
