@@ -130,6 +130,7 @@ def main():
                          "1 = one synchronous call per step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
+    ap.add_argument("--no-x", action="store_true", help="skip the configs[4] all-pass leg (roofline_hbm_regime)")
     args = ap.parse_args()
 
     import torch
@@ -368,6 +369,40 @@ def main():
         host_info = {"pageable_windows_per_s": host_leg(False, hs), "pinned_windows_per_s": host_leg(True, hs), "steps": hs,
                      "entry": "jdaDetectBatchSubmitHost / jdaDetectBatchWait, two batches in flight"}
 
+    # ---- the regime of this path in which HBM / Infinity Cache traffic is the bound: BASELINE.json configs[4] (T=7, K=2000,
+    #      68 landmarks, depth 6: W = 243.7 MB, 34.8 MB per stage) with every window of a 1080p frame walking all 14,000
+    #      carts -- each window gathers K 544-byte weight rows per stage, far more than L2 holds ----
+    x_info = None
+    if rank == 0 and world == 1 and not args.no_allpass and not args.no_x:
+        try:
+            xd = (7, 2000, 68, 6)
+            xp = os.path.join(synth.cache_dir(), "x_allpass.model")
+            if not os.path.exists(xp):
+                synth.make_model(*xd, seed=2).save(xp + ".tmp", 4)
+                os.replace(xp + ".tmp", xp)
+            xc = api.Cascador(xp, "float", device=local_rank)
+            xf = torch.from_numpy(synth.make_frames(1, 1920, 1080, seed=4)).to(dev)
+            for _ in range(2):
+                xc.detect_batch_device(xf, th=float("inf"), keep_results=False)
+            barrier(); t0 = time.perf_counter()
+            _, xs = xc.detect_batch_device(xf, th=float("inf"), keep_results=False, stats=True)
+            barrier(); xel = time.perf_counter() - t0
+            xc.close()
+            xalg = algorithmic_bytes(xd, xs["cart_total_n"], xs["stage_done_n"][:7], xs["patch_n"], 0)
+            x_info = {"workload": "BASELINE.json configs[4]: T=7 K=2000 L=68 D=6 (float model 259.6 MB), one 1920x1080 frame, canonical "
+                                  "call, every cart threshold -inf (all-pass): 303,222 windows x 14,000 carts",
+                      "ms_per_step": xel * 1e3, "windows_per_s": xs["patch_n"] / xel, "carts_per_s": xs["cart_total_n"] / xel,
+                      "bound": "hbm", "achieved": xalg / xel / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": xalg / xel / 1e9 / HBM_PEAK_GBPS,
+                      "algorithmic_bytes_per_window": xalg / max(1, xs["patch_n"]),
+                      "traffic": None, "traffic_source": "profiles/r02_x_allpass.txt (builder-run rocprofv3 --pmc FETCH_SIZE of "
+                                 "tools/x_allpass.py: 2.55e9 KiB per k_finish dispatch), not measured in this run",
+                      "note": "achieved = SURVEY 8(d) algorithmic bytes (10.2 MB per window: 186 B per cart + K weight rows per stage) "
+                              "/ wall time of one jdaDetectBatchDevice call; the 34.8 MB of a stage's weight rows exceed L2 (4 MB per "
+                              "XCD) and are served by the Infinity Cache / HBM"}
+        except Exception as e:
+            x_info = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
@@ -439,6 +474,7 @@ def main():
                          "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0: the launches of a step run back to back on one "
                                           "stream, HIP events recorded on that stream before the first and after the last "
                                           "LDS-tiled launch (jdaStats.scan_lds_ms); the throughput legs overlap two batches"},
+            "roofline_hbm_regime": x_info,
             "cpu_baseline": cpu,
             "regimes": {"cascade": casc_info, "cascade_single_caller": single_info, "cascade_one_lane": roof_info,
                         "allpass": allpass_info, "host_frames": host_info},
