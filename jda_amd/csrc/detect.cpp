@@ -455,8 +455,22 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
       if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
         d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
       } else if (glb_ok) {
-        // no LDS tile: k_scan reads the frame through L1/L2 (the offsets fit the packed node)
+        // no LDS tile: k_scan reads the frame through L1/L2 (the offsets fit the packed node).  The tile is only a
+        // grouping of up to 512 windows per workgroup here: the shape that wastes the fewest lane slots of the
+        // first phase (a fixed 32 x 16 filled about half of them on the big-window levels of 640x480)
         d.tiled = 2; d.tw = 32; d.th = 16; d.pitch = sp.width;
+        if (env_ll("JDA_GLB_TILE_FIT", 1)) {
+          long long best = -1;
+          for (int th = 1; th <= std::min(s.ny, 512); th++)
+            for (int tw = 1; tw <= std::min(s.nx, 512) && tw * th <= 512; tw++) {
+              const int n_tile = tw * th;
+              int slots = (n_tile + 63) & ~63;
+              if (n_tile <= cp_max) { slots = 16; while (slots < n_tile) slots *= 2; }
+              const long long tiles = (long long)((s.nx + tw - 1) / tw) * ((s.ny + th - 1) / th);
+              const long long cost = tiles * (slots + 96);          // (+ a fixed cost per workgroup: table load, barriers)
+              if (best < 0 || cost < best) { best = cost; d.tw = tw; d.th = th; }
+            }
+        }
       }
       if (env_ll("JDA_DEBUG_TILES", 0))
         std::fprintf(stderr, "[jda] level %d win %d step %d windows %dx%d: mode %d tile %dx%d pitch %d pix %d lds %d block %d cost/window %.0f\n",
