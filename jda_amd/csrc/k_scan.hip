@@ -99,8 +99,11 @@ __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const u
 
 }  // namespace
 
+// Registers: three 512-thread workgroups per CU are 6 waves per SIMD, which 80 VGPRs still allow and 82 do not (a
+// two-register creep cost 0.17 ms per step in an r02 experiment) -- the occupancy the LDS footprint permits is pinned.
 template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 6 : 4)))
+void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                                 const S0Node* __restrict__ table, WorkT<Real> w,
                                                 int level, int tiles_total, int pix_bytes, int handoff, int chunk,
                                                 int cp_max, int opts) {
