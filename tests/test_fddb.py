@@ -136,3 +136,42 @@ def test_fddb_end_to_end_gpu(built, model_file, tmp_path, dialect):
             total += len(r["scores"])
         assert open(fddb.fold_out_path(d, i)).read() == want, i
     assert total > 0 and sum(s.face_patch_n for s in stats.values()) >= total
+
+
+@pytest.mark.gpu
+def test_config3_fddb_sized_job_in_eight_shards(built, tmp_path):
+    """BASELINE.json configs[3] at its stated size on the one GPU a test box has: 2,845 images of FDDB-like sizes
+    (<= 450x450, every one its own scan plan), shipped model dimensions in the cascade regime, sharded into the 8
+    contiguous blocks the 8 ranks would own (floor(i*G/N)), each block detected and packed into the
+    rows a rank hands to the gather; the concatenation in rank order is the job's result in image order, and a
+    sample of images is compared with the oracle (reference c/jda.c:443-480).  The RCCL exchange itself needs one
+    GPU per rank: tests/test_gpu_parity.py::test_c_gather_entry_over_rccl_group_of_one, tests/test_dist_gloo.py."""
+    from jda_amd import api, synth, dist as jd
+    from oracle.pyoracle import Oracle
+    from conftest import S_DIMS, same
+    n_images, world = 2845, 8
+    rng = np.random.default_rng(3)
+    sizes = [(int(rng.integers(120, 451)), int(rng.integers(120, 451))) for _ in range(n_images)]
+    m = synth.make_model(*S_DIMS, seed=1)
+    synth.calibrate_thresholds(m, synth.make_frames(8, 450, 450, seed=0, first=10_000_000))
+    p = str(tmp_path / "fddb.model"); m.save(p, 8)
+    c, o = api.Cascador(p), Oracle(p)
+    images = [synth.make_frames(1, w, h, seed=5, first=i)[0] for i, (w, h) in enumerate(sizes)]
+    blocks, owned = [], 0
+    for r in range(world):
+        lo, hi = jd.shard_range(n_images, r, world)
+        assert 355 <= hi - lo <= 356                                    # ceil(2845 / 8) per GPU
+        owned += hi - lo
+        res = [c.detect(images[i]) for i in range(lo, hi)]
+        blocks.append(jd.pack_detections(res, c.L, frame_offset=lo))
+    assert owned == n_images
+    rows = np.concatenate(blocks)                                       # what rank 0 holds after the gather
+    assert len(rows) > 0 and (np.diff(rows[:, 0]) >= 0).all()           # rank order == image order
+    got = jd.unpack_detections(rows, c.L)
+    for i in list(range(0, n_images, 97)) + [n_images - 1]:
+        want = o.detect(images[i])
+        if len(want["scores"]) == 0:
+            assert i not in got
+            continue
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(got[i][k], want[k]), (i, k)
