@@ -123,7 +123,10 @@ struct PlanEntry {
   unsigned long long last_use = 0;
 };
 
-constexpr int kDefaultHandoff = 128;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
+constexpr int kDefaultHandoff = 128;
+// k_finish: windows up to this side are copied to LDS before the walks of stages >= 1 (-1: as large as the LDS
+// budget of launch_finish allows, 68 pixels for the 27-landmark 540-cart model)
+constexpr int kFinishTileWin = -1;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
 constexpr int kLanes = 2;     // sub-batches in flight at once, each on its own stream + workspace
 
 template <typename Real>
@@ -327,11 +330,30 @@ static bool upload_model(Cascador* c) {
   std::vector<Real> par0(carts * 4);             // {th, norm, mean, std} per cart (CartPar), packed for LDS staging
   for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cnorm[k] ? (Real)1 : (Real)0; par0[4 * k + 2] = cmean[k]; par0[4 * k + 3] = cstd[k]; }
 
+  // level-major split copy of the nodes for k_finish (kernels.h: NodeOff, lm_index)
+  std::vector<NodeOff<Real>> lm_off(nodes.size());
+  std::vector<uint2> lm_meta(nodes.size());
+  for (size_t t = 0; t < (size_t)h.T; t++)
+    for (unsigned k = 0; k < (unsigned)h.K; k++)
+      for (unsigned d = 0, n = 0; n < (unsigned)node_n; n++) {
+        while (n >= (2u << d) - 1u) d++;
+        const Node& s = nodes[(t * h.K + k) * node_n + n];
+        const size_t o = t * (size_t)h.K * node_n + lm_index((unsigned)h.K, k, d, n);
+        lm_off[o].o1x = s.o1x; lm_off[o].o1y = s.o1y; lm_off[o].o2x = s.o2x; lm_off[o].o2y = s.o2y;
+        lm_meta[o].x = (uint32_t)s.lm1x2 | ((uint32_t)s.lm2x2 << 15) | ((uint32_t)s.scale << 30);
+        lm_meta[o].y = (uint32_t)s.th;
+      }
+
   Carver sz(nullptr);
+  sz.take<NodeOff<Real>>(nodes.size()); sz.take<uint2>(nodes.size());
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
   sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
+  NodeOff<Real>* d_lm_off = cv.take<NodeOff<Real>>(nodes.size());
+  uint2* d_lm_meta = cv.take<uint2>(nodes.size());
+  JDA_HIP(hipMemcpy(d_lm_off, lm_off.data(), nodes.size() * sizeof(NodeOff<Real>), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_lm_meta, lm_meta.data(), nodes.size() * sizeof(uint2), hipMemcpyHostToDevice));
   Node* d_nodes = cv.take<Node>(nodes.size());
   Real* d_leaf = cv.take<Real>(leaf.size());
   Real* d_cth = cv.take<Real>(carts);
@@ -354,7 +376,7 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
-  m.nodes = d_nodes; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
+  m.nodes = d_nodes; m.lm_off = d_lm_off; m.lm_meta = d_lm_meta; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   m.par0 = d_par0;
@@ -523,11 +545,11 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   if (entries) {
     if (!pe.table) {
       pe.table_cap = std::max(entries, (size_t)16 * n0);      // room for 16 levels: most recycled tables fit the next plan
-      JDA_HIP(hipMalloc((void**)&pe.table, pe.table_cap * sizeof(S0Node)));
+      JDA_HIP(hipMalloc((void**)&pe.table, 2 * pe.table_cap * sizeof(S0Node)));   // cart-major tables + their level-major copy
     }
     const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
     const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
-    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, c->stream[0]));
+    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->stream[0]));
     // the scans that read the table run on other streams (second lane, caller's stream)
     JDA_HIP(hipStreamSynchronize(c->stream[0]));
   }
@@ -676,7 +698,8 @@ struct Pass {
     return best;
   }
   // resolved stage-0 tables for k_finish (A/B switch: JDA_FIN_S0=0)
-  const S0Node* s0_tbl() const { return (pe->fast_scan && env_ll("JDA_FIN_S0", 1)) ? pe->table : nullptr; }
+  // k_finish reads the level-major copy of the stage-0 tables (second half of the allocation)
+  const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && env_ll("JDA_FIN_S0", 1)) ? pe->table + pe->table_cap : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {
@@ -841,7 +864,7 @@ struct Pass {
     if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch + one synchronisation less)
-      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", stage_groups()), n_tail, s0_tbl(), st));
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", stage_groups()), n_tail, s0_tbl(), (int)env_ll("JDA_FIN_TILE", kFinishTileWin), st));
       finished = true;
       return true;
     }
@@ -850,9 +873,9 @@ struct Pass {
     // of the mid queue (the kernel reads it from the device counter): its grid is a quarter of the hand-off count
     // -- one workgroup per window as long as fewer than 25 % pass stage 0 (6.7 % in the cascade regime), a grid-stride
     // loop beyond that; the surplus workgroups exit at once (an empty workgroup costs ~1.3 ns of dispatcher time).
-    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), 0, st));
     const long long wg2 = std::min<long long>(n_tail, std::max<long long>(2048, n_tail / std::max<long long>(1, env_ll("JDA_FIN_GRID_DIV", 4))));
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), wg2, nullptr, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), wg2, nullptr, (int)env_ll("JDA_FIN_TILE", kFinishTileWin), st));
     finished = true;
     return true;
   }

@@ -65,10 +65,12 @@ struct View {
 
 // Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
 // data.cpp:18-58).
-template <typename DL, bool MULTI, bool ST>
+// TILE: the window's own pixels are in LDS (tile, row pitch tpitch), see load_window_tile.
+template <typename DL, bool MULTI, bool ST, bool TILE = false>
 __device__ __forceinline__ int node_feature(typename DL::Node nd, const typename DL::Real* sh, int win,
                                             const View& v0, const View& v1, const View& v2,
-                                            const Stp<typename DL::Real>& stp, bool apply_st) {
+                                            const Stp<typename DL::Real>& stp, bool apply_st,
+                                            const uint8_t* tile = nullptr, int tpitch = 0) {
   using Real = typename DL::Real;
   const Real s1x = sh[nd.lm1x2], s1y = sh[nd.lm1x2 + 1];
   const Real s2x = sh[nd.lm2x2], s2y = sh[nd.lm2x2 + 1];
@@ -82,6 +84,11 @@ __device__ __forceinline__ int node_feature(typename DL::Node nd, const typename
     // (DL::pixel's fused clamp does not pay here: k_finish is not VALU bound, measured 3 % slower)
     const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win), y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
     const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win), y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
+    if (TILE) {
+      const int a = tile[__umul24((unsigned)y1, (unsigned)tpitch) + (unsigned)x1];
+      const int b = tile[__umul24((unsigned)y2, (unsigned)tpitch) + (unsigned)x2];
+      return a - b;
+    }
     // rows and widths are below 2^16: 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate)
     const int a = v0.img[__umul24((unsigned)(v0.oy + y1), (unsigned)v0.w) + (unsigned)(v0.ox + x1)];
     const int b = v0.img[__umul24((unsigned)(v0.oy + y2), (unsigned)v0.w) + (unsigned)(v0.ox + x2)];
@@ -131,28 +138,62 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   }
 }
 
-// value held by lane j, as a wave-uniform scalar
+// The window's win x win pixels -> LDS, by one wave: tile[y * tpitch + x], tpitch = win rounded up to 4.
+// A finishing window reads 2 random pixels per split node, 6*K per stage: from the frame each 64-lane byte
+// load touches up to 64 cache lines (44 texture-addresser clocks, lds_bench) and drags 128-byte lines through
+// L1; from LDS it is one ds_read_u8 (8 clocks at random addresses).  Rows are fetched as aligned dwords and
+// shifted into place (the window's first column is at any byte); a dword is only loaded when it holds at
+// least one byte of the row, so no load leaves the frame's last page.
+__device__ __forceinline__ void load_window_tile(const uint8_t* __restrict__ wbase, int W, int win, uint8_t* tile,
+                                                 int tpitch, int lane) {
+  const int dpr = tpitch >> 2;
+  const float inv = 1.0f / (float)dpr;
+  const int total = win * dpr;
+  uint32_t* t32 = (uint32_t*)tile;
+  for (int idx = lane; idx < total; idx += 64) {
+    const int y = (int)(((float)idx + 0.5f) * inv);      // exact: idx < 2^16, see walk_carts_s0
+    const int j = idx - y * dpr;
+    const uint8_t* p = wbase + (size_t)y * W + 4 * j;
+    const unsigned sft = (unsigned)((uintptr_t)p & 3u);
+    const uint32_t* q = (const uint32_t*)(p - sft);
+    const uint32_t lo = q[0];
+    uint32_t hi = 0;
+    if ((int)sft + min(4, win - 4 * j) > 4) hi = q[1];
+    t32[idx] = __builtin_amdgcn_alignbyte(hi, lo, sft);
+  }
+}
 
 }  // namespace
 
 // Tree walks of G carts (k[0..G)) of one stage for the window whose shape is sh[],
 // in lockstep: per tree level the G node records are fetched together, then the
 // 2G pixels, so the memory round trips of the G walks overlap.  -> leaf indices.
-template <typename DL, int G, bool MULTI, bool ST>
-__device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__ stage_nodes, const int* k,
+template <typename DL, int G, bool MULTI, bool ST, bool TILE = false>
+__device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __restrict__ stage_off,
+                                           const uint2* __restrict__ stage_meta, int K, const int* k,
                                            int depth, int node_n, const typename DL::Real* sh, int win,
                                            const View& v0, const View& v1, const View& v2,
-                                           const Stp<typename DL::Real>& stp, bool apply_st, int* leaf) {
+                                           const Stp<typename DL::Real>& stp, bool apply_st, int* leaf,
+                                           const uint8_t* tile = nullptr, int tpitch = 0) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
   for (int d = 0; d < depth - 1; d++) {
+    // the level's records of the wave's 64 carts are consecutive (kernels.h: lm_index)
+    const unsigned first = (1u << d) - 1u, lvl = (unsigned)K * first - first;
     typename DL::Node nd[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) nd[g] = stage_nodes[(unsigned)(k[g] * node_n + node[g])];
+    for (int g = 0; g < G; g++) {
+      const unsigned o = lvl + ((unsigned)k[g] << d) + (unsigned)node[g];
+      const NodeOff<typename DL::Real> f = stage_off[o];
+      const uint2 mt = stage_meta[o];
+      nd[g].o1x = f.o1x; nd[g].o1y = f.o1y; nd[g].o2x = f.o2x; nd[g].o2y = f.o2y;
+      nd[g].lm1x2 = (int)(mt.x & 0x7fffu); nd[g].lm2x2 = (int)((mt.x >> 15) & 0x7fffu); nd[g].scale = (int)(mt.x >> 30);
+      nd[g].th = (int)mt.y;
+    }
     int feat[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI, ST>(nd[g], sh, win, v0, v1, v2, stp, apply_st);
+    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI, ST, TILE>(nd[g], sh, win, v0, v1, v2, stp, apply_st, tile, tpitch);
 #pragma unroll
     for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (feat[g] <= nd[g].th ? 1 : 2);   // c/jda.c:392-393
   }
@@ -160,23 +201,24 @@ __device__ __forceinline__ void walk_carts(const typename DL::Node* __restrict__
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
 }
 
-// Stage-0 walks from the resolved tables k_scan uses (S0Node, one 8-byte record per node with both
-// pixel offsets and the threshold): one record load instead of two, no coordinate arithmetic.
+// Stage-0 walks from the level-major copy of the resolved tables k_scan uses (S0Node, one 8-byte record per node
+// with both pixel offsets and the threshold): one record load instead of two, no coordinate arithmetic.
 // mode 2: offsets are frame offsets (row pitch = frame width); modes 1 and 3: offsets are LDS-tile
 // offsets y*pitch + x, split back into (y, x) with an exact float division ((off + 0.5) / pitch is
 // at least 0.5/pitch away from an integer; offsets stay below 2^18 and pitches below 2^10, so the
 // float error of the quotient is below 1e-4, a tenth of that margin).
 template <int G>
-__device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, const int* k, int depth, int node_n,
+__device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, int K, const int* k, int depth, int node_n,
                                               int mode, int pitch, float inv_pitch, const uint8_t* __restrict__ wbase,
                                               int W, int* leaf) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
   for (int d = 0; d < depth - 1; d++) {
+    const unsigned first = (1u << d) - 1u, lvl = (unsigned)K * first - first;     // level-major table, lm_index
     S0Node r[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) r[g] = tbl[(unsigned)(k[g] * node_n + node[g])];
+    for (int g = 0; g < G; g++) r[g] = tbl[lvl + ((unsigned)k[g] << d) + (unsigned)node[g]];
     unsigned o1[G], o2[G];
     int th[G];
 #pragma unroll
@@ -208,31 +250,47 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, co
 // Stages [t_begin, t_end) for every window of the input queue.  Windows that are
 // still alive after stage t_end-1 go to the mid queue (t_end < T) or, after the
 // final threshold, to the detection list (t_end == T).
+// (One-wave workgroups: the hardware keeps at most 16 workgroups on a CU, so a CU works on 16 windows at a
+// time.  Workgroups of 2-4 independent waves lift that to the register limit, measured: no gain -- the launches
+// are bound by the CU's texture addresser / L1 (TA_BUSY 70-75 % on average, 95 % on the busiest CU with 16
+// windows), not by the number of windows in flight.)
 template <typename DL, bool TRACE, int kG, bool MULTI, bool ST>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
                                                int t_begin, int t_end, int apply_th, typename DL::Real final_th,
-                                               const S0Node* __restrict__ s0_table) {
+                                               const S0Node* __restrict__ s0_table, int tile_win) {
   using Real = typename DL::Real;
-  using Node = typename DL::Node;
   constexpr bool kCpp = sizeof(Real) == 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x;
   const int T = m.T, K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
   const int dim_pad = (dim + 1) & ~1;
   Real* sh = (Real*)lds;                                     // current shape        [dim_pad]
   Real* sh2 = sh + dim_pad;                                  // shape being built    [dim_pad]
-  uint32_t* lbf = (uint32_t*)(sh2 + dim_pad);                // W row (in elements) chosen by every cart [K]
+  uint32_t* lbf = (uint32_t*)(sh2 + dim_pad);                // W row (in elements) chosen by every cart [K] (kept as the
+                                                             // finished offset: 16-bit leaf indices and the multiply in the
+                                                             // regression loop cost 37 us per step)
   int* stage_cnt = (int*)(lbf + ((K + 3) & ~3));             // per-block stage counters
   Real* st_tmp = (Real*)(stage_cnt + kMaxStages);            // similarity-transform scratch [2*dim_pad + 8] (ST only)
+  // the window's pixels (windows up to tile_win pixels, single-scale models), behind the scratch, 16-byte aligned
+  uint8_t* tile = lds + (((size_t)((unsigned char*)(st_tmp + (ST ? 2 * dim_pad + 8 : 0)) - lds) + 15) & ~(size_t)15);
   constexpr bool multi = MULTI;   // split nodes read the half/quarter images too
   (void)multi_i;
-  const int lane = threadIdx.x;
   if (lane < kMaxStages) stage_cnt[lane] = 0;
   const bool from_scan = t_begin == 0;
   const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)w.cap);
   unsigned long long carts_acc = 0;
 
+#ifdef JDA_SCAN_TIMING
+  unsigned long long stamps[15];
+  int n_stamp = 0;
+  int dbg_win = 0;
+#define JDA_FSTAMP() do { if (n_stamp < 15) stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define JDA_FSTAMP() do { } while (0)
+#endif
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    JDA_FSTAMP();
     const uint32_t gid = from_scan ? w.q_gid[i] : w.m_gid[i];
     Real score = from_scan ? w.q_score[i] : w.m_score[i];
     const int kstart = from_scan ? (int)w.q_kstart[i] : 0;
@@ -256,17 +314,25 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       }
     }
     const uint8_t* wbase = v0.img + (size_t)v0.oy * v0.w + v0.ox;
-    __syncthreads();                       // previous window's readers are done with sh
+#ifdef JDA_SCAN_TIMING
+    dbg_win = win;
+#endif
+    const bool use_tile = !MULTI && win <= tile_win && !(t_begin == 0 && t_end == 1 && s0_mode);
+    const int tpitch = (win + 3) & ~3;
+    __syncthreads();                       // previous window's readers are done with sh (and the tile)
+    if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane);
     {
       const Real* src = from_scan ? m.mean_shape : w.m_shape + (size_t)i * dim;
       for (int d = lane; d < dim; d += 64) sh[d] = src[d];
     }
     __syncthreads();
+    JDA_FSTAMP();
 
     bool alive = true;
     int carts_n = 0;
     for (int t = t_begin; t < t_end; t++) {
-      const Node* nodes = (const Node*)m.nodes + (size_t)t * K * node_n;
+      const NodeOff<Real>* n_off = (const NodeOff<Real>*)m.lm_off + (size_t)t * K * node_n;
+      const uint2* n_meta = m.lm_meta + (size_t)t * K * node_n;
       const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
       const Real* cth = m.cth + (size_t)t * K;
       const Real* cmean = m.cmean + (size_t)t * K;
@@ -298,8 +364,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
-        else walk_carts<DL, kG, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
+        else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
         for (int g = 0; g < kG; g++) {
           const int k = k0 + g * 64 + lane;
@@ -321,18 +388,22 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
                                                     max(0, kbeg - kg), min(64, K - kg));
           if (jr >= 0) { alive = false; carts_n = t * K + kg + jr + 1; }
         }
+        if (t == t_begin) JDA_FSTAMP();
       }
+      if (t != t_begin) JDA_FSTAMP();
       if (!alive) break;
       // leaves of the carts k_scan already scored (needed only now that the stage is passed)
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
-        else walk_carts<DL, 2, MULTI, ST>(nodes, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
+        else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
         if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)dim;
       }
       __syncthreads();
+      if (t == t_begin) JDA_FSTAMP();
       // ---- stage regression: K weight rows added strictly in cart order
       //      (c/jda.c:404-411); dialect CPP sums the delta from zero and adds it
       //      once (btcart.cpp:407-424) ----
@@ -360,6 +431,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       }
       __syncthreads();
       { Real* tmp = sh; sh = sh2; sh2 = tmp; }
+      JDA_FSTAMP();
       if (lane == 0) stage_cnt[t] += 1;
     }
 
@@ -391,6 +463,16 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       }
     }
   }
+#ifdef JDA_SCAN_TIMING
+  JDA_FSTAMP();
+  if (lane == 0 && w.dbg && blockIdx.x < 65536 && t_begin > 0 && blockIdx.x < n) {
+    unsigned long long* o = w.dbg + (size_t)blockIdx.x * 32;
+    o[0] = (unsigned long long)n_stamp | (0x7777ull << 32);
+    for (int i = 0; i < n_stamp; i++) o[1 + i] = stamps[i];
+    o[16] = (unsigned long long)dbg_win;
+    o[17] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32);   // HW_ID, XCC_ID
+  }
+#endif
   __syncthreads();
   if (lane < T && stage_cnt[lane]) atomicAdd(shard_counter(w.counters, kCntStage0 + lane), (unsigned long long)stage_cnt[lane]);
   if (lane == 0 && carts_acc) atomicAdd(shard_counter(w.counters, kCntCarts), carts_acc);
@@ -401,13 +483,26 @@ template <typename DL>
 hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th, typename DL::Real th,
                               const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
                               const WorkT<typename DL::Real>& w, int groups, long long n_hint, const S0Node* s0_table,
-                              hipStream_t stream) {
+                              int tile_win, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
   const bool st = sizeof(Real) == 8 && m.similarity != 0;
-  const size_t lds = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int) +
-                     (st ? (2 * (size_t)dim_pad + 8) * sizeof(Real) : 0);
   const int multi = (w.half != nullptr) ? 1 : 0;
+  if (multi) tile_win = 0;
+  const size_t base = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int) +
+                      (st ? (2 * (size_t)dim_pad + 8) * sizeof(Real) : 0);
+  // tile_win < 0: the largest window tile that keeps 16 workgroups on a CU.  Measured on MI355X with one-wave
+  // workgroups (profiles/r02_finish_experiments.txt): up to 7,680 bytes of LDS per workgroup the launch time does
+  // not depend on the LDS size, 7,712 bytes cost +17 %, 7,856 +23 % (16 x 7.5 KB = 120 KB) -- the launch is bound
+  // by the texture addresser but still needs its 16 windows per CU.
+  if (tile_win < 0) {
+    tile_win = 0;
+    for (int tw = 16; tw <= 255; tw++)
+      if (base + (size_t)tw * ((tw + 3) & ~3) + 16 <= kFinishLdsPerGroup) tile_win = tw;
+  }
+  size_t tile_bytes = tile_win > 0 ? (size_t)tile_win * ((tile_win + 3) & ~3) + 16 : 0;
+  if (const char* e = getenv("JDA_FIN_LDS_EXTRA")) tile_bytes += (size_t)atoll(e);    // experiment: LDS size without use
+  const size_t lds = base + tile_bytes;
   const float r = 1.f / sqrtf(2.f);
   // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to
   // 1M workgroups, grid-stride beyond), so the hardware dispatcher balances the very
@@ -419,7 +514,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, t_begin, t_end,
-                       apply_th ? 1 : 0, th, s0_table);
+                       apply_th ? 1 : 0, th, s0_table, tile_win);
   };
   // groups = 64-cart groups walked speculatively per round: 1 where most windows are
   // rejected within a few carts (throughput), 4 where most pass (latency)
@@ -443,14 +538,14 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
 template <>
 hipError_t launch_finish<float>(bool trace, int t_begin, int t_end, bool apply_final_th, float final_th,
                                 const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
-                                int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream) {
-  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, stream);
+                                int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream) {
+  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, stream);
 }
 template <>
 hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_final_th, double final_th,
                                  const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
-                                 int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream) {
-  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, stream);
+                                 int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream) {
+  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, stream);
 }
 
 

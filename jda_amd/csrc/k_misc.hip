@@ -107,7 +107,7 @@ hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw
 template <typename DL>
 __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename DL::Node* __restrict__ nodes,
                               const typename DL::Real* __restrict__ mean_shape, int K, int node_n,
-                              S0Node* __restrict__ table) {
+                              S0Node* __restrict__ table, S0Node* __restrict__ table_lm) {
   const int l = blockIdx.y;
   const DevLevel lv = plan->lv[l];
   if (!lv.tiled) return;
@@ -131,19 +131,24 @@ __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename D
                                  ((unsigned long long)(uint32_t)(th + 256) << (2 * kS0GlobalOffBits));
     o.lo = (uint32_t)v; o.hi = (uint32_t)(v >> 32);
   }
-  table[lv.s0_table + i] = o;
+  table[lv.s0_table + i] = o;                       // cart-major: k_scan stages chunks of carts into LDS
+  // level-major copy for k_finish (kernels.h: lm_index)
+  const unsigned k = (unsigned)i / (unsigned)node_n, n = (unsigned)i - k * (unsigned)node_n;
+  unsigned d = 0;
+  while (n >= (2u << d) - 1u) d++;
+  table_lm[lv.s0_table + lm_index((unsigned)K, k, d, n)] = o;
 }
 
 hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,
                               const void* nodes, const void* mean_shape, int K, int node_n,
-                              S0Node* table, hipStream_t stream) {
+                              S0Node* table, S0Node* table_lm, hipStream_t stream) {
   dim3 block(256), grid((K * node_n + 255) / 256, h_plan.n_levels);
   if (dialect == 0)
     hipLaunchKernelGGL(k_prep_stage0<DialectC>, grid, block, 0, stream, d_plan, (const NodeF*)nodes,
-                       (const float*)mean_shape, K, node_n, table);
+                       (const float*)mean_shape, K, node_n, table, table_lm);
   else
     hipLaunchKernelGGL(k_prep_stage0<DialectCPP>, grid, block, 0, stream, d_plan, (const NodeD*)nodes,
-                       (const double*)mean_shape, K, node_n, table);
+                       (const double*)mean_shape, K, node_n, table, table_lm);
   return hipGetLastError();
 }
 

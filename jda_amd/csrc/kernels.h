@@ -56,6 +56,19 @@ struct NodeD {         // dialect CPP: fp64 offsets (already passed through the 
   double o1x, o1y, o2x, o2y;
 };
 
+// k_finish walks 64 carts per wave, one cart per lane.  In cart-major order every lane's node sits in its own
+// cache line (a cart's nodes are 7 x 32 bytes apart) and the two 16-byte halves of a node are two accesses; the
+// L1 tag rate is what bounds k_finish (TA busy 70-75 %).  k_finish therefore reads a second copy of the nodes:
+// level-major (the roots of all carts of a stage together, then the second level, ...) and split into the four
+// offsets and the integer fields, so that the lanes of a wave read consecutive records.
+template <typename Real>
+struct NodeOff { Real o1x, o1y, o2x, o2y; };
+// index of heap node `node` (on level d) of cart k inside one stage's K*node_n records
+__host__ __device__ inline unsigned lm_index(unsigned K, unsigned k, unsigned d, unsigned node) {
+  const unsigned first = (1u << d) - 1u;
+  return K * first + (k << d) + (node - first);
+}
+
 // Stage-0 node with its pixel offsets resolved for one level (DESIGN.md
 // "stage-0 hoist"): in stage 0 every window holds the mean shape, so the
 // feature coordinates depend only on (node, window size).
@@ -73,6 +86,8 @@ template <typename Real>
 struct DevModelT {
   int T, K, L, D, node_n, leaf_n, dim;
   const void* nodes;       // NodeF / NodeD  [T*K*node_n]
+  const void* lm_off;      // NodeOff<Real> [T*K*node_n], level-major (lm_index): k_finish's copy of the offsets
+  const uint2* lm_meta;    // the same nodes' {lm1x2 | lm2x2 << 15 | scale << 30, th}
   const Real* leaf;        // [T*K*leaf_n]
   const Real* cth;         // [T*K]
   const Real* cmean;       // [T*K]
@@ -140,10 +155,11 @@ hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, i
 hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
                             uint8_t* dst, size_t dst_stride, int dw, int dh, hipStream_t stream);
 
-// Resolves stage-0 node offsets for every tiled level (dialect 0 = C, 1 = CPP).
+// Resolves stage-0 node offsets for every tiled level (dialect 0 = C, 1 = CPP): cart-major into table (k_scan),
+// level-major (lm_index) into table_lm (k_finish).
 hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,
                               const void* nodes, const void* mean_shape, int K, int node_n,
-                              S0Node* table, hipStream_t stream);
+                              S0Node* table, S0Node* table_lm, hipStream_t stream);
 
 int scan_handoff_cap(int node_n, int leaf_n, int real_bytes);   // carts per LDS table chunk of k_scan
 size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real_bytes, bool trace, int block);
@@ -167,8 +183,11 @@ hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max,
 template <typename Real>
 hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
-                         int groups, long long n_hint, const S0Node* s0_table, hipStream_t stream);
+                         int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream);
 // s0_table: the plan's resolved stage-0 tables (or null): stage 0 of windows from levels that have one walks from it
+// tile_win: windows up to this side copy their pixels to LDS first (0: every pixel is read from the frame,
+// < 0: the largest side that leaves the workgroup within kFinishLdsPerGroup)
+constexpr size_t kFinishLdsPerGroup = 7680;
 
 // Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
 // pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).
