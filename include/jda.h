@@ -183,13 +183,15 @@ JDA_API int jdaDetectBatchDevice(void *cascador, const unsigned char *d_frames,
                                  float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt, jdaResult *out);
 
-/* Two batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
+/* Up to three batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
  * Submit queues the stage-0 scan of a batch of device-resident frames and returns at once with a
- * ticket (0 or 1; -1 on error: both tickets in use, the workspace would have to grow while the other
+ * ticket (0..2; -1 on error: every ticket in use, the workspace would have to grow while another
  * batch is pending, multi-scale model); Wait walks that batch through the rest of the pipeline,
  * post-processes it and fills out[0..n) exactly like jdaDetectBatchDevice.  Submitting batch i+1
  * before waiting for batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i
- * (queue-length reads, D2H, sort, NMS, result assembly) run.  The frames must stay valid until Wait
+ * (queue-length reads, D2H, sort, NMS, result assembly) run (one batch ahead is enough for frames that are
+ * already on the device; frames coming from the host want two ahead, see jdaDetectBatchSubmitHost).
+ * The frames must stay valid until Wait
  * returns; the other entry points refuse to run while a ticket is pending.  opt->stats is ignored by
  * Submit; Wait takes the stats pointer (gpu_ms = that batch's own device span, call_ms = submit to
  * the end of wait). */
@@ -200,8 +202,10 @@ JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaR
 
 /* Submit for frames in HOST memory (frames[i] is width*height bytes): the batch is copied to a staging buffer
  * of its ticket on that ticket's stream, then scanned like jdaDetectBatchSubmit.  With pageable frames the
- * copy blocks this call but still overlaps the kernels of the other ticket's batch; with pinned frames
- * (hipHostMalloc / hipHostRegister) it is asynchronous and the frames must stay valid until Wait returns. */
+ * copy blocks this call but still overlaps the kernels of the other tickets' batches; with pinned frames
+ * (hipHostMalloc / hipHostRegister) it is asynchronous and the frames must stay valid until Wait returns.
+ * A ticket lives for copy + kernels + host work while the copy alone takes about half of that: keep TWO
+ * batches submitted ahead of the one being waited for and the PCIe link never idles. */
 JDA_API int jdaDetectBatchSubmitHost(void *cascador, const unsigned char *const *frames, int n,
                                      int width, int height, float scale, float step, int min_size, int max_size,
                                      float th, const jdaDetectOptions *opt);

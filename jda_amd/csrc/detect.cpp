@@ -127,7 +127,10 @@ constexpr int kDefaultHandoff = 128;
 // k_finish: windows up to this side are copied to LDS before the walks of stages >= 1 (-1: as large as the LDS
 // budget of launch_finish allows, 68 pixels for the 27-landmark 540-cart model)
 constexpr int kFinishTileWin = -1;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
-constexpr int kLanes = 2;     // sub-batches in flight at once, each on its own stream + workspace
+// sub-batches in flight at once, each on its own stream + workspace: two inside one synchronous call; three tickets
+// of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms, the
+// copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight)
+constexpr int kLanes = 3;
 
 template <typename Real>
 struct Workspace {
@@ -150,12 +153,12 @@ struct Cascador {
   int device = -1;
   int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
   bool dev_init = false;
-  hipStream_t stream[kLanes] = {nullptr, nullptr};                  // one per lane, see Pass / run_device
-  hipEvent_t ev[kLanes][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  hipStream_t stream[kLanes] = {};                                  // one per lane, see Pass / run_device
+  hipEvent_t ev[kLanes][5] = {};
   hipEvent_t ev_user = nullptr;
-  hipStream_t side[kLanes] = {nullptr, nullptr};            // global-pixel scan launch of a lane, next to its LDS-tiled launches
-  hipEvent_t ev_side[kLanes][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  hipStream_t fin[kLanes] = {nullptr, nullptr};             // high-priority stream of a lane's finishing kernels (JDA_FIN_PRIO)
+  hipStream_t side[kLanes] = {};                            // global-pixel scan launch of a lane, next to its LDS-tiled launches
+  hipEvent_t ev_side[kLanes][2] = {};
+  hipStream_t fin[kLanes] = {};                             // high-priority stream of a lane's finishing kernels (JDA_FIN_PRIO)
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -1357,7 +1360,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   if (!c->pending) c->pending = new PendingBatch[kLanes];
   int slot = -1;
   for (int i = 0; i < kLanes; i++) if (!c->pending[i].active) { slot = i; break; }
-  if (slot < 0) { fail("both submit slots are in use: wait for a batch first"); return -1; }
+  if (slot < 0) { fail("every submit slot is in use: wait for a batch first"); return -1; }
   PendingBatch& pb = c->pending[slot];
   pb.join_issuer();
   pb = PendingBatch();

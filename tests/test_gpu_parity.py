@@ -847,8 +847,9 @@ def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
             assert st[k] == want[name][1][k], (name, k)
     ta = c.submit_batch_device(fa)
     tb = c.submit_batch_device(fb)
-    assert {ta, tb} == {0, 1}
-    with pytest.raises(api.JdaError):                       # both tickets in use
+    ta2 = c.submit_batch_device(fa)
+    assert {ta, tb, ta2} == {0, 1, 2}
+    with pytest.raises(api.JdaError):                       # every ticket in use
         c.submit_batch_device(fc)
     with pytest.raises(api.JdaError):                       # synchronous entries refuse while a ticket is pending
         c.detect_batch_device(fa)
@@ -856,6 +857,7 @@ def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
     tc = c.submit_batch_device(fc)
     check(c.wait_batch(ta, stats=True), "a")
     check(c.wait_batch(tc, stats=True), "c")
+    check(c.wait_batch(ta2, stats=True), "a")
     assert api.lib.jdaDetectBatchWait(c.h, 0, None, (api.jdaResult * 1)()) != 0      # nothing pending in that slot any more
     # a stream of batches, one ahead
     t = c.submit_batch_device(fa)
@@ -863,6 +865,14 @@ def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
         nxt = c.submit_batch_device(fb if i % 2 == 0 else fa) if i < 3 else None
         check(c.wait_batch(t, stats=True), "a" if i % 2 == 0 else "b")
         t = nxt
+    # ... and two ahead (three tickets in flight)
+    names = ["a", "b", "c", "a", "c", "b"]
+    src = {"a": fa, "b": fb, "c": fc}
+    q = [c.submit_batch_device(src[names[0]]), c.submit_batch_device(src[names[1]])]
+    for i in range(len(names)):
+        if i + 2 < len(names):
+            q.append(c.submit_batch_device(src[names[i + 2]]))
+        check(c.wait_batch(q.pop(0), stats=True), names[i])
     check(c.detect_batch_device(fa, stats=True), "a")      # and the synchronous path works again afterwards
 
 

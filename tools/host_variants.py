@@ -18,13 +18,16 @@ for spec in (sys.argv[1:] or [""]):
     out = []
     for name, frames in (("pageable", src), ("pinned", [p.numpy() for p in pin])):
         c = api.Cascador(mp)
-        t = c.submit_batch_host(frames[0])
-        for i in range(3):
-            nxt = c.submit_batch_host(frames[(i + 1) % 2]); c.wait_batch(t, keep_results="packed"); t = nxt
+        ahead = int(os.environ.get("AHEAD", "2"))
+        def run(steps):
+            q = [c.submit_batch_host(frames[j % 2]) for j in range(min(ahead, steps))]
+            for i in range(steps):
+                if i + ahead < steps:
+                    q.append(c.submit_batch_host(frames[(i + ahead) % 2]))
+                c.wait_batch(q.pop(0), keep_results="packed")
+        run(4)
         torch.cuda.synchronize(); t0 = time.perf_counter(); steps = 30
-        for i in range(steps):
-            nxt = c.submit_batch_host(frames[i % 2]) if i + 1 < steps else None
-            c.wait_batch(t, keep_results="packed"); t = nxt
+        run(steps)
         el = (time.perf_counter() - t0) / steps
         out.append("%s %.3f ms %.2e win/s" % (name, el * 1e3, wpf * 256 / el))
         c.close()
