@@ -117,6 +117,7 @@ struct PlanEntry {
   DevPlan* dp = nullptr;
   S0Node* table = nullptr;
   bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
+  bool lm_ok = false;           // the frame offsets of every tiled level fit k_finish's stage-0 table (21 bits)
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
@@ -535,8 +536,13 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   pe.fast_scan = s0_plain && env_ll("JDA_NO_FAST_SCAN", 0) == 0;
   assign_tiles(sp, c->hm, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe);
   size_t entries = 0;
+  pe.lm_ok = true;
   for (int i = 0; i < pe.hp.n_levels; i++)
-    if (pe.hp.lv[i].tiled) entries += n0;
+    if (pe.hp.lv[i].tiled) {
+      entries += n0;
+      const long long win = pe.hp.lv[i].win;
+      if ((win - 1) * sp.width + win - 1 >= (1LL << kS0GlobalOffBits)) pe.lm_ok = false;
+    }
   if (!c->plan_pool.empty()) {            // recycle an evicted plan's allocations
     Cascador::PlanBuffers b = c->plan_pool.back();
     c->plan_pool.pop_back();
@@ -702,7 +708,7 @@ struct Pass {
   }
   // resolved stage-0 tables for k_finish (A/B switch: JDA_FIN_S0=0)
   // k_finish reads the level-major copy of the stage-0 tables (second half of the allocation)
-  const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && env_ll("JDA_FIN_S0", 1)) ? pe->table + pe->table_cap : nullptr; }
+  const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && pe->lm_ok && env_ll("JDA_FIN_S0", 1)) ? pe->table + pe->table_cap : nullptr; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {

@@ -201,16 +201,12 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
 }
 
-// Stage-0 walks from the level-major copy of the resolved tables k_scan uses (S0Node, one 8-byte record per node
-// with both pixel offsets and the threshold): one record load instead of two, no coordinate arithmetic.
-// mode 2: offsets are frame offsets (row pitch = frame width); modes 1 and 3: offsets are LDS-tile
-// offsets y*pitch + x, split back into (y, x) with an exact float division ((off + 0.5) / pitch is
-// at least 0.5/pitch away from an integer; offsets stay below 2^18 and pitches below 2^10, so the
-// float error of the quotient is below 1e-4, a tenth of that margin).
+// Stage-0 walks from the level-major table k_prep_stage0 writes for k_finish (S0Node, one 8-byte record per node:
+// both pixels as offsets from the window's origin in the frame, 21 bits each, and the clamped threshold): one record
+// load instead of two, no coordinate arithmetic.
 template <int G>
 __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, int K, const int* k, int depth, int node_n,
-                                              int mode, int pitch, float inv_pitch, const uint8_t* __restrict__ wbase,
-                                              int W, int* leaf) {
+                                              const uint8_t* __restrict__ wbase, int* leaf) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
@@ -219,29 +215,14 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, in
     S0Node r[G];
 #pragma unroll
     for (int g = 0; g < G; g++) r[g] = tbl[lvl + ((unsigned)k[g] << d) + (unsigned)node[g]];
-    unsigned o1[G], o2[G];
-    int th[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      if (mode == 2) {
-        o1[g] = r[g].lo & 0x1fffffu;
-        o2[g] = __builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu;
-        th[g] = (int)(r[g].hi >> 10) - 256;
-      } else {
-        // LDS-tile offsets y*pitch + x (16-bit packing in mode 1, 21-bit in mode 3) -> frame offsets
-        const unsigned a = mode == 1 ? (r[g].lo & 0xffffu) : (r[g].lo & 0x1fffffu);
-        const unsigned b = mode == 1 ? (r[g].lo >> 16) : (__builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu);
-        const unsigned ya = (unsigned)(((float)a + 0.5f) * inv_pitch), yb = (unsigned)(((float)b + 0.5f) * inv_pitch);
-        o1[g] = __umul24(ya, (unsigned)W) + (a - __umul24(ya, (unsigned)pitch));
-        o2[g] = __umul24(yb, (unsigned)W) + (b - __umul24(yb, (unsigned)pitch));
-        th[g] = mode == 1 ? (int)r[g].hi : (int)(r[g].hi >> 10) - 256;
-      }
-    }
     int pa[G], pb[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) { pa[g] = wbase[o1[g]]; pb[g] = wbase[o2[g]]; }
+    for (int g = 0; g < G; g++) {
+      pa[g] = wbase[r[g].lo & 0x1fffffu];
+      pb[g] = wbase[__builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu];
+    }
 #pragma unroll
-    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (pa[g] - pb[g] <= th[g] ? 1 : 2);   // c/jda.c:391-393
+    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (pa[g] - pb[g] <= (int)(r[g].hi >> 10) - 256 ? 1 : 2);   // c/jda.c:391-393
   }
 #pragma unroll
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
@@ -302,15 +283,14 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     const uint32_t wf = from_scan ? w.q_wf[i] : w.m_wf[i];
     decode_window<Real>(plan, w, xy, wf, inv_sqrt2, &win, &v0, &v1, &v2, multi);
     // stage 0 of a window whose level has resolved tables (every level k_scan covers): walk from them
-    int s0_mode = 0, s0_pitch = 0;
-    float s0_inv = 0.f;
+    int s0_mode = 0;
     const S0Node* s0_tbl = nullptr;
     if (!MULTI && s0_table != nullptr && t_begin == 0) {
       const bool hit = lane < plan->n_levels && plan->lv[lane].win == win;
       const unsigned long long mh = __ballot(hit);
       if (mh) {
         const DevLevel lv = plan->lv[__ffsll((long long)mh) - 1];
-        if (lv.tiled) { s0_mode = lv.tiled; s0_pitch = lv.pitch; s0_inv = 1.0f / (float)lv.pitch; s0_tbl = s0_table + lv.s0_table; }
+        if (lv.tiled) { s0_mode = lv.tiled; s0_tbl = s0_table + lv.s0_table; }
       }
     }
     const uint8_t* wbase = v0.img + (size_t)v0.oy * v0.w + v0.ox;
@@ -364,7 +344,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
         else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
@@ -396,7 +376,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, s0_mode, s0_pitch, s0_inv, wbase, v0.w, lf);
+        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
         else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;

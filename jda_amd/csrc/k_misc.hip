@@ -121,22 +121,31 @@ __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename D
   int y2 = clamp_win(DL::coord(mean_shape[nd.lm2x2 + 1], nd.o2y, win), win);
   // feature is a difference of two bytes: thresholds beyond [-256,255] behave like the ends
   const int th = nd.th < -256 ? -256 : (nd.th > 255 ? 255 : nd.th);
+  // byte offset of the window's pixel (x, y) in k_scan's pixel store: the LDS tile (rows of `pitch` bytes) or the
+  // frame itself (tiled == 2: pitch = frame width)
+  auto off = [&](int x, int y) -> uint32_t { return (uint32_t)(y * lv.pitch + x); };
+  auto wide = [&](uint32_t a, uint32_t b) {
+    const unsigned long long v = (unsigned long long)a | ((unsigned long long)b << kS0GlobalOffBits) |
+                                 ((unsigned long long)(uint32_t)(th + 256) << (2 * kS0GlobalOffBits));
+    S0Node r; r.lo = (uint32_t)v; r.hi = (uint32_t)(v >> 32);
+    return r;
+  };
   S0Node o;
   if (lv.tiled == 1) {
-    o.lo = (uint32_t)(y1 * lv.pitch + x1) | ((uint32_t)(y2 * lv.pitch + x2) << 16);
+    o.lo = off(x1, y1) | (off(x2, y2) << 16);
     o.hi = (uint32_t)th;
   } else {
-    const unsigned long long v = (unsigned long long)(uint32_t)(y1 * lv.pitch + x1) |
-                                 ((unsigned long long)(uint32_t)(y2 * lv.pitch + x2) << kS0GlobalOffBits) |
-                                 ((unsigned long long)(uint32_t)(th + 256) << (2 * kS0GlobalOffBits));
-    o.lo = (uint32_t)v; o.hi = (uint32_t)(v >> 32);
+    o = wide(off(x1, y1), off(x2, y2));
   }
   table[lv.s0_table + i] = o;                       // cart-major: k_scan stages chunks of carts into LDS
   // level-major copy for k_finish (kernels.h: lm_index)
   const unsigned k = (unsigned)i / (unsigned)node_n, n = (unsigned)i - k * (unsigned)node_n;
   unsigned d = 0;
   while (n >= (2u << d) - 1u) d++;
-  table_lm[lv.s0_table + lm_index((unsigned)K, k, d, n)] = o;
+  // ... always as offsets inside the frame (k_finish reads the frame; the host only hands it this table when
+  // every tiled level's offsets fit the 21 bits)
+  const int W = plan->width;
+  table_lm[lv.s0_table + lm_index((unsigned)K, k, d, n)] = wide((uint32_t)(y1 * W + x1), (uint32_t)(y2 * W + x2));
 }
 
 hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,
