@@ -556,6 +556,22 @@ def test_4k_frame_and_odd_strides(built, gpu, model_file):
         _compare_detect(api._take(res[i]), o.detect(fr[i]))
 
 
+def test_very_wide_frame_stage0_offsets_do_not_fit_k_finish_table(built, gpu, model_file):
+    """24000x110: the LDS-tiled levels' window offsets inside the FRAME ((win-1)*W + win-1) no longer fit the 21 bits
+    of k_finish's stage-0 table, so k_finish walks stage 0 from the generic node records while k_scan still uses its
+    tile-relative tables."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((3, 24, 5, 4), 8, seed=45, cart_th=-0.2, norm_every=5)
+    c, o = api.Cascador(p), Oracle(p)
+    wide = synth.make_frames(1, 24000, 110, seed=46)
+    levels = c.plan_tiles(24000, 110, 1.1, 80, -1)
+    assert any(lv["mode"] in (1, 3) and (lv["win"] - 1) * 24000 + lv["win"] - 1 >= 2 ** 21 for lv in levels)
+    _compare_trace(c, o, wide, scale=1.1, min_size=80)
+    d = c.detect_batch(wide, scale=1.1, min_size=80, th=0.0)[0]
+    _compare_detect(d, o.detect(wide[0], scale=1.1, min_size=80, th=0.0))
+
+
 def test_batch_larger_than_workspace_is_processed_in_passes(built, gpu, model_file, monkeypatch):
     from jda_amd import api, synth
     p, _ = model_file((3, 20, 5, 4), 8, seed=44, cart_th=-0.8)
