@@ -126,7 +126,7 @@ struct PlanEntry {
 
 constexpr int kDefaultHandoff = 128;
 // k_finish: windows up to this side are copied to LDS before the walks of stages >= 1 (-1: as large as the LDS
-// budget of launch_finish allows, 68 pixels for the 27-landmark 540-cart model)
+// budget of launch_finish allows, 72 pixels for the 27-landmark 540-cart model)
 constexpr int kFinishTileWin = -1;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
 // sub-batches in flight at once, each on its own stream + workspace: two inside one synchronous call; three tickets
 // of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms, the

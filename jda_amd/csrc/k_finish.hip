@@ -246,9 +246,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   const int lane = threadIdx.x;
   const int T = m.T, K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
   const int dim_pad = (dim + 1) & ~1;
-  Real* sh = (Real*)lds;                                     // current shape        [dim_pad]
-  Real* sh2 = sh + dim_pad;                                  // shape being built    [dim_pad]
-  uint32_t* lbf = (uint32_t*)(sh2 + dim_pad);                // W row (in elements) chosen by every cart [K] (kept as the
+  Real* sh = (Real*)lds;                                     // current shape        [dim_pad] (the regression updates it
+                                                             // in place: coordinate d is read and written by one lane only)
+  uint32_t* lbf = (uint32_t*)(sh + dim_pad);                 // W row (in elements) chosen by every cart [K] (kept as the
                                                              // finished offset: 16-bit leaf indices and the multiply in the
                                                              // regression loop cost 37 us per step)
   int* stage_cnt = (int*)(lbf + ((K + 3) & ~3));             // per-block stage counters
@@ -283,21 +283,20 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     const uint32_t wf = from_scan ? w.q_wf[i] : w.m_wf[i];
     decode_window<Real>(plan, w, xy, wf, inv_sqrt2, &win, &v0, &v1, &v2, multi);
     // stage 0 of a window whose level has resolved tables (every level k_scan covers): walk from them
-    int s0_mode = 0;
     const S0Node* s0_tbl = nullptr;
     if (!MULTI && s0_table != nullptr && t_begin == 0) {
       const bool hit = lane < plan->n_levels && plan->lv[lane].win == win;
       const unsigned long long mh = __ballot(hit);
       if (mh) {
         const DevLevel lv = plan->lv[__ffsll((long long)mh) - 1];
-        if (lv.tiled) { s0_mode = lv.tiled; s0_tbl = s0_table + lv.s0_table; }
+        if (lv.tiled) s0_tbl = s0_table + lv.s0_table;
       }
     }
     const uint8_t* wbase = v0.img + (size_t)v0.oy * v0.w + v0.ox;
 #ifdef JDA_SCAN_TIMING
     dbg_win = win;
 #endif
-    const bool use_tile = !MULTI && win <= tile_win && !(t_begin == 0 && t_end == 1 && s0_mode);
+    const bool use_tile = !MULTI && win <= tile_win && !(t_begin == 0 && t_end == 1 && s0_tbl);
     const int tpitch = (win + 3) & ~3;
     __syncthreads();                       // previous window's readers are done with sh (and the tile)
     if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane);
@@ -344,7 +343,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        if (t == 0 && s0_mode) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
+        if (t == 0 && s0_tbl) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
         else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        if (t == 0 && s0_mode) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
+        if (t == 0 && s0_tbl) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
         else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
@@ -407,10 +406,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
           acc = (d & 1) ? stp.scale * (stp.r10 * other + stp.r11 * acc) : stp.scale * (stp.r00 * acc + stp.r01 * other);
           acc = sh[d] + acc;
         }
-        sh2[d] = acc;
+        sh[d] = acc;
       }
       __syncthreads();
-      { Real* tmp = sh; sh = sh2; sh2 = tmp; }
       JDA_FSTAMP();
       if (lane == 0) stage_cnt[t] += 1;
     }
@@ -469,7 +467,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   const bool st = sizeof(Real) == 8 && m.similarity != 0;
   const int multi = (w.half != nullptr) ? 1 : 0;
   if (multi) tile_win = 0;
-  const size_t base = 2 * (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int) +
+  const size_t base = (size_t)dim_pad * sizeof(Real) + (size_t)((m.K + 3) & ~3) * 4 + kMaxStages * sizeof(int) +
                       (st ? (2 * (size_t)dim_pad + 8) * sizeof(Real) : 0);
   // tile_win < 0: the largest window tile that keeps 16 workgroups on a CU.  Measured on MI355X with one-wave
   // workgroups (profiles/r02_finish_experiments.txt): up to 7,680 bytes of LDS per workgroup the launch time does
