@@ -117,7 +117,7 @@ struct PlanEntry {
   DevPlan* dp = nullptr;
   S0Node* table = nullptr;
   bool fast_scan = false;       // stage 0 has only scale==0 nodes: LDS-tiled scan is valid
-  bool lm_ok = false;           // the frame offsets of every tiled level fit k_finish's stage-0 table (21 bits)
+  bool lm_ok = false;           // every tiled level's windows fit k_finish's stage-0 table ((x, y) in 11 bits each)
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
@@ -127,7 +127,11 @@ struct PlanEntry {
 constexpr int kDefaultHandoff = 128;
 // k_finish: windows up to this side are copied to LDS before the walks of stages >= 1 (-1: as large as the LDS
 // budget of launch_finish allows, 72 pixels for the 27-landmark 540-cart model)
-constexpr int kFinishTileWin = -1;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
+constexpr int kFinishTileWin = -1;
+// ... and in the stage-0 launch (JDA_FIN_TILE1): off -- most hand-off windows die within a round or two of carts and
+// the copy is one more dependent step in front of them (measured: 1.816 ms of GPU time per step with tiles of 46, 57
+// or 72 pixels against 1.806 without)
+constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
 // sub-batches in flight at once, each on its own stream + workspace: two inside one synchronous call; three tickets
 // of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms, the
 // copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight)
@@ -540,8 +544,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   for (int i = 0; i < pe.hp.n_levels; i++)
     if (pe.hp.lv[i].tiled) {
       entries += n0;
-      const long long win = pe.hp.lv[i].win;
-      if ((win - 1) * sp.width + win - 1 >= (1LL << kS0GlobalOffBits)) pe.lm_ok = false;
+      if (pe.hp.lv[i].win > 2047) pe.lm_ok = false;      // (x, y) inside the window: 11 bits each
     }
   if (!c->plan_pool.empty()) {            // recycle an evicted plan's allocations
     Cascador::PlanBuffers b = c->plan_pool.back();
@@ -882,7 +885,7 @@ struct Pass {
     // of the mid queue (the kernel reads it from the device counter): its grid is a quarter of the hand-off count
     // -- one workgroup per window as long as fewer than 25 % pass stage 0 (6.7 % in the cascade regime), a grid-stride
     // loop beyond that; the surplus workgroups exit at once (an empty workgroup costs ~1.3 ns of dispatcher time).
-    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), 0, st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), (int)env_ll("JDA_FIN_TILE1", kFinishTileWin1), st));
     const long long wg2 = std::min<long long>(n_tail, std::max<long long>(2048, n_tail / std::max<long long>(1, env_ll("JDA_FIN_GRID_DIV", 4))));
     JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), wg2, nullptr, (int)env_ll("JDA_FIN_TILE", kFinishTileWin), st));
     finished = true;

@@ -202,11 +202,12 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
 }
 
 // Stage-0 walks from the level-major table k_prep_stage0 writes for k_finish (S0Node, one 8-byte record per node:
-// both pixels as offsets from the window's origin in the frame, 21 bits each, and the clamped threshold): one record
-// load instead of two, no coordinate arithmetic.
-template <int G>
+// both pixels as (x, y) inside the window, 11 bits each, and the clamped threshold): one record load instead of two,
+// no coordinate arithmetic.  pix/pitch: the window's origin in the frame with the frame's width, or the window's own
+// copy in LDS (TILE) with its pitch.
+template <int G, bool TILE>
 __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, int K, const int* k, int depth, int node_n,
-                                              const uint8_t* __restrict__ wbase, int* leaf) {
+                                              const uint8_t* __restrict__ pix, int pitch, int* leaf) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
@@ -218,11 +219,12 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, in
     int pa[G], pb[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      pa[g] = wbase[r[g].lo & 0x1fffffu];
-      pb[g] = wbase[__builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 21) & 0x1fffffu];
+      const unsigned p1 = r[g].lo & 0x3fffffu, p2 = __builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 22) & 0x3fffffu;
+      pa[g] = pix[__umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu)];
+      pb[g] = pix[__umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu)];
     }
 #pragma unroll
-    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (pa[g] - pb[g] <= (int)(r[g].hi >> 10) - 256 ? 1 : 2);   // c/jda.c:391-393
+    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (pa[g] - pb[g] <= (int)((r[g].hi >> 12) & 0x3ffu) - 256 ? 1 : 2);   // c/jda.c:391-393
   }
 #pragma unroll
   for (int g = 0; g < G; g++) leaf[g] = node[g] - node_n;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
 #ifdef JDA_SCAN_TIMING
     dbg_win = win;
 #endif
-    const bool use_tile = !MULTI && win <= tile_win && !(t_begin == 0 && t_end == 1 && s0_tbl);
+    const bool use_tile = !MULTI && win <= tile_win;
     const int tpitch = (win + 3) & ~3;
     __syncthreads();                       // previous window's readers are done with sh (and the tile)
     if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane);
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        if (t == 0 && s0_tbl) walk_carts_s0<kG>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
+        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<kG, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
+        else if (t == 0 && s0_tbl) walk_carts_s0<kG, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
         else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
 #pragma unroll
@@ -375,7 +378,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        if (t == 0 && s0_tbl) walk_carts_s0<2>(s0_tbl, K, kk, m.D, node_n, wbase, lf);
+        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<2, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
+        else if (t == 0 && s0_tbl) walk_carts_s0<2, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
         else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;

@@ -142,10 +142,14 @@ __global__ void k_prep_stage0(const DevPlan* __restrict__ plan, const typename D
   const unsigned k = (unsigned)i / (unsigned)node_n, n = (unsigned)i - k * (unsigned)node_n;
   unsigned d = 0;
   while (n >= (2u << d) - 1u) d++;
-  // ... always as offsets inside the frame (k_finish reads the frame; the host only hands it this table when
-  // every tiled level's offsets fit the 21 bits)
-  const int W = plan->width;
-  table_lm[lv.s0_table + lm_index((unsigned)K, k, d, n)] = wide((uint32_t)(y1 * W + x1), (uint32_t)(y2 * W + x2));
+  // ... with the two pixels as (x, y) inside the window, 11 bits each (k_finish reads the frame or its own copy of
+  // the window, two different pitches; the host only hands it this table when every tiled window is below 2048 px):
+  //   x1 : 11 | y1 : 11 | x2 : 11 | y2 : 11 | th + 256 : 10
+  const unsigned long long v = (unsigned long long)(uint32_t)(x1 | (y1 << 11)) |
+                               ((unsigned long long)(uint32_t)(x2 | (y2 << 11)) << 22) |
+                               ((unsigned long long)(uint32_t)(th + 256) << 44);
+  S0Node q; q.lo = (uint32_t)v; q.hi = (uint32_t)(v >> 32);
+  table_lm[lv.s0_table + lm_index((unsigned)K, k, d, n)] = q;
 }
 
 hipError_t launch_prep_stage0(int dialect, const DevPlan* d_plan, const DevPlan& h_plan,

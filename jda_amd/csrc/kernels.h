@@ -72,10 +72,12 @@ __host__ __device__ inline unsigned lm_index(unsigned K, unsigned k, unsigned d,
 // Stage-0 node with its pixel offsets resolved for one level (DESIGN.md
 // "stage-0 hoist"): in stage 0 every window holds the mean shape, so the
 // feature coordinates depend only on (node, window size).
-// Two packings of the same 8 bytes:
-//   tiled == 1    : lo = off1 | off2 << 16 (byte offsets inside the LDS tile), hi = th in [-256,255]
-//   tiled == 2, 3 : off1 : 21 | off2 : 21 | th + 256 : 10 (byte offsets inside the frame, row pitch = width,
-//                   or inside a big LDS tile)
+// Packings of the same 8 bytes:
+//   k_scan, tiled == 1    : lo = off1 | off2 << 16 (byte offsets inside the LDS tile), hi = th in [-256,255]
+//   k_scan, tiled == 2, 3 : off1 : 21 | off2 : 21 | th + 256 : 10 (byte offsets inside the frame, row pitch = width,
+//                           or inside a big LDS tile)
+//   k_finish (level-major copy of the table, every level): x1 : 11 | y1 : 11 | x2 : 11 | y2 : 11 | th + 256 : 10,
+//                           pixel coordinates inside the window (read from the frame or from the window's LDS copy)
 struct S0Node {
   uint32_t lo;
   uint32_t hi;

@@ -556,10 +556,10 @@ def test_4k_frame_and_odd_strides(built, gpu, model_file):
         _compare_detect(api._take(res[i]), o.detect(fr[i]))
 
 
-def test_very_wide_frame_stage0_offsets_do_not_fit_k_finish_table(built, gpu, model_file):
-    """24000x110: the LDS-tiled levels' window offsets inside the FRAME ((win-1)*W + win-1) no longer fit the 21 bits
-    of k_finish's stage-0 table, so k_finish walks stage 0 from the generic node records while k_scan still uses its
-    tile-relative tables."""
+def test_very_wide_frame_stage0_offsets_beyond_21_bits(built, gpu, model_file):
+    """24000x110: the LDS-tiled levels' window offsets inside the FRAME ((win-1)*W + win-1) exceed 21 bits (the packing
+    of the global-pixel scan's table); k_finish's stage-0 table holds (x, y) pairs instead and k_scan its tile-relative
+    offsets, so both still take their table paths."""
     from jda_amd import api, synth
     from oracle.pyoracle import Oracle
     p, _ = model_file((3, 24, 5, 4), 8, seed=45, cart_th=-0.2, norm_every=5)
