@@ -114,9 +114,41 @@ def cpu_baseline(model_file, dims, frames, budget_s=20.0):
             "single_thread_value": single, "single_thread_sample": "%d frames" % n1}
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn_argv(argv, gpus, port):
+    """The command `python bench.py --gpus N ...` re-executes itself as when N > 1 and it was not started by a
+    launcher (no RANK / WORLD_SIZE in the environment): one process per GPU, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_spawn(args, argv):
+    """--gpus N > 1 without a launcher: become the launcher.  Returns the exit code of the N-rank job, or None when
+    this process is itself a rank (or N == 1) and should go on."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and os.environ.get("JDA_BENCH_ONE_GPU") != "1":
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible on this node\n" % (args.gpus, have))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(self_spawn_argv(argv, args.gpus, free_port()), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node; N > 1 without a launcher re-executes under torch.distributed.run")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--rotate", type=int, default=4,
@@ -132,6 +164,9 @@ def main():
     ap.add_argument("--no-allpass", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="skip the configs[4] all-pass leg (roofline_hbm_regime)")
     args = ap.parse_args()
+    rc = maybe_self_spawn(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
 
     import torch
     import torch.distributed as dist

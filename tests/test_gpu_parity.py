@@ -286,6 +286,59 @@ def test_config2_1080p_batch_shipped_dims(built, gpu, tmp_path):
     _compare_trace(c, o, frames[7:8], **kw)
 
 
+def test_config2_at_its_stated_size_256_frames_1080p(built, gpu, tmp_path):
+    """BASELINE.json configs[2] at the size it states: 256 frames 1920x1080 (531 MB of frames resident in HBM),
+    8 window sizes (scale 1.5, c/jda.c:331-333), shipped model dimensions, cascade regime: 32,089,600 candidate
+    windows per call.  Size-independent properties over the whole batch (window accounting, determinism, the
+    batch equals its halves) and the oracle (+ the compiled reference c/jda.c:318-480) on sampled frames."""
+    import json
+    import time
+    import torch
+    from jda_amd import api, synth
+    from oracle import pyoracle
+    n = 256
+    frames = synth.make_frames(n, 1920, 1080, seed=0)
+    m = synth.make_model(*S_DIMS, seed=1)
+    synth.calibrate_thresholds(m, frames[:4], scale=1.5)
+    p = str(tmp_path / "cfg2_full.model"); m.save(p, 8)
+    c = api.Cascador(p)
+    d_frames = torch.from_numpy(frames).to(gpu)
+    kw = dict(scale=1.5)
+    res1, st1 = c.detect_batch_device(d_frames, stats=True, **kw)
+    assert st1["patch_n"] == n * 125350 == 32089600                          # SURVEY.md 8d config 3
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res2, st2 = c.detect_batch_device(d_frames, stats=True, **kw)
+    el = time.perf_counter() - t0
+    for k in ("cart_gothrough_n", "cart_total_n", "face_patch_n", "stage_done_n", "scan_cart_n", "scan_patch_n"):
+        assert st1[k] == st2[k], k
+    for a, b in zip(res1, res2):
+        _compare_detect(a, b)
+    assert 10 < st1["average_cart_n"] < 60
+    assert sum(len(r["scores"]) for r in res1) > n
+    # additivity: the counters of the batch are the sums over its two halves, the results the concatenation
+    ra, sa = c.detect_batch_device(d_frames[:128], stats=True, **kw)
+    rb, sb = c.detect_batch_device(d_frames[128:], stats=True, **kw)
+    for k in ("cart_total_n", "face_patch_n", "cart_gothrough_n", "handoff_n"):
+        assert sa[k] + sb[k] == st1[k], k
+    for a, b in zip(ra + rb, res1):
+        _compare_detect(a, b)
+    o = pyoracle.Oracle(p)
+    ref = pyoracle.Reference(p, S_DIMS, 8) if pyoracle.reference_lib_path(*S_DIMS) else None
+    for i in (3, 200):
+        _compare_detect(res1[i], o.detect(frames[i], **kw))
+        if ref is not None:
+            _compare_detect(res1[i], ref.detect(frames[i], **kw))
+    _compare_detect(res1[255], c.detect(frames[255], 1.5, 0.1, 40, -1, -0.5))
+    rec = {"config": "BASELINE.json configs[2]: 256 x 1920x1080, scale 1.5 (8 levels), S dims, cascade regime",
+           "windows": st1["patch_n"], "ms_per_call": el * 1e3, "windows_per_s": st1["patch_n"] / el,
+           "gpu_ms": st2["gpu_ms"], "average_cart_n": st1["average_cart_n"], "handoff_n": st1["handoff_n"]}
+    print("config2 full size:", json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config2_full.json"), "w") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
 X_DIMS = (7, 2000, 68, 6)
 
 
@@ -793,8 +846,9 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     env = dict(os.environ, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1", JDA_DENSE="1")   # the roofline leg needs the scan
     import socket
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+    # no launcher: `python bench.py --gpus 2` starts its two ranks itself (bench.py:maybe_self_spawn), the way the
+    # driver invokes it
+    cmd = [sys.executable, os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--no-cpu", "--no-allpass"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -803,6 +857,29 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["achieved"] > 0 and d["regimes"]["cascade"]["detections_after_nms"] > 0
+    assert "gather" in d["config"]
+
+
+def test_bench_plain_invocation_one_gpu(built, gpu):
+    """`python bench.py --gpus 1 --steps K --warmup W` exactly as the driver runs it (no launcher): one JSON line
+    with the contract's keys, the roofline and the FDDB-shaped images/s."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "32", "--no-cpu", "--no-allpass"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert 0 < d["roofline"]["frac"] <= 1
 
 
 def test_pipelined_gather_device_path_over_rccl_group_of_one(built, gpu):
