@@ -123,6 +123,20 @@ JDA_API int jdaCascadorInfo(void *cascador, jdaModelInfo *info);
  * use).  Must be called before the first detect on this cascador. */
 JDA_API int jdaSetDevice(void *cascador, int device);
 
+/* Tuning options of a cascador.  They start from the JDA_* environment variables (read once, when the cascador
+ * is created) and can be changed here while no submitted batch is pending; a change drops the
+ * cached scan plans.  None of them changes results.  Documented keys:
+ *   "handoff"       carts of stage 0 the scan kernel evaluates before the finishing kernel takes over (128)
+ *   "lanes"         sub-batches of one synchronous call that run side by side on their own streams (2)
+ *   "dense"         whole-stage tile kernel for models that reject little: 0 off, 1 auto, 2 always (1)
+ *   "workspace_mb"  device workspace budget of a call in MiB; larger batches run in several passes (24576)
+ *   "plan_cache"    scan plans (one per frame size and call parameters) kept per cascador (64)
+ *   "predict"       size the finishing launches from the previous pass instead of a host round trip (1)
+ * (the other keys of DESIGN.md section 8 are accepted as well; they are experiment switches).
+ * Returns 0, or -1 for an unknown key / a pending batch.  jdaGetOption returns the value (-1: unknown key). */
+JDA_API int jdaSetOption(void *cascador, const char *key, long long value);
+JDA_API long long jdaGetOption(void *cascador, const char *key);
+
 /* Window enumeration of reference c/jda.c:320-339 without running anything:
  * number of candidate windows and pyramid levels for one frame. */
 JDA_API int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
@@ -201,9 +215,10 @@ JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, 
 JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaResult *out);
 
 /* Submit for frames in HOST memory (frames[i] is width*height bytes): the batch is copied to a staging buffer
- * of its ticket on that ticket's stream, then scanned like jdaDetectBatchSubmit.  With pageable frames the
- * copy blocks this call but still overlaps the kernels of the other tickets' batches; with pinned frames
- * (hipHostMalloc / hipHostRegister) it is asynchronous and the frames must stay valid until Wait returns.
+ * of its ticket on that ticket's stream, then scanned like jdaDetectBatchSubmit.  The copy and the scan launches
+ * are issued by a helper thread AFTER this call has returned, so in EVERY case -- pageable or pinned frames --
+ * both the frame bytes and the frames[] pointer array itself must stay valid and unchanged until
+ * jdaDetectBatchWait for this ticket has returned (do not reuse a capture buffer or a stack array before that).
  * A ticket lives for copy + kernels + host work while the copy alone takes about half of that: keep TWO
  * batches submitted ahead of the one being waited for and the PCIe link never idles. */
 JDA_API int jdaDetectBatchSubmitHost(void *cascador, const unsigned char *const *frames, int n,

@@ -91,6 +91,9 @@ def _load():
     lib.jdaGetLastError.restype = C.c_char_p
     lib.jdaCascadorInfo.argtypes = [C.c_void_p, C.POINTER(jdaModelInfo)]
     lib.jdaSetDevice.argtypes = [C.c_void_p, C.c_int]
+    lib.jdaSetOption.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+    lib.jdaGetOption.restype = C.c_longlong
+    lib.jdaGetOption.argtypes = [C.c_void_p, C.c_char_p]
     lib.jdaCountWindows.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                     C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
     lib.jdaDetectOptionsInit.restype = None
@@ -245,6 +248,14 @@ class Cascador:
         """Dialect CPP: Config face.similarity_transform (reference common.cpp:214)."""
         if lib.jdaSetSimilarityTransform(self.h, 1 if on else 0) != 0:
             raise JdaError("jdaSetSimilarityTransform failed")
+
+    def set_option(self, key, value):
+        """jdaSetOption: tuning knobs of this cascador (include/jda.h); never changes results."""
+        if lib.jdaSetOption(self.h, key.encode(), int(value)) != 0:
+            raise JdaError(last_error())
+
+    def get_option(self, key):
+        return int(lib.jdaGetOption(self.h, key.encode()))
 
     def serialize(self, path):
         lib.jdaCascadorSerializeTo(self.h, os.fsencode(path))

@@ -60,6 +60,71 @@ static long long env_ll(const char* name, long long dflt) {
   return v && *v ? std::atoll(v) : dflt;
 }
 
+// ---------------------------------------------------------------- knobs
+// Tuning values of a cascador.  Read ONCE, when the cascador is created, from the JDA_* environment variables of
+// DESIGN.md section 8 (experiments set them before jdaCascadorCreate*); jdaSetOption changes the documented ones
+// afterwards.  Nothing on the call path touches the environment.
+#define JDA_KNOBS(X)                                                                                   \
+  X(handoff, "JDA_HANDOFF", 128)            /* carts of stage 0 k_scan evaluates before k_finish takes over */ \
+  X(first_phase, "JDA_FIRST_PHASE", 16)     /* carts before k_scan's first compaction */                \
+  X(cp_max, "JDA_CP_MAX", 128)              /* windows per tile at or below which a phase spreads (window, cart) pairs */ \
+  X(lds_win_max, "JDA_LDS_WIN_MAX", 100)    /* largest window that gets an LDS pixel tile */            \
+  X(tile_cglb, "JDA_TILE_CGLB", 800)        /* cost per window of the global-pixel mode (tile chooser) */ \
+  X(glb_tile_fit, "JDA_GLB_TILE_FIT", 1)                                                               \
+  X(no_global_scan, "JDA_NO_GLOBAL_SCAN", 0)                                                           \
+  X(no_lds_scan, "JDA_NO_LDS_SCAN", 0)                                                                 \
+  X(no_fast_scan, "JDA_NO_FAST_SCAN", 0)                                                               \
+  X(debug_tiles, "JDA_DEBUG_TILES", 0)                                                                 \
+  X(plan_cache, "JDA_PLAN_CACHE", 64)       /* scan plans kept per cascador */                          \
+  X(fin_s0, "JDA_FIN_S0", 1)                                                                           \
+  X(dense, "JDA_DENSE", 1)                  /* 0 off, 1 auto, 2 always */                              \
+  X(dense_lds_max, "JDA_DENSE_LDS_MAX", 160 * 1024)                                                    \
+  X(dense_pix, "JDA_DENSE_PIX", 16 * 1024)                                                             \
+  X(dense_pct, "JDA_DENSE_PCT", 50)                                                                    \
+  X(merge_blocks, "JDA_MERGE_BLOCKS", 2048) /* workgroups below which the LDS-tiled levels share one launch */ \
+  X(side_small, "JDA_SIDE_SMALL", 0)                                                                   \
+  X(side_stream, "JDA_SIDE_STREAM", 1)                                                                 \
+  X(lanes_reverse, "JDA_LANES_REVERSE", 1)                                                             \
+  X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
+  X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
+  X(fin_g1, "JDA_FIN_G1", 1)                                                                           \
+  X(fin_g2, "JDA_FIN_G2", 0)                                                                           \
+  X(fin_tile, "JDA_FIN_TILE", -1)           /* k_finish LDS window tile: -1 auto, 0 off, n pixels */    \
+  X(fin_tile1, "JDA_FIN_TILE1", 0)                                                                     \
+  X(fin_grid_div, "JDA_FIN_GRID_DIV", 4)                                                               \
+  X(predict, "JDA_PREDICT", 1)              /* size the finishing launches from the previous pass (no host round trip) */ \
+  X(debug_times, "JDA_DEBUG_TIMES", 0)                                                                 \
+  X(test_wpf_scale, "JDA_TEST_WPF_SCALE", 1) /* test hook of the 32-bit window-id guard */             \
+  X(lanes, "JDA_LANES", 2)                  /* sub-batch lanes of one synchronous call */               \
+  X(lanes_min_windows, "JDA_LANES_MIN_WINDOWS", 2000000)                                               \
+  X(host_chunk, "JDA_HOST_CHUNK", 128)      /* frames per sub-batch when the frames come from host memory */ \
+  X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
+  X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
+  X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */
+
+struct Knobs {
+#define X(name, env, dflt) long long name = (dflt);
+  JDA_KNOBS(X)
+#undef X
+  void load() {
+#define X(name, env, dflt) name = env_ll(env, (dflt));
+    JDA_KNOBS(X)
+#undef X
+  }
+  bool set(const char* key, long long v) {
+#define X(name, env, dflt) if (std::strcmp(key, #name) == 0) { name = v; return true; }
+    JDA_KNOBS(X)
+#undef X
+    return false;
+  }
+  bool get(const char* key, long long* v) const {
+#define X(name, env, dflt) if (std::strcmp(key, #name) == 0) { *v = name; return true; }
+    JDA_KNOBS(X)
+#undef X
+    return false;
+  }
+};
+
 // ---------------------------------------------------------------- device buffers
 
 struct DevBuf {
@@ -121,10 +186,15 @@ struct PlanEntry {
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
+  // Hand-off queue length and detections of earlier passes on this plan, as fractions of the pass's windows (< 0:
+  // none yet).  With a prediction the finishing launches are sized and queued right behind the scan, and a prefix
+  // of the detection list is copied back speculatively: the whole pass is ONE enqueue and one host wait.  The kernels
+  // read the true lengths from the device counters (grid-stride), so a wrong prediction costs time, never results.
+  double pred_tail = -1, pred_out = -1;
+  int pins = 0;                 // submitted batches that still use this plan (never evicted while > 0)
   unsigned long long last_use = 0;
 };
 
-constexpr int kDefaultHandoff = 128;
 // k_finish: windows up to this side are copied to LDS before the walks of stages >= 1 (-1: as large as the LDS
 // budget of launch_finish allows, 72 pixels for the 27-landmark 540-cart model)
 constexpr int kFinishTileWin = -1;
@@ -151,9 +221,34 @@ struct Workspace {
 
 struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
 
+// Pinned host memory, grow-only (results of a pass land here by asynchronous D2H copies).
+struct HostPinned {
+  void* p = nullptr;
+  size_t bytes = 0;
+  // keep: bytes at the front that must survive a reallocation
+  bool reserve(size_t n, size_t keep = 0) {
+    if (n <= bytes) return true;
+    n = std::max<size_t>(n + n / 2, (size_t)1 << 20);
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, n, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); fail("hipHostMalloc(" + std::to_string(n) + " bytes) failed: " + hipGetErrorString(e)); return false; }
+    if (p && keep) std::memcpy(q, p, std::min(keep, bytes));
+    if (p) (void)hipHostFree(p);
+    p = q; bytes = n;
+    return true;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 struct Cascador {
   HostModel hm;
+  Knobs kn;
   std::mutex mu;
+  // queue lengths of the last pass as fractions of its windows (hand-off queue, detections): a new plan starts from
+  // them, see PlanEntry::pred_tail
+  double pred_tail = -1, pred_out = -1;
+  bool last_dense = false;
+  HostPinned h_gid[kLanes], h_score[kLanes], h_shape[kLanes];   // detections of a lane's pass
   int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
   int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
@@ -163,7 +258,6 @@ struct Cascador {
   hipEvent_t ev_user = nullptr;
   hipStream_t side[kLanes] = {};                            // global-pixel scan launch of a lane, next to its LDS-tiled launches
   hipEvent_t ev_side[kLanes][2] = {};
-  hipStream_t fin[kLanes] = {};                             // high-priority stream of a lane's finishing kernels (JDA_FIN_PRIO)
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -232,24 +326,9 @@ static bool ensure_lane(Cascador* c, int lane) {
   return true;
 }
 
-// a stream of the highest priority the device offers: the texture-addresser-bound kernels (global-pixel scan,
-// finishing kernels) get their workgroups placed first whenever the LDS-bound scan of the other batch frees slots
-static hipError_t create_priority_stream(hipStream_t* s, bool high) {
-  int least = 0, greatest = 0;
-  if (!high || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-}
-
-static bool ensure_fin(Cascador* c, int lane) {
-  if (c->fin[lane]) return true;
-  JDA_HIP(create_priority_stream(&c->fin[lane], true));
-  return true;
-}
-
 static bool ensure_side(Cascador* c, int lane) {
   if (c->side[lane]) return true;
-  JDA_HIP(create_priority_stream(&c->side[lane], env_ll("JDA_SIDE_PRIO", 0) != 0));
+  JDA_HIP(hipStreamCreateWithFlags(&c->side[lane], hipStreamNonBlocking));
   for (auto& ev : c->ev_side[lane]) JDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   return true;
 }
@@ -412,9 +491,10 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
                       c_fix = (double)env_ll("JDA_TILE_CFIX", 1500), w_sat = (double)env_ll("JDA_TILE_WSAT", 20),
                       alpha = (double)env_ll("JDA_TILE_ALPHA_PCT", 70) / 100.0;
   const int lds_cu = 160 * 1024;
-  const int lds_max = (int)std::min<long long>(lds_cu, env_ll("JDA_SCAN_LDS_MAX", lds_cu));
+  static const int lds_max = (int)std::min<long long>(lds_cu, env_ll("JDA_SCAN_LDS_MAX", lds_cu));
+  static const char* const tiles_env = std::getenv("JDA_TILES");      // (experiments; read once per process)
   int force_tw = 0, force_th = 0;
-  if (const char* e = std::getenv("JDA_TILES")) {
+  if (const char* e = tiles_env) {
     for (const char* p = e; p && *p;) {
       int w = 0, a = 0, b = 0;
       if (std::sscanf(p, "%d:%dx%d", &w, &a, &b) == 3 && w == s.win) { force_tw = a; force_th = b; }
@@ -442,7 +522,7 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
       const long long pix = (long long)pitch * ph;
       const int block = n_tile > 256 ? 512 : 256;
       const long long lds = (block == 512 ? fixed512 : fixed256) + ((pix + 15) & ~15LL);
-      if (lds > lds_max) break;                      // wider tiles of this height are larger still
+      if (lds > lds_max) continue;                   // (the pitch is not monotonic in tw: a wider tile can fit again)
       const long long max_off = (long long)(s.win - 1) * pitch + s.win - 1 + 15;
       if (max_off >= (1LL << kS0GlobalOffBits)) continue;
       const int mode = max_off <= 65535 ? 1 : 3;
@@ -462,26 +542,26 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
   return best;
 }
 
-static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan, int real_bytes, PlanEntry* pe) {
+static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool fast_scan, int real_bytes, PlanEntry* pe) {
   DevPlan& hp = pe->hp;
   hp.n_levels = (int)sp.levels.size();
   hp.width = sp.width; hp.height = sp.height; hp.windows = (int)sp.windows;
   int table = 0;
   pe->any_untiled = false;
-  const int handoff = (int)env_ll("JDA_HANDOFF", kDefaultHandoff);
+  const int handoff = (int)kn.handoff;
   const int chunk = std::min(std::min(hm.K, handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), real_bytes));
-  const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, env_ll("JDA_CP_MAX", 128)));
+  const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn.cp_max));
   // a level's cost per window in global-pixel mode, in the units of choose_tile (r01: 0.38 ms for 952 k windows)
-  const double glb_per_window = (double)env_ll("JDA_TILE_CGLB", 800);
+  const double glb_per_window = (double)kn.tile_cglb;
   for (int i = 0; i < hp.n_levels; i++) {
     const Level& s = sp.levels[i];
     DevLevel& d = hp.lv[i];
     d.win = s.win; d.step = s.step; d.nx = s.nx; d.ny = s.ny; d.base = (int)s.base;
     d.tiled = 0; d.tw = d.th = 1; d.tiles_x = d.tiles_y = 0; d.pitch = 0; d.s0_table = 0;
-    const bool glb_ok = env_ll("JDA_NO_GLOBAL_SCAN", 0) == 0 &&
+    const bool glb_ok = kn.no_global_scan == 0 &&
                         (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits);
     if (fast_scan) {
-      const TileChoice t = (env_ll("JDA_NO_LDS_SCAN", 0) || s.win > env_ll("JDA_LDS_WIN_MAX", 100)) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
+      const TileChoice t = (kn.no_lds_scan || s.win > kn.lds_win_max) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
       if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
         d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
       } else if (glb_ok) {
@@ -489,7 +569,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
         // grouping of up to 512 windows per workgroup here: the shape that wastes the fewest lane slots of the
         // first phase (a fixed 32 x 16 filled about half of them on the big-window levels of 640x480)
         d.tiled = 2; d.tw = 32; d.th = 16; d.pitch = sp.width;
-        if (env_ll("JDA_GLB_TILE_FIT", 1)) {
+        if (kn.glb_tile_fit) {
           long long best = -1;
           for (int th = 1; th <= std::min(s.ny, 512); th++)
             for (int tw = 1; tw <= std::min(s.nx, 512) && tw * th <= 512; tw++) {
@@ -502,7 +582,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, bool fast_scan
             }
         }
       }
-      if (env_ll("JDA_DEBUG_TILES", 0))
+      if (kn.debug_tiles)
         std::fprintf(stderr, "[jda] level %d win %d step %d windows %dx%d: mode %d tile %dx%d pitch %d pix %d lds %d block %d cost/window %.0f\n",
                      i, s.win, s.step, s.nx, s.ny, d.tiled, d.tw, d.th, d.pitch, t.pix, t.lds, t.block,
                      t.mode ? t.cost / ((double)s.nx * s.ny) : 0.0);
@@ -519,12 +599,14 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   auto it = c->plans.find(key);
   if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; *out = &it->second; return true; }
   // bounded cache: a stream of differently sized images (FDDB) must not pile up device tables
-  const size_t cap = (size_t)std::max<long long>(2, env_ll("JDA_PLAN_CACHE", 64));
+  const size_t cap = (size_t)std::max<long long>(2, c->kn.plan_cache);
   while (c->plans.size() >= cap) {
-    auto victim = c->plans.begin();
+    // least recently used plan that no submitted batch still runs on (PlanEntry::pins): a pending ticket's kernels
+    // read the plan's device tables until its Wait
+    auto victim = c->plans.end();
     for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
-      if (p->second.last_use < victim->second.last_use) victim = p;
-    // the caller holds c->mu and every detect call ends synchronised, so nothing is using the victim
+      if (p->second.pins == 0 && (victim == c->plans.end() || p->second.last_use < victim->second.last_use)) victim = p;
+    if (victim == c->plans.end()) break;        // every plan is pinned (at most kLanes are): exceed the cap for now
     c->plan_pool.push_back({victim->second.dp, victim->second.table, victim->second.table_cap});
     c->plans.erase(victim);
   }
@@ -537,8 +619,8 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   bool s0_plain = true;
   const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
   for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
-  pe.fast_scan = s0_plain && env_ll("JDA_NO_FAST_SCAN", 0) == 0;
-  assign_tiles(sp, c->hm, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe);
+  pe.fast_scan = s0_plain && c->kn.no_fast_scan == 0;
+  assign_tiles(sp, c->hm, c->kn, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe);
   size_t entries = 0;
   pe.lm_ok = true;
   for (int i = 0; i < pe.hp.n_levels; i++)
@@ -566,6 +648,8 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     JDA_HIP(hipStreamSynchronize(c->stream[0]));
   }
   pe.last_use = ++c->plan_clock;
+  pe.pred_tail = c->pred_tail; pe.pred_out = c->pred_out;      // a new frame size starts from the cascador's last pass
+  pe.dense_hint = c->last_dense;
   auto ins = c->plans.emplace(key, std::move(pe));
   *out = &ins.first->second;
   return true;
@@ -691,9 +775,10 @@ struct Pass {
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
   // state between the steps
   bool dense = false, finished = false, lds_span = false;
+  bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
+  bool counters_issued = false, results_pending = false;
   long long n_tail = -1;
-  size_t n_out = 0;
-  std::vector<uint32_t> g; std::vector<Real> sc, sh;
+  size_t n_out = 0, out_copied = 0;   // detections of the pass / how many of them are already on their way to the host
 
   const HostModel& hm() const { return c->hm; }
   const DevModelT<Real>& model() const { return Sel<Real>::model(c).m; }
@@ -711,16 +796,17 @@ struct Pass {
   }
   // resolved stage-0 tables for k_finish (A/B switch: JDA_FIN_S0=0)
   // k_finish reads the level-major copy of the stage-0 tables (second half of the allocation)
-  const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && pe->lm_ok && env_ll("JDA_FIN_S0", 1)) ? pe->table + pe->table_cap : nullptr; }
+  const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && pe->lm_ok && c->kn.fin_s0) ? pe->table + pe->table_cap : nullptr; }
+  const Knobs& kn() const { return c->kn; }
   long long windows() const { return (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {
     constexpr int dialect = Sel<Real>::dialect;
-    const long long dense_env = env_ll("JDA_DENSE", 1);           // 0 off, 1 auto, 2 always
-    *lds_max = (int)env_ll("JDA_DENSE_LDS_MAX", 160 * 1024);
+    const long long dense_env = kn().dense;                       // 0 off, 1 auto, 2 always
+    *lds_max = (int)kn().dense_lds_max;
     const int dim = hm().dim();
     const int fixed = (int)stage_lds_bytes(dim, hm().node_n(), hm().leaf_n(), (int)sizeof(Real));
-    *pix_cap = std::max(0, std::min<int>((int)env_ll("JDA_DENSE_PIX", 16 * 1024), *lds_max - fixed));
+    *pix_cap = std::max(0, std::min<int>((int)kn().dense_pix, *lds_max - fixed));
     return dense_env != 0 && !multi && !(dialect == JDA_DIALECT_CPP && c->similarity) &&
            dim <= 160 && hm().leaf_n() <= 256 && fixed <= *lds_max;
   }
@@ -771,7 +857,7 @@ struct Pass {
     //      the results do not depend on the choice. ----
     int pix_cap, lds_max;
     const bool ok = dense_ok(&pix_cap, &lds_max);
-    dense = ok && (env_ll("JDA_DENSE", 1) == 2 || pe->dense_hint);
+    dense = ok && (kn().dense == 2 || pe->dense_hint);
     if (dense) {
       JDA_HIP(hipEventRecord(ev[1], st));
       JDA_HIP(hipEventRecord(ev[2], st));
@@ -781,14 +867,14 @@ struct Pass {
     // ---- windows k_scan does not cover enter the hand-off queue at cart 0 ----
     if (!pe->fast_scan || pe->any_untiled) JDA_HIP(launch_enqueue<Real>(pe->dp, pe->hp, !pe->fast_scan, w, st));
     // ---- stage-0 scan: first `handoff` carts, one launch per LDS-tiled level ----
-    // (optionally staggered behind the previous lane's scan, JDA_LANES_STAGGER=1; measured
-    // SLOWER than letting both scans share the machine: 2.65 ms vs 2.39 ms per 256-frame step,
-    // because half-size scans are less efficient and k_finish is throughput bound itself)
-    if (scan_after) JDA_HIP(hipStreamWaitEvent(st, scan_after, 0));
+    // (staggering a lane's scan behind the previous lane's was measured SLOWER than letting both scans share the
+    // machine: 2.65 ms vs 2.39 ms per 256-frame step -- half-size scans are less efficient and k_finish is
+    // throughput bound itself)
+    (void)scan_after;
     JDA_HIP(hipEventRecord(ev[1], st));
     if (pe->fast_scan) {
-      const int handoff = (int)env_ll("JDA_HANDOFF", kDefaultHandoff);
-      const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, env_ll("JDA_CP_MAX", 128)));
+      const int handoff = (int)kn().handoff;
+      const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
       bool any_glb = false, any_wide = false, side_pending = false;
       long long lds_blocks = 0;
       for (int l = 0; l < pe->hp.n_levels; l++) {
@@ -797,14 +883,8 @@ struct Pass {
         if (pe->hp.lv[l].tiled == 1) lds_blocks += (long long)pe->hp.lv[l].tiles_x * pe->hp.lv[l].tiles_y * nf;
       }
       auto scan = [&](int mode, int level, hipStream_t s) -> bool {
-        // 8 trees in flight per lane where a level's pixel tile leaves room for few waves per CU (JDA_ILP8_LDS:
-        // LDS bytes per workgroup above which; the kernel is latency bound there, LDS-pipe bound below)
-        int opts = (int)(std::max<long long>(4, std::min<long long>(64, env_ll("JDA_FIRST_PHASE", 16))) & ~3LL) << 8;
-        if (level >= 0 && mode == 1) {
-          const DevLevel& lv = pe->hp.lv[level];
-          if ((long long)lv.pitch * (lv.win + (lv.th - 1) * lv.step) >= env_ll("JDA_ILP8_LDS", 1 << 30)) opts |= 1;
-        }
-        if (mode == 3 && env_ll("JDA_ILP8_WIDE", 0)) opts |= 1;
+        // (opts bit 0, 8 trees in flight per lane in the LDS-tiled modes, was measured neutral to slower: off)
+        const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
         JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, s));
         rs->scan_launches++;
         return true;
@@ -822,18 +902,18 @@ struct Pass {
         side_pending = true;
         return true;
       };
-      const bool small = lds_blocks <= env_ll("JDA_MERGE_BLOCKS", 2048);
+      const bool small = lds_blocks <= kn().merge_blocks;
       if (small) {
         // small job (a frame or a few): all levels of a pixel mode in one launch -- every workgroup
         // is resident at once anyway, so per-level launches would only serialise their latency
-        if (any_glb && solo && env_ll("JDA_SIDE_SMALL", 0) && ensure_side(c, lane) && !fork_glb()) return false;
+        if (any_glb && solo && kn().side_small && ensure_side(c, lane) && !fork_glb()) return false;
         if (lds_blocks > 0 && !scan(1, -1, st)) return false;
         if (any_wide && !scan(3, -1, st)) return false;
       } else {
         // odd lanes go through the levels in the opposite order (big windows first): the launches of
         // one lane then run next to different ones of the other instead of next to their twins
-        const bool rev = (lane & 1) && env_ll("JDA_LANES_REVERSE", 1);
-        if (any_glb && solo && env_ll("JDA_SIDE_STREAM", 1) && ensure_side(c, lane) && !fork_glb()) return false;
+        const bool rev = (lane & 1) && kn().lanes_reverse;
+        if (any_glb && solo && kn().side_stream && ensure_side(c, lane) && !fork_glb()) return false;
         if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
@@ -844,39 +924,40 @@ struct Pass {
           if (!scan(1, l, st)) return false;
         }
       }
-      lds_span = !side_pending && !(((lane & 1) && env_ll("JDA_LANES_REVERSE", 1)) && !small);   // LDS launches first, back to back
+      lds_span = !side_pending && !(((lane & 1) && kn().lanes_reverse) && !small);   // LDS launches first, back to back
       if (lds_span) JDA_HIP(hipEventRecord(ev[4], st));
       if (any_glb && !scan(2, -1, st)) return false;
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
+    // With a prediction of the hand-off queue's length (earlier passes on this plan) everything else is queued
+    // right here, behind the scan: finishing launches sized by the prediction, counters and a predicted prefix of
+    // the detections -> host.  The pass is then one enqueue and ONE host wait (after_counters).  Without one, the
+    // host reads the queue length first (after_tail).
+    if (kn().predict && pe->pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pe->pred_tail >= 0.4)) {
+      const long long nw = windows();
+      const long long guess = std::min<long long>((long long)cap, (long long)(pe->pred_tail * (double)nw * 1.1) + 64);
+      if (!launch_finishers(guess)) return false;
+      predicted = true;
+      if (!issue_counters()) return false;
+      const double po = pe->pred_out >= 0 ? pe->pred_out : 0.0;
+      return issue_results(0, std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64));
+    }
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
     return read_counter(kCntTail);
   }
 
-  // step 2: every survivor of the scan: remaining carts of stage 0 (+ all stages when few are left)
-  bool after_tail() {
-    if (finished) return true;
-    JDA_HIP(hipStreamSynchronize(st));
-    n_tail = (long long)std::min<unsigned long long>(h_cnt[0], cap);
+  // Finishing launches for a hand-off queue of (about) n_grid windows: the kernels take the true length from the
+  // device counter and stride over it, n_grid only sizes the grids.
+  bool launch_finishers(long long n_grid) {
     const int T = hm().T;
-    int pix_cap, lds_max;
-    const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
-    if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
-      // most windows are still alive after the scan: start over in dense mode (the scan's work
-      // is a small part of T*K carts per window) and remember the choice for the next pass
-      dense = true; finished = true;
-      pe->dense_hint = true;
-      if (!clear_counters()) return false;
-      return run_dense();
-    }
-    // the scan is done (the host has just waited for it): the finishing kernels, the counters and the results
-    // may go to the lane's high-priority stream
-    if (env_ll("JDA_FIN_PRIO", 0) && ensure_fin(c, lane)) st = c->fin[lane];
-    if (T == 1 || n_tail <= env_ll("JDA_FINISH_MERGE", 4096)) {
+    const int gm = kn().fin_gm > 0 ? (int)kn().fin_gm : stage_groups();
+    const int g2 = kn().fin_g2 > 0 ? (int)kn().fin_g2 : stage_groups();
+    n_grid = std::max<long long>(n_grid, 1);
+    if (T == 1 || n_grid <= kn().finish_merge) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
-      // one launch + one synchronisation less)
-      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_GM", stage_groups()), n_tail, s0_tbl(), (int)env_ll("JDA_FIN_TILE", kFinishTileWin), st));
+      // one launch less)
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, gm, n_grid, s0_tbl(), (int)kn().fin_tile, st));
       finished = true;
       return true;
     }
@@ -885,11 +966,30 @@ struct Pass {
     // of the mid queue (the kernel reads it from the device counter): its grid is a quarter of the hand-off count
     // -- one workgroup per window as long as fewer than 25 % pass stage 0 (6.7 % in the cascade regime), a grid-stride
     // loop beyond that; the surplus workgroups exit at once (an empty workgroup costs ~1.3 ns of dispatcher time).
-    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G1", 1), n_tail, s0_tbl(), (int)env_ll("JDA_FIN_TILE1", kFinishTileWin1), st));
-    const long long wg2 = std::min<long long>(n_tail, std::max<long long>(2048, n_tail / std::max<long long>(1, env_ll("JDA_FIN_GRID_DIV", 4))));
-    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, (int)env_ll("JDA_FIN_G2", stage_groups()), wg2, nullptr, (int)env_ll("JDA_FIN_TILE", kFinishTileWin), st));
+    JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)kn().fin_g1, n_grid, s0_tbl(), (int)kn().fin_tile1, st));
+    const long long wg2 = std::min<long long>(n_grid, std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)));
+    JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, g2, wg2, nullptr, (int)kn().fin_tile, st));
     finished = true;
     return true;
+  }
+
+  // step 2 (passes without a prediction): every survivor of the scan: remaining carts of stage 0 (+ all stages
+  // when few are left)
+  bool after_tail() {
+    if (finished) return true;
+    JDA_HIP(hipStreamSynchronize(st));
+    n_tail = (long long)std::min<unsigned long long>(h_cnt[0], cap);
+    int pix_cap, lds_max;
+    const double dense_frac = (double)kn().dense_pct / 100.0;
+    if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
+      // most windows are still alive after the scan: start over in dense mode (the scan's work
+      // is a small part of T*K carts per window) and remember the choice for the next pass
+      dense = true; finished = true;
+      pe->dense_hint = true;
+      if (!clear_counters()) return false;
+      return run_dense();
+    }
+    return launch_finishers(n_tail);
   }
 
   // step 3: (nothing left to wait for between the two finishing launches)
@@ -897,15 +997,34 @@ struct Pass {
 
   // step 4: counters -> host (asynchronous)
   bool issue_counters() {
+    if (counters_issued) return true;
+    counters_issued = true;
     JDA_HIP(hipEventRecord(ev[3], st));
     JDA_HIP(hipMemcpyAsync(h_cnt, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
     return true;
   }
 
-  // step 5: statistics, detections -> host (asynchronous)
+  // detections [from, to) of the device list -> the lane's pinned host arrays (asynchronous)
+  bool issue_results(size_t from, size_t to) {
+    const int dim = hm().dim();
+    if (!dets || to <= from) return true;
+    HostPinned &hg = c->h_gid[lane], &hs = c->h_score[lane], &hh = c->h_shape[lane];
+    if (!hg.reserve(to * 4, from * 4) || !hs.reserve(to * sizeof(Real), from * sizeof(Real)) ||
+        !hh.reserve(to * dim * sizeof(Real), from * dim * sizeof(Real))) return false;
+    const size_t n = to - from;
+    JDA_HIP(hipMemcpyAsync((uint32_t*)hg.p + from, w.out_gid + from, n * 4, hipMemcpyDeviceToHost, st));
+    JDA_HIP(hipMemcpyAsync((Real*)hs.p + from, w.out_score + from, n * sizeof(Real), hipMemcpyDeviceToHost, st));
+    JDA_HIP(hipMemcpyAsync((Real*)hh.p + from * dim, w.out_shape + from * dim, n * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
+    out_copied = to;
+    results_pending = true;
+    return true;
+  }
+
+  // step 5: statistics, (the rest of) the detections -> host (asynchronous)
   bool after_counters() {
-    const int T = hm().T, dim = hm().dim();
+    const int T = hm().T;
     JDA_HIP(hipStreamSynchronize(st));
+    results_pending = false;
     for (int shd = 1; shd < kCntShards; shd++)     // fold the counter shards into shard 0
       for (int i = 0; i < kCntTotal; i++) h_cnt[i] += h_cnt[shd * kCntStride + i];
     rs->carts += (long long)h_cnt[kCntCarts];
@@ -914,21 +1033,29 @@ struct Pass {
     rs->win_scan += (long long)h_cnt[kCntWinScan];
     for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)h_cnt[kCntStage0 + t];
     rs->tail += (long long)h_cnt[kCntTail];
+    const double nw = (double)windows();
+    const double dense_frac = (double)kn().dense_pct / 100.0;
     if (dense) {
       rs->dense_passes++;
       // fall back to the sparse pipeline when stage 0 rejects most windows after all
-      const double dense_frac = (double)env_ll("JDA_DENSE_PCT", 50) / 100.0;
-      if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * (double)windows()) pe->dense_hint = false;
+      if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * nw) pe->dense_hint = false;
+    } else {
+      // what the next pass on this plan (and a new plan of this cascador) may expect; a prediction decays slowly,
+      // so that one quiet batch does not undersize the launches of the next busy one
+      const double ft = (double)h_cnt[kCntTail] / nw;
+      pe->pred_tail = std::max(ft, pe->pred_tail * 0.9);
+      c->pred_tail = pe->pred_tail;
+      int pix_cap, lds_max;
+      if (predicted && kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && ft >= dense_frac && h_cnt[kCntTail] > 4096)
+        pe->dense_hint = true;       // this pass went through k_finish window by window; the next one runs dense
     }
+    c->last_dense = pe->dense_hint;
+    n_tail = (long long)h_cnt[kCntTail];
     n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;
     if (n_out > cap) { fail("internal: more detections than windows"); return false; }
-    if (n_out && dets) {
-      g.resize(n_out); sc.resize(n_out); sh.resize(n_out * dim);
-      JDA_HIP(hipMemcpyAsync(g.data(), w.out_gid, n_out * 4, hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipMemcpyAsync(sc.data(), w.out_score, n_out * sizeof(Real), hipMemcpyDeviceToHost, st));
-      JDA_HIP(hipMemcpyAsync(sh.data(), w.out_shape, n_out * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
-    }
+    if (!dense) { pe->pred_out = std::max((double)n_out / nw, pe->pred_out * 0.9); c->pred_out = pe->pred_out; }
+    if (n_out > out_copied && !issue_results(out_copied, n_out)) return false;   // the prediction fell short (or there was none)
     return true;
   }
 
@@ -938,8 +1065,12 @@ struct Pass {
     const long long wpf = pe->sp.windows;
     const double t_dbg = now_ms();
     if (n_out && dets) {
-      JDA_HIP(hipStreamSynchronize(st));
-      if (env_ll("JDA_DEBUG_TIMES", 0)) fprintf(stderr, "[jda] lane %d: results D2H wait %.3f ms (%zu detections)\n", lane, now_ms() - t_dbg, n_out);
+      if (results_pending) JDA_HIP(hipStreamSynchronize(st));
+      results_pending = false;
+      if (kn().debug_times) fprintf(stderr, "[jda] lane %d: results D2H wait %.3f ms (%zu detections)\n", lane, now_ms() - t_dbg, n_out);
+      const uint32_t* g = (const uint32_t*)c->h_gid[lane].p;
+      const Real* sc = (const Real*)c->h_score[lane].p;
+      const Real* sh = (const Real*)c->h_shape[lane].p;
       // back into scan order: sort (gid, arrival index) packed in one word -- gids are unique
       std::vector<unsigned long long> key(n_out);
       for (size_t i = 0; i < n_out; i++) key[i] = ((unsigned long long)g[i] << 32) | (unsigned long long)i;
@@ -953,7 +1084,7 @@ struct Pass {
         dets->score[o0 + i] = sc[j];
         std::memcpy(&dets->shape[(o0 + i) * dim], &sh[(size_t)j * dim], dim * sizeof(Real));
       }
-      if (env_ll("JDA_DEBUG_TIMES", 0)) fprintf(stderr, "[jda] lane %d: collect total %.3f ms\n", lane, now_ms() - t_dbg);
+      if (kn().debug_times) fprintf(stderr, "[jda] lane %d: collect total %.3f ms\n", lane, now_ms() - t_dbg);
     }
     if (want_trace()) {
       JDA_HIP(hipStreamSynchronize(st));
@@ -988,8 +1119,8 @@ struct PendingBatch {
 
 // test hook: JDA_TEST_WPF_SCALE pretends every frame has that many times more windows (the gid-overflow guard
 // is otherwise only reachable with thousands of 4K frames)
-static bool jda_gid_overflow(long long n, long long wpf) {
-  const long long scale = std::max<long long>(1, env_ll("JDA_TEST_WPF_SCALE", 1));
+static bool jda_gid_overflow(const Knobs& kn, long long n, long long wpf) {
+  const long long scale = std::max<long long>(1, kn.test_wpf_scale);
   return (double)n * (double)wpf * (double)scale > 4294967295.0;
 }
 
@@ -1019,19 +1150,19 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   }
 
   // two lanes when the batch is big enough for each half to fill the machine
-  const long long lanes_min = env_ll("JDA_LANES_MIN_WINDOWS", 2000000);
-  int lanes = (int)env_ll("JDA_LANES", 2);
+  const long long lanes_min = c->kn.lanes_min_windows;
+  int lanes = (int)c->kn.lanes;
   if (lanes < 1) lanes = 1;
   if (lanes > kLanes) lanes = kLanes;
   if (n < 2 || (long long)n * wpf < lanes_min * 2) lanes = 1;
   // frames still on the host: smaller sub-batches on two lanes, so that the (host-blocking, pageable)
   // copy of one sub-batch overlaps the kernels of the previous one
-  const long long host_chunk = env_ll("JDA_HOST_CHUNK", 128);
-  if (host_frames && n >= 2 * host_chunk && env_ll("JDA_LANES", 2) >= 2) lanes = 2;
+  const long long host_chunk = c->kn.host_chunk;
+  if (host_frames && n >= 2 * host_chunk && c->kn.lanes >= 2) lanes = 2;
 
   // frames per sub-batch, bounded by the workspace budget (shared by the lanes)
   const size_t bpw = bytes_per_window<Real>(dim, want_trace);
-  const long long budget = (env_ll("JDA_WORKSPACE_MB", 24 * 1024) << 20) / lanes;
+  const long long budget = (c->kn.workspace_mb << 20) / lanes;
   long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
   fpp = std::min<long long>(fpp, (n + lanes - 1) / lanes);
   if (host_frames && lanes > 1) fpp = std::min<long long>(fpp, std::max<long long>(1, host_chunk));
@@ -1041,7 +1172,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   // detections carry a 32-bit gid over the WHOLE batch (frame * windows-per-frame + scan index): the
   // frame split in the post-processing divides by windows-per-frame, so a wrapped gid would land in
   // the wrong frame silently
-  if (jda_gid_overflow(n, wpf)) {
+  if (jda_gid_overflow(c->kn, n, wpf)) {
     fail("batch too large: frames x windows per frame exceeds 2^32 window ids -- split the batch");
     return false;
   }
@@ -1099,8 +1230,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     }
     for (auto& p : ps) {
       uint8_t* hbuf = multi ? (uint8_t*)ws.pyr.p + (hs + qs) * (size_t)fpp * (size_t)p.lane : nullptr;
-      hipEvent_t scan_after = (p.lane > 0 && env_ll("JDA_LANES_STAGGER", 0)) ? c->ev[p.lane - 1][2] : nullptr;
-      if (!p.issue_scan(hbuf, hs, hbuf ? hbuf + hs * (size_t)fpp : nullptr, qs, scan_after)) return false;
+      if (!p.issue_scan(hbuf, hs, hbuf ? hbuf + hs * (size_t)fpp : nullptr, qs, nullptr)) return false;
     }
     for (auto& p : ps) if (!p.after_tail()) return false;
     for (auto& p : ps) if (!p.after_mid()) return false;
@@ -1127,7 +1257,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       if (hipEventElapsedTime(&ms, ps[0].ev[0], p.ev[3]) == hipSuccess) ms_all = std::max(ms_all, ms);
     }
     rs->gpu_ms += ms_all;
-    if (env_ll("JDA_DEBUG_TIMES", 0)) {
+    if (c->kn.debug_times) {
       for (auto& p : ps) {
         float a = 0, b = 0, d = 0;
         (void)hipEventElapsedTime(&a, p.ev[0], p.ev[1]); (void)hipEventElapsedTime(&b, p.ev[1], p.ev[2]);
@@ -1347,7 +1477,6 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &sp, &pe)) return -1;
   RawDets<float> dets;
   RunStats rs;
-  PostPool::get().prewake(n, env_ll("JDA_POST_PREWAKE_MS", 0));   // per-frame NMS + assembly follows the GPU work
   if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
     return -1;
   const double post_ms = post_c(c, sp, dets, n, opt, out);
@@ -1374,6 +1503,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   pb.join_issuer();
   pb = PendingBatch();
   if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &pb.sp, &pb.pe)) return -1;
+  PlanEntry* const plan_entry = pb.pe;
   const long long wpf = pb.sp.windows;
   if (wpf <= 0) { fail("no candidate window in these frames"); return -1; }
   if ((long long)n * wpf > 0x7fffffffLL || n > 65535) { fail("batch too large for one submit: split it"); return -1; }
@@ -1413,11 +1543,12 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
     if (hipEventRecord(c->ev_user, (hipStream_t)opt->hip_stream) != hipSuccess ||
         hipStreamWaitEvent(p.st, c->ev_user, 0) != hipSuccess) { fail("cannot order the batch behind opt->hip_stream"); return -1; }
   }
-  if (host_frames && env_ll("JDA_HOST_SUBMIT_THREAD", 1)) {
+  if (host_frames && c->kn.host_submit_thread) {
     // the copy + scan launches of this ticket on their own thread (joined by Wait): a pageable H2D copy blocks
     // its caller for the whole transfer (1.8 ms per 256 frames 640x480), time in which the submitting thread can
     // already collect and post-process the other ticket
     pb.active = true;
+    plan_entry->pins++;
     pb.issue_ok = true; pb.issue_err.clear();
     PendingBatch* pbp = &pb;
     const int dev = c->device;
@@ -1431,6 +1562,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   }
   if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) return -1;
   pb.active = true;
+  plan_entry->pins++;
   return slot;
 }
 
@@ -1443,6 +1575,7 @@ static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out)
   Pass<float>& p = pb.pass;
   pb.join_issuer();
   pb.active = false;
+  if (pb.pe && pb.pe->pins > 0) pb.pe->pins--;
   if (!pb.issue_ok) { fail(pb.issue_err); return -1; }
   p.dets = &pb.dets; p.rs = &pb.rs;              // (the PendingBatch may have moved since submit: re-point)
   if (!p.after_tail() || !p.after_mid() || !p.issue_counters() || !p.after_counters() || !p.collect()) return -1;
@@ -1492,6 +1625,7 @@ static void* create_impl(const char* path, int real_bytes) {
   g_err.clear();
   Cascador* c = new (std::nothrow) Cascador();
   if (!c) return nullptr;
+  c->kn.load();
   std::string err;
   if (!load_model(path, real_bytes, &c->hm, &err)) {
     g_err = err;   // reference returns NULL silently (c/jda.c:487-488); keep the reason retrievable
@@ -1524,11 +1658,11 @@ void jdaCascadorRelease(void* cascador) {
     c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
     for (auto& b : c->submit_frames) b.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (int l = 0; l < kLanes; l++) { c->h_gid[l].release(); c->h_score[l].release(); c->h_shape[l].release(); }
     for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
     for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
     for (auto& st : c->side) if (st) (void)hipStreamDestroy(st);
-    for (auto& st : c->fin) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& l : c->ev_side) for (auto& ev : l) if (ev) (void)hipEventDestroy(ev);
   }
   delete[] c->pending;
@@ -1562,6 +1696,31 @@ int jdaSetDevice(void* cascador, int device) {
   if (c->dev_init && c->device != device) { fail("jdaSetDevice after first use"); return -1; }
   c->device = device;
   return 0;
+}
+
+int jdaSetOption(void* cascador, const char* key, long long value) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !key) { fail("jdaSetOption: null cascador or key"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  for (int i = 0; c->pending && i < kLanes; i++)
+    if (c->pending[i].active) { fail("jdaSetOption while a submitted batch is pending"); return -1; }
+  if (!c->kn.set(key, value)) { fail(std::string("jdaSetOption: unknown option '") + key + "'"); return -1; }
+  // scan plans (tile shapes, table chunking) depend on the knobs: rebuild them on next use
+  if (c->dev_init) {
+    (void)hipSetDevice(c->device);
+    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
+  }
+  for (auto& kv : c->plans) c->plan_pool.push_back({kv.second.dp, kv.second.table, kv.second.table_cap});
+  c->plans.clear();
+  return 0;
+}
+
+long long jdaGetOption(void* cascador, const char* key) {
+  Cascador* c = (Cascador*)cascador;
+  long long v = 0;
+  if (!c || !key || !c->kn.get(key, &v)) { fail("jdaGetOption: unknown option"); return -1; }
+  return v;
 }
 
 int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
@@ -1908,7 +2067,7 @@ int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int mi
   bool s0_plain = true;
   const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
   for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
-  assign_tiles(sp, c->hm, s0_plain, 4, &pe);
+  assign_tiles(sp, c->hm, c->kn, s0_plain, 4, &pe);
   for (int i = 0; i < pe.hp.n_levels && i < cap_levels && out; i++) {
     const DevLevel& d = pe.hp.lv[i];
     const int v[10] = {d.win, d.step, d.nx, d.ny, d.tiled, d.tw, d.th, d.pitch, d.tiles_x, d.tiles_y};

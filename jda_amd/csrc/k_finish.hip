@@ -482,8 +482,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
     for (int tw = 16; tw <= 255; tw++)
       if (base + (size_t)tw * ((tw + 3) & ~3) + 16 <= kFinishLdsPerGroup) tile_win = tw;
   }
-  size_t tile_bytes = tile_win > 0 ? (size_t)tile_win * ((tile_win + 3) & ~3) + 16 : 0;
-  if (const char* e = getenv("JDA_FIN_LDS_EXTRA")) tile_bytes += (size_t)atoll(e);    // experiment: LDS size without use
+  const size_t tile_bytes = tile_win > 0 ? (size_t)tile_win * ((tile_win + 3) & ~3) + 16 : 0;
   const size_t lds = base + tile_bytes;
   const float r = 1.f / sqrtf(2.f);
   // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to

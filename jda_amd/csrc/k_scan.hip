@@ -559,10 +559,7 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
   if (L.total > 160 * 1024) return hipErrorInvalidValue;
   const int groups = (w.n_frames + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * tiles)), block(BLOCK);
-  // JDA_SCAN_LDS_PAD (experiment): ask for at least that much LDS per workgroup of an LDS-tiled launch, i.e. cap
-  // its workgroups per CU, leaving wave slots and LDS to the kernels of the other batch in flight
-  int lds_req = L.total;
-  if (MODE == 1) if (const char* e = getenv("JDA_SCAN_LDS_PAD")) lds_req = std::min(160 * 1024, std::max(lds_req, atoi(e)));
+  const int lds_req = L.total;
   auto go = [&](auto kern) {
     if (lds_req > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);

@@ -274,9 +274,8 @@ hipError_t launch_stage_impl(bool trace, int level, int t, bool apply_th, typena
   const bool glb = need > pix_cap;
   const int pix_bytes = glb ? 0 : (int)need;
   const int acc = dense_acc(m.dim);
-  int chunk = dense_chunk<Real, Node>(pix_bytes, m.dim, m.node_n, m.leaf_n, m.K, lds_max);
+  const int chunk = dense_chunk<Real, Node>(pix_bytes, m.dim, m.node_n, m.leaf_n, m.K, lds_max);
   if (chunk == 0) return hipErrorInvalidValue;
-  if (const char* e = getenv("JDA_DENSE_CHUNK")) chunk = std::max(4, std::min(chunk, atoi(e)));   // experiments
   const DenseLds<Real, Node> L(pix_bytes, m.dim, m.node_n, m.leaf_n, chunk, acc);
   const int tiles = ((lv.nx + kDenseTw - 1) / kDenseTw) * ((lv.ny + kDenseTh - 1) / kDenseTh);
   const int groups = (w.n_frames + 7) / 8;

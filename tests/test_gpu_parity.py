@@ -1011,17 +1011,20 @@ def test_submit_host_frames_pageable_and_pinned(built, gpu, model_file):
 
 def test_batch_too_large_for_32bit_window_ids_is_refused(built, gpu, model_file, monkeypatch):
     """Detections carry a 32-bit window id over the whole batch; a batch whose frames x windows exceeds 2^32
-    must fail loudly instead of wrapping (JDA_TEST_WPF_SCALE inflates the count the guard sees)."""
+    must fail loudly instead of wrapping (the test_wpf_scale option inflates the count the guard sees)."""
     from jda_amd import api, synth
     p, _ = model_file((2, 8, 5, 3), 8, seed=5)
     frames = synth.make_frames(2, 100, 80, seed=6)
     c = api.Cascador(p)
     assert len(c.detect_batch(frames)) == 2
-    monkeypatch.setenv("JDA_TEST_WPF_SCALE", "1000000000")
+    c.set_option("test_wpf_scale", 1000000000)          # jdaSetOption: the knobs are per cascador, not per call
+    assert c.get_option("test_wpf_scale") == 1000000000
     with pytest.raises(api.JdaError, match="batch too large"):
         c.detect_batch(frames)
-    monkeypatch.delenv("JDA_TEST_WPF_SCALE")
+    c.set_option("test_wpf_scale", 1)
     assert len(c.detect_batch(frames)) == 2
+    with pytest.raises(api.JdaError, match="unknown option"):
+        c.set_option("no_such_knob", 1)
 
 
 def test_c_gather_entry_over_rccl_group_of_one(built, gpu, model_file):
