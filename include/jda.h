@@ -197,6 +197,25 @@ JDA_API int jdaDetectBatchDevice(void *cascador, const unsigned char *d_frames,
                                  float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt, jdaResult *out);
 
+/* Ragged batch: n images of DIFFERENT sizes in one job -- the reference's FDDB loop, one Detect per image
+ * (src/test.cpp:100-170), or any loop of jdaDetect calls over a list of images.  images[i] is widths[i]*heights[i]
+ * bytes in HOST memory, rows back to back (the `data` of jdaDetect); out must point at n jdaResult slots.  Per
+ * image the result is identical to jdaDetect(cascador, images[i], widths[i], heights[i], scale, step, min_size,
+ * max_size, th).  The images are staged on the device with one common row pitch, the pyramid levels (the same
+ * window-size series for every image, c/jda.c:331-333) share tile shapes and stage-0 tables, and the job runs as a
+ * few large passes (chunks of `ragged_chunk_windows` candidate windows, three in flight) instead of n latency-bound
+ * ones.  Models with multi-scale split nodes and cascades that reject almost nothing run image by image inside.
+ * Images too small for a window give an empty result, like jdaDetect.  Returns 0 on success. */
+JDA_API int jdaDetectBatchRagged(void *cascador, const unsigned char *const *images, const int *widths,
+                                 const int *heights, int n, float scale, float step, int min_size, int max_size,
+                                 float th, const jdaDetectOptions *opt, jdaResult *out);
+
+/* Same, images already resident in device memory: image i starts at d_base + offsets[i], rows back to back. */
+JDA_API int jdaDetectBatchRaggedDevice(void *cascador, const unsigned char *d_base, const size_t *offsets,
+                                       const int *widths, const int *heights, int n, float scale, float step,
+                                       int min_size, int max_size, float th, const jdaDetectOptions *opt,
+                                       jdaResult *out);
+
 /* Up to three batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
  * Submit queues the stage-0 scan of a batch of device-resident frames and returns at once with a
  * ticket (0..2; -1 on error: every ticket in use, the workspace would have to grow while another

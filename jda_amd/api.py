@@ -103,6 +103,12 @@ def _load():
     lib.jdaDetectBatchDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
                                          C.POINTER(jdaResult)]
+    lib.jdaDetectBatchRagged.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                         C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
+                                         C.POINTER(jdaResult)]
+    lib.jdaDetectBatchRaggedDevice.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                               C.c_float, C.POINTER(jdaDetectOptions), C.POINTER(jdaResult)]
     lib.jdaDetectBatchSubmit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions)]
     lib.jdaDetectBatchSubmitHost.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float,
@@ -318,6 +324,62 @@ class Cascador:
         else:
             out = [res[i].n for i in range(n)]
             lib.jdaResultsRelease(res, n)
+        return (out, st.asdict()) if stats else out
+
+    # -- images of different sizes in one job --------------------------------------------
+    def _collect(self, res, n, keep_results, frame_offset=0):
+        if keep_results == "packed":
+            rows = lib.jdaResultsPack(res, n, frame_offset, None, 0)
+            out = np.empty((max(rows, 0), 5 + self.dim), np.float32)
+            if rows > 0:
+                lib.jdaResultsPack(res, n, frame_offset, out.ctypes.data_as(C.POINTER(C.c_float)), rows)
+            lib.jdaResultsRelease(res, n)
+        elif keep_results:
+            out = [_take(res[i]) for i in range(n)]
+        else:
+            out = [res[i].n for i in range(n)]
+            lib.jdaResultsRelease(res, n)
+        return out
+
+    def detect_ragged(self, images, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True, stats=False,
+                      keep_results=True):
+        """jdaDetectBatchRagged: a list of uint8 [h, w] arrays of different sizes in host memory."""
+        images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        n = len(images)
+        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(im) for im in images])
+        ws = (C.c_int * max(n, 1))(*[im.shape[1] for im in images])
+        hs = (C.c_int * max(n, 1))(*[im.shape[0] for im in images])
+        res = (jdaResult * max(n, 1))()
+        o, st = self._opts(nms, stats)
+        rc = lib.jdaDetectBatchRagged(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = self._collect(res, n, keep_results)
+        return (out, st.asdict()) if stats else out
+
+    def detect_ragged_packed(self, buf, offsets, widths, heights, scale=1.25, min_size=40, max_size=-1, th=-0.5,
+                             nms=True, stats=False, keep_results=True):
+        """The same for images packed in ONE buffer (image i = buf[offsets[i] : offsets[i] + w*h], rows back to
+        back): a numpy uint8 array (host entry, jdaDetectBatchRagged) or a torch uint8 CUDA tensor
+        (jdaDetectBatchRaggedDevice)."""
+        n = len(offsets)
+        ws = (C.c_int * max(n, 1))(*[int(v) for v in widths])
+        hs = (C.c_int * max(n, 1))(*[int(v) for v in heights])
+        res = (jdaResult * max(n, 1))()
+        o, st = self._opts(nms, stats)
+        if isinstance(buf, np.ndarray):
+            assert buf.dtype == np.uint8 and buf.flags.c_contiguous
+            base = buf.ctypes.data
+            ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[C.cast(C.c_void_p(base + int(off)), C.POINTER(C.c_ubyte)) for off in offsets])
+            rc = lib.jdaDetectBatchRagged(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o), res)
+        else:
+            assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
+            offs = (C.c_size_t * max(n, 1))(*[int(v) for v in offsets])
+            rc = lib.jdaDetectBatchRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, scale, 0.1,
+                                                min_size, max_size, th, C.byref(o), res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = self._collect(res, n, keep_results)
         return (out, st.asdict()) if stats else out
 
     # -- two batches in flight from one thread -----------------------------------

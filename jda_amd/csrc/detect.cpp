@@ -249,6 +249,9 @@ struct Cascador {
   double pred_tail = -1, pred_out = -1;
   bool last_dense = false;
   HostPinned h_gid[kLanes], h_score[kLanes], h_shape[kLanes];   // detections of a lane's pass
+  // ragged passes, per lane: images at the common pitch, tight images, tables (segments, block map, image records)
+  DevBuf rag_frames[kLanes], rag_raw[kLanes], rag_tab[kLanes];
+  HostPinned h_tab[kLanes], h_raw[kLanes];
   int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
   int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
@@ -486,7 +489,8 @@ static bool upload_model(Cascador* c) {
 // JDA_TILES="win:twxth,win:twxth" forces shapes (experiments); JDA_DEBUG_TILES=1 prints the choice.
 struct TileChoice { int mode = 0, tw = 1, th = 1, pitch = 0, pix = 0, lds = 0, block = 256; double cost = 0; };
 
-static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, int real_bytes, int chunk, int cp_max) {
+static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, int real_bytes, int chunk, int cp_max,
+                              bool ragged = false) {
   static const double c_win = (double)env_ll("JDA_TILE_CWIN", 23), c_bw = (double)env_ll("JDA_TILE_CBW", 32),
                       c_fix = (double)env_ll("JDA_TILE_CFIX", 1500), w_sat = (double)env_ll("JDA_TILE_WSAT", 20),
                       alpha = (double)env_ll("JDA_TILE_ALPHA_PCT", 70) / 100.0;
@@ -516,7 +520,15 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
       const int tiles_x = (s.nx + tw - 1) / tw, tiles_y = (s.ny + th - 1) / th;
       const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
       int xs = 0;
-      for (int tx = 0; tx < tiles_x; tx++) xs = std::max(xs, (tx * tw * s.step) & 15);
+      if (ragged) {
+        // images of any width share the tile shape: the worst lead-in of a tile origin x0 = tx * tw * step over ALL
+        // tx, i.e. the largest multiple of gcd(tw * step, 16) below 16
+        int g = (tw * s.step) & 15, h = 16;
+        while (g) { const int t = h % g; h = g; g = t; }
+        xs = ((tw * s.step) & 15) ? 16 - h : 0;
+      } else {
+        for (int tx = 0; tx < tiles_x; tx++) xs = std::max(xs, (tx * tw * s.step) & 15);
+      }
       int pitch = (xs + pw + 15) & ~15;
       if ((pitch & 127) == 0) pitch += 16;          // keep tile rows off a 32-bank multiple
       const long long pix = (long long)pitch * ph;
@@ -542,7 +554,10 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
   return best;
 }
 
-static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool fast_scan, int real_bytes, PlanEntry* pe) {
+// ragged: sp holds the global level list of a ragged batch with NOMINAL grids (the mean nx, ny over the images that
+// have the level) and the common row pitch as its width; the shapes must suit every image
+static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool fast_scan, int real_bytes, PlanEntry* pe,
+                         bool ragged = false) {
   DevPlan& hp = pe->hp;
   hp.n_levels = (int)sp.levels.size();
   hp.width = sp.width; hp.height = sp.height; hp.windows = (int)sp.windows;
@@ -561,7 +576,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& k
     const bool glb_ok = kn.no_global_scan == 0 &&
                         (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits);
     if (fast_scan) {
-      const TileChoice t = (kn.no_lds_scan || s.win > kn.lds_win_max) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max);
+      const TileChoice t = (kn.no_lds_scan || s.win > kn.lds_win_max) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max, ragged);
       if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
         d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
       } else if (glb_ok) {
@@ -595,7 +610,7 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& k
   }
 }
 
-static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out) {
+static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out, bool ragged = false) {
   auto it = c->plans.find(key);
   if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; *out = &it->second; return true; }
   // bounded cache: a stream of differently sized images (FDDB) must not pile up device tables
@@ -611,7 +626,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     c->plans.erase(victim);
   }
   if ((int)sp.levels.size() > kMaxLevels) { fail("too many pyramid levels"); return false; }
-  if (sp.windows * 1LL > 0x7fffffffLL) { fail("frame has too many windows"); return false; }
+  if (!ragged && sp.windows * 1LL > 0x7fffffffLL) { fail("frame has too many windows"); return false; }
   if (sp.width > 65535 || sp.height > 65535) { fail("frames wider or taller than 65535 pixels are not supported"); return false; }
   PlanEntry pe;
   pe.sp = sp;
@@ -620,7 +635,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
   const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
   for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
   pe.fast_scan = s0_plain && c->kn.no_fast_scan == 0;
-  assign_tiles(sp, c->hm, c->kn, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe);
+  assign_tiles(sp, c->hm, c->kn, pe.fast_scan, dialect == JDA_DIALECT_C ? 4 : 8, &pe, ragged);
   size_t entries = 0;
   pe.lm_ok = true;
   for (int i = 0; i < pe.hp.n_levels; i++)
@@ -759,6 +774,25 @@ static bool copy_frames_h2d(uint8_t* dst, size_t stride, const unsigned char* co
   return true;
 }
 
+// ---- ragged batches: images of different sizes in one pass (kernels.h: RagSeg) ----
+// Host tables of one chunk of a ragged job: what its pass uploads and launches.
+struct RaggedChunk {
+  int i0 = 0, n = 0;                    // images [i0, i0 + n) of the job
+  long long windows = 0;                // candidate windows of the chunk
+  size_t frame_bytes = 0;               // staged images (common row pitch)
+  size_t raw_bytes = 0;                 // tight images (host staging; 0 when the images are already on the device)
+  int max_h = 0, pitch = 0;
+  std::vector<uint32_t> gid_base;       // [n + 1] first gid of every image inside the pass
+  struct Launch { int mode, block, pix_bytes, blk_base, blk_n; };
+  std::vector<Launch> launches;
+  int n_segs = 0, n_blk = 0;
+  size_t off_segs = 0, off_blk = 0, off_imgoff = 0, off_rimg = 0, table_bytes = 0;   // layout of the table buffer
+  const unsigned char* const* host_imgs = nullptr;   // the chunk's images in host memory (tight), or
+  const uint8_t* d_raw = nullptr;                    // the base their RagImg::src_off refer to on the device
+  const int* widths = nullptr; const int* heights = nullptr;      // of the chunk's images
+  bool host_contiguous = false;         // the host images lie back to back in memory in RagImg::src_off order
+};
+
 // One sub-batch of frames going through the device pipeline on one lane (stream + workspace).
 // The pipeline has four host-visible waits (hand-off count, mid-queue count, counters, results);
 // the methods are the pieces between them, so that run_device can interleave two lanes: while
@@ -773,6 +807,7 @@ struct Pass {
   WorkT<Real> w; size_t cap = 0;
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
+  const RaggedChunk* rag = nullptr;   // ragged pass: images of different sizes (w.segs / w.blk / w.img_off set by stage_ragged)
   // state between the steps
   bool dense = false, finished = false, lds_span = false;
   bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
@@ -798,7 +833,7 @@ struct Pass {
   // k_finish reads the level-major copy of the stage-0 tables (second half of the allocation)
   const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && pe->lm_ok && c->kn.fin_s0) ? pe->table + pe->table_cap : nullptr; }
   const Knobs& kn() const { return c->kn; }
-  long long windows() const { return (long long)nf * pe->sp.windows; }
+  long long windows() const { return rag ? rag->windows : (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {
     constexpr int dialect = Sel<Real>::dialect;
@@ -836,6 +871,7 @@ struct Pass {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
     JDA_HIP(hipEventRecord(ev[0], st));
+    if (rag) return issue_scan_ragged();
     if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes, st))
       return false;
     if (multi) {
@@ -930,10 +966,15 @@ struct Pass {
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
-    // With a prediction of the hand-off queue's length (earlier passes on this plan) everything else is queued
-    // right here, behind the scan: finishing launches sized by the prediction, counters and a predicted prefix of
-    // the detections -> host.  The pass is then one enqueue and ONE host wait (after_counters).  Without one, the
-    // host reads the queue length first (after_tail).
+    return issue_rest();
+  }
+
+  // With a prediction of the hand-off queue's length (earlier passes on this plan) everything else is queued
+  // right behind the scan: finishing launches sized by the prediction, counters and a predicted prefix of
+  // the detections -> host.  The pass is then one enqueue and ONE host wait (after_counters).  Without one, the
+  // host reads the queue length first (after_tail).
+  bool issue_rest() {
+    int pix_cap, lds_max;
     if (kn().predict && pe->pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pe->pred_tail >= 0.4)) {
       const long long nw = windows();
       const long long guess = std::min<long long>((long long)cap, (long long)(pe->pred_tail * (double)nw * 1.1) + 64);
@@ -945,6 +986,39 @@ struct Pass {
     }
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
     return read_counter(kCntTail);
+  }
+
+  // Ragged pass: tables and images -> device (tight rows repacked to the common pitch), then the scan launches of the
+  // chunk's block map.  Never dense, never traced (the caller falls back to per-image passes for those).
+  bool issue_scan_ragged() {
+    const DevModelT<Real>& m = model();
+    const RaggedChunk& ch = *rag;
+    uint8_t* tab = (uint8_t*)c->rag_tab[lane].p;
+    JDA_HIP(hipMemcpyAsync(tab, c->h_tab[lane].p, ch.table_bytes, hipMemcpyHostToDevice, st));
+    const uint8_t* raw = ch.d_raw;
+    if (ch.host_imgs) {
+      // tight images -> device: one copy when they lie back to back in the caller's memory, else through the lane's
+      // pinned staging buffer (filled by build_chunk)
+      const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : c->h_raw[lane].p;
+      JDA_HIP(hipMemcpyAsync(c->rag_raw[lane].p, src, ch.raw_bytes, hipMemcpyHostToDevice, st));
+      raw = (const uint8_t*)c->rag_raw[lane].p;
+    }
+    JDA_HIP(launch_repack(raw, (uint8_t*)c->rag_frames[lane].p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
+    w.frames = (const uint8_t*)c->rag_frames[lane].p; w.frame_stride = 0; w.n_frames = ch.n;
+    w.segs = (const RagSeg*)(tab + ch.off_segs); w.blk = (const RagBlk*)(tab + ch.off_blk);
+    w.img_off = (const unsigned long long*)(tab + ch.off_imgoff);
+    if (!clear_counters()) return false;
+    JDA_HIP(hipEventRecord(ev[1], st));
+    const int handoff = (int)kn().handoff;
+    const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
+    const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
+    for (const RaggedChunk::Launch& l : ch.launches) {
+      JDA_HIP(launch_scan_ragged<Real>(l.mode, l.block, false, handoff, cp_max, opts, pe->dp, m, pe->table, w, l.pix_bytes,
+                                       l.blk_base, l.blk_n, st));
+      rs->scan_launches++;
+    }
+    JDA_HIP(hipEventRecord(ev[2], st));
+    return issue_rest();
   }
 
   // Finishing launches for a hand-off queue of (about) n_grid windows: the kernels take the true length from the
@@ -984,8 +1058,9 @@ struct Pass {
     if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
       // most windows are still alive after the scan: start over in dense mode (the scan's work
       // is a small part of T*K carts per window) and remember the choice for the next pass
-      dense = true; finished = true;
       pe->dense_hint = true;
+      if (rag) return launch_finishers(n_tail);   // (a ragged pass finishes window by window; the NEXT job runs image by image, dense)
+      dense = true; finished = true;
       if (!clear_counters()) return false;
       return run_dense();
     }
@@ -1062,7 +1137,7 @@ struct Pass {
   // step 6: detections of this pass sorted back into scan order and appended; trace arrays
   bool collect() {
     const int dim = hm().dim();
-    const long long wpf = pe->sp.windows;
+    const long long wpf = rag ? 0 : pe->sp.windows;
     const double t_dbg = now_ms();
     if (n_out && dets) {
       if (results_pending) JDA_HIP(hipStreamSynchronize(st));
@@ -1609,6 +1684,428 @@ static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n,
   return true;
 }
 
+// ---------------------------------------------------------------- ragged batches (images of different sizes)
+//
+// The reference's FDDB loop calls Detect once per image (src/test.cpp:100-170), the C API once per jdaDetect; on a
+// GPU that is one latency-bound pass per image.  A ragged job runs a list of differently sized images as a few
+// passes: the window sizes of c/jda.c:331-333 are the same series for every image (an image uses the prefix that fits
+// it), so the levels, their tile shapes and stage-0 tables are shared, and the images are staged with ONE row pitch.
+// Per image the results are those of jdaDetect on that image.
+
+struct RaggedJob {
+  int n = 0;
+  const int* widths = nullptr; const int* heights = nullptr;
+  const unsigned char* const* host_imgs = nullptr;     // tight images in host memory, or
+  const uint8_t* d_base = nullptr; const size_t* d_offsets = nullptr;   // ... on the device at d_base + d_offsets[i]
+  int pitch = 0;                    // common row pitch of the staged images (multiple of 16)
+  ScanPlan levels;                  // global level list; nx, ny = nominal (mean) grids, width = pitch
+  std::vector<int> n_lv;            // levels image i has (a prefix of the global list)
+  PlanEntry* pe = nullptr;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Levels of image (w, h): the prefix of the job's global list whose windows fit (c/jda.c:321-322,332).
+static int ragged_levels_of(const RaggedJob& job, int w, int h) {
+  const int lim = std::min(w, h);
+  int k = 0;
+  while (k < (int)job.levels.levels.size() && job.levels.levels[k].win <= lim) k++;
+  return k;
+}
+
+// Geometry of a ragged call: common pitch, global levels with nominal grids, the plan (tile shapes + tables).
+// Returns 0 = ok, 1 = this job needs the per-image fallback, -1 = error.
+static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size, int max_size) {
+  int max_w = 0, max_min = 0;
+  for (int i = 0; i < job->n; i++) {
+    if (job->widths[i] <= 0 || job->heights[i] <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
+    if (job->widths[i] > 65535 || job->heights[i] > 65535) { fail("images wider or taller than 65535 pixels are not supported"); return -1; }
+    max_w = std::max(max_w, job->widths[i]);
+    max_min = std::max(max_min, std::min(job->widths[i], job->heights[i]));
+  }
+  std::string err;
+  if (!plan_dialect_c(max_min, max_min, scale, min_size, max_size, &job->levels, &err)) { fail(err); return -1; }
+  const int nl = (int)job->levels.levels.size();
+  if (nl > kMaxLevels) return 1;
+  int pitch = (max_w + 15) & ~15;
+  if ((pitch & 255) == 0) pitch += 16;            // keep rows of neighbouring tiles off one memory channel
+  job->pitch = pitch;
+  job->levels.width = pitch; job->levels.height = max_min;
+  // nominal grids: the mean over the images that have the level (tile shapes are chosen for them)
+  std::vector<double> sx(nl, 0.0), sy(nl, 0.0);
+  std::vector<long long> cnt(nl, 0);
+  job->n_lv.resize(job->n);
+  for (int i = 0; i < job->n; i++) {
+    const int k = ragged_levels_of(*job, job->widths[i], job->heights[i]);
+    job->n_lv[i] = k;
+    for (int l = 0; l < k; l++) {
+      const Level& lv = job->levels.levels[l];
+      sx[l] += (job->widths[i] - lv.win) / lv.step + 1; sy[l] += (job->heights[i] - lv.win) / lv.step + 1; cnt[l]++;
+    }
+  }
+  unsigned long long h = 1469598103934665603ull;
+  for (int l = 0; l < nl; l++) {
+    Level& lv = job->levels.levels[l];
+    // quantised, so that jobs over similar image sets share a plan
+    const int qx = cnt[l] ? std::max(1, (int)(sx[l] / (double)cnt[l] / 4.0 + 0.5) * 4) : 1;
+    const int qy = cnt[l] ? std::max(1, (int)(sy[l] / (double)cnt[l] / 4.0 + 0.5) * 4) : 1;
+    lv.nx = qx; lv.ny = qy; lv.base = 0;
+    h = (h ^ (unsigned long long)(qx * 65536 + qy)) * 1099511628211ull;
+  }
+  job->levels.windows = 0;
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{pitch, nl, 3 /* ragged, dialect C */, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, h};
+  if (!get_plan(c, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;
+  if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
+  if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
+  for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;
+  return 0;
+}
+
+// Tables of images [i0, i0 + n) into the lane's pinned table buffer (and, for host images that do not lie back to
+// back, the images into the lane's pinned staging buffer).
+static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, int lane, RaggedChunk* ch) {
+  const DevPlan& hp = job.pe->hp;
+  const int nl = hp.n_levels;
+  ch->i0 = i0; ch->n = n; ch->pitch = job.pitch;
+  ch->widths = job.widths + i0; ch->heights = job.heights + i0;
+  ch->host_imgs = job.host_imgs ? job.host_imgs + i0 : nullptr;
+  ch->d_raw = job.d_base;
+  // ---- counts ----
+  int n_segs = 0;
+  long long n_blk = 0;
+  for (int i = 0; i < n; i++) {
+    const int W = job.widths[i0 + i], H = job.heights[i0 + i];
+    n_segs += job.n_lv[i0 + i];
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      const int nx = (W - d.win) / d.step + 1, ny = (H - d.win) / d.step + 1;
+      n_blk += (long long)((nx + d.tw - 1) / d.tw) * ((ny + d.th - 1) / d.th);
+    }
+  }
+  if (n_blk > 0x7fffffffLL) { fail("ragged chunk has too many tiles"); return false; }
+  ch->n_segs = n_segs; ch->n_blk = (int)n_blk;
+  size_t o = 0;
+  ch->off_segs = o; o = align_up(o + (size_t)n_segs * sizeof(RagSeg), 256);
+  ch->off_blk = o; o = align_up(o + (size_t)n_blk * sizeof(RagBlk), 256);
+  ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
+  ch->off_rimg = o; o = align_up(o + (size_t)n * sizeof(RagImg), 256);
+  ch->table_bytes = o;
+  if (!c->h_tab[lane].reserve(o) || !c->rag_tab[lane].reserve(o)) return false;
+  uint8_t* tab = (uint8_t*)c->h_tab[lane].p;
+  RagSeg* segs = (RagSeg*)(tab + ch->off_segs);
+  RagBlk* blk = (RagBlk*)(tab + ch->off_blk);
+  unsigned long long* img_off = (unsigned long long*)(tab + ch->off_imgoff);
+  RagImg* rimg = (RagImg*)(tab + ch->off_rimg);
+  // ---- images and segments ----
+  ch->gid_base.assign(n + 1, 0);
+  std::vector<int> seg_first(n + 1, 0);
+  size_t dst = 0, src = 0;
+  long long gid = 0;
+  int max_h = 0, si = 0;
+  bool contiguous = job.host_imgs != nullptr;
+  for (int i = 0; i < n; i++) {
+    const int W = job.widths[i0 + i], H = job.heights[i0 + i];
+    max_h = std::max(max_h, H);
+    img_off[i] = dst;
+    rimg[i].dst_off = dst; rimg[i].w = W; rimg[i].h = H;
+    if (job.host_imgs) {
+      if (!job.host_imgs[i0 + i]) { fail("null image pointer"); return false; }
+      if (i > 0 && job.host_imgs[i0 + i] != job.host_imgs[i0 + i - 1] + (size_t)job.widths[i0 + i - 1] * job.heights[i0 + i - 1]) contiguous = false;
+      rimg[i].src_off = src;                         // tight, back to back in the staging copy
+      src += (size_t)W * H;
+    } else {
+      rimg[i].src_off = job.d_offsets[i0 + i];
+    }
+    dst += align_up((size_t)H * job.pitch, 256);
+    ch->gid_base[i] = (uint32_t)gid;
+    seg_first[i] = si;
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      RagSeg& sg = segs[si++];
+      sg.img_off = img_off[i]; sg.gid_base = (uint32_t)gid;
+      sg.nx = (uint16_t)((W - d.win) / d.step + 1); sg.ny = (uint16_t)((H - d.win) / d.step + 1);
+      sg.tiles_x = (uint16_t)((sg.nx + d.tw - 1) / d.tw);
+      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = sg.pad2 = 0;
+      gid += (long long)sg.nx * sg.ny;
+    }
+  }
+  seg_first[n] = si;
+  ch->gid_base[n] = (uint32_t)gid;
+  if (gid > 0x7fffffffLL) { fail("ragged chunk has too many windows"); return false; }
+  ch->windows = gid; ch->frame_bytes = dst + 256; ch->max_h = max_h;
+  ch->raw_bytes = job.host_imgs ? src : 0;
+  ch->host_contiguous = contiguous;
+  if (!c->rag_frames[lane].reserve(ch->frame_bytes)) return false;
+  if (job.host_imgs) {
+    if (!c->rag_raw[lane].reserve(src + 16)) return false;
+    if (!contiguous) {
+      if (!c->h_raw[lane].reserve(src + 16)) return false;
+      uint8_t* hr = (uint8_t*)c->h_raw[lane].p;
+      for (int i = 0; i < n; i++) std::memcpy(hr + rimg[i].src_off, job.host_imgs[i0 + i], (size_t)rimg[i].w * rimg[i].h);
+    }
+  }
+  // ---- block map and launches: one launch per LDS-tiled level (all of them in one when the chunk is small), one for
+  //      the big-window LDS levels, one for the global-pixel levels.  Inside a launch the tiles of 8 images interleave,
+  //      so that an image's tiles mostly land on one XCD's L2 (block b -> XCD b % 8). ----
+  ch->launches.clear();
+  int bi = 0;
+  auto emit_level = [&](int l) {
+    const DevLevel& d = hp.lv[l];
+    for (int g0 = 0; g0 < n; g0 += 8) {
+      int tiles[8], seg[8], most = 0;
+      const int ge = std::min(n, g0 + 8);
+      for (int i = g0; i < ge; i++) {
+        tiles[i - g0] = 0; seg[i - g0] = -1;
+        if (l < job.n_lv[i0 + i]) {
+          const RagSeg& sg = segs[seg_first[i] + l];
+          tiles[i - g0] = (int)sg.tiles_x * ((sg.ny + d.th - 1) / d.th);
+          seg[i - g0] = seg_first[i] + l;
+          most = std::max(most, tiles[i - g0]);
+        }
+      }
+      for (int t = 0; t < most; t++)
+        for (int j = 0; j < ge - g0; j++)
+          if (t < tiles[j]) { blk[bi].seg = (uint32_t)seg[j]; blk[bi].tile = (uint32_t)t; bi++; }
+    }
+  };
+  auto pix_of = [&](int l) { const DevLevel& d = hp.lv[l]; return d.pitch * (d.win + (d.th - 1) * d.step); };
+  long long lds_blocks = 0;
+  for (int i = 0; i < n; i++)
+    for (int l = 0; l < job.n_lv[i0 + i]; l++)
+      if (hp.lv[l].tiled == 1) { const RagSeg& sg = segs[seg_first[i] + l]; lds_blocks += (long long)sg.tiles_x * ((sg.ny + hp.lv[l].th - 1) / hp.lv[l].th); }
+  const bool small = lds_blocks <= c->kn.merge_blocks;
+  auto merged = [&](int mode) {
+    RaggedChunk::Launch L{mode, 256, 0, bi, 0};
+    for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode) { emit_level(l); if (mode != 2) L.pix_bytes = std::max(L.pix_bytes, pix_of(l)); }
+    L.blk_n = bi - L.blk_base;
+    if (L.blk_n > 0) ch->launches.push_back(L);
+  };
+  if (small) merged(1);
+  else
+    for (int l = 0; l < nl; l++)
+      if (hp.lv[l].tiled == 1) {
+        RaggedChunk::Launch L{1, hp.lv[l].tw * hp.lv[l].th > 256 ? 512 : 256, pix_of(l), bi, 0};
+        emit_level(l);
+        L.blk_n = bi - L.blk_base;
+        if (L.blk_n > 0) ch->launches.push_back(L);
+      }
+  merged(3);
+  merged(2);
+  if (bi != ch->n_blk) { fail("internal: ragged block map size"); return false; }
+  return true;
+}
+
+// NMS, relocation and the jdaResult of every image of a ragged chunk (dets sorted by gid = image, level, y, x).
+static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets,
+                          const jdaDetectOptions* opt, jdaResult* out) {
+  const double t0 = now_ms();
+  const int L = c->hm.L, dim = c->hm.dim();
+  const bool do_nms = !opt || opt->nms;
+  const float overlap = opt ? opt->nms_overlap : 0.3f;
+  const DevPlan& hp = job.pe->hp;
+  std::vector<size_t> first(ch.n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < ch.n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] < ch.gid_base[f + 1]) i++;
+    }
+    first[ch.n] = i;
+  }
+  parallel_for(ch.n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    static thread_local std::vector<int> bb, keep;
+    bb.resize(cnt * 3);
+    const int W = ch.widths[f], H = ch.heights[f];
+    int l = 0;
+    uint32_t lbase = ch.gid_base[f];
+    int nx = 0, cntl = 0;
+    auto level_grid = [&](int lv) {
+      const DevLevel& d = hp.lv[lv];
+      nx = (W - d.win) / d.step + 1;
+      cntl = nx * ((H - d.win) / d.step + 1);
+    };
+    if (cnt) level_grid(0);
+    for (size_t i = 0; i < cnt; i++) {          // gids ascend: levels are walked once
+      const uint32_t g = dets.gid[a + i];
+      while (g >= lbase + (uint32_t)cntl) { lbase += (uint32_t)cntl; l++; level_grid(l); }
+      const uint32_t rel = g - lbase;
+      const DevLevel& d = hp.lv[l];
+      bb[3 * i] = (int)(rel % (uint32_t)nx) * d.step; bb[3 * i + 1] = (int)(rel / (uint32_t)nx) * d.step; bb[3 * i + 2] = d.win;
+    }
+    if (do_nms) nms_dialect_c_into(bb.data(), &dets.score[a], (int)cnt, overlap, &keep);
+    else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
+    jdaResult& r = out[f];
+    r.n = (int)keep.size(); r.landmark_n = L;
+    r.bboxes = (int*)std::malloc(std::max<size_t>(1, keep.size() * 3) * sizeof(int));
+    r.scores = (float*)std::malloc(std::max<size_t>(1, keep.size()) * sizeof(float));
+    r.shapes = (float*)std::malloc(std::max<size_t>(1, keep.size() * dim) * sizeof(float));
+    for (size_t i = 0; i < keep.size(); i++) {
+      const int k = keep[i];
+      std::memcpy(r.bboxes + 3 * i, &bb[3 * k], 3 * sizeof(int));
+      r.scores[i] = dets.score[a + k];
+      float* sh = r.shapes + i * dim;
+      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
+      relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
+    }
+  }, dets.gid.size() < 20000);
+  return now_ms() - t0;
+}
+
+static void add_stats(RunStats* a, const RunStats& b) {
+  a->carts += b.carts; a->out += b.out; a->carts_scan += b.carts_scan; a->carts_scan_glb += b.carts_scan_glb;
+  a->win_scan += b.win_scan; a->tail += b.tail; a->gpu_ms += b.gpu_ms; a->scan_ms += b.scan_ms;
+  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes;
+  for (int t = 0; t < kMaxStages; t++) a->stage_done[t] += b.stage_done[t];
+}
+
+// A ragged job: images of different sizes, in host memory (host_imgs) or on the device (d_base + d_offsets).
+static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                         const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
+                         const jdaDetectOptions* opt, jdaResult* out) {
+  const double t_call = now_ms();
+  if (!c || !out || n < 0 || !widths || !heights || (!host_imgs && !(d_base && d_offsets))) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L;
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  for (int i = 0; c->pending && i < kLanes; i++)
+    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return -1; }
+  if (n == 0) return 0;
+  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  RunStats total;
+  long long patch_n = 0;
+  double post_ms = 0;
+  jdaDetectOptions o1;
+  jdaStats st1;
+  auto finish = [&]() {
+    fill_stats(opt ? opt->stats : nullptr, total, patch_n, c->hm.T, c->hm.K, post_ms);
+    if (opt && opt->stats) opt->stats->call_ms = now_ms() - t_call;
+    return 0;
+  };
+  // per-image passes: models the ragged scan does not cover (multi-scale split nodes, levels without a tile), and
+  // cascades that reject so little that the dense kernel is the right tool
+  auto fallback = [&]() -> int {
+    for (int i = 0; i < n; i++) {
+      if (opt) o1 = *opt; else jdaDetectOptionsInit(&o1);
+      o1.stats = &st1; o1.hip_stream = nullptr;
+      const int W = widths[i], H = heights[i];
+      if (W <= 0 || H <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
+      int rc;
+      if (host_imgs) {
+        size_t stride = 0;
+        const unsigned char* one[1] = {host_imgs[i]};
+        if (!stage_frames<float>(c, one, 1, (size_t)W * H, &stride, true)) return -1;
+        rc = detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
+      } else {
+        c->pending_host = nullptr;
+        rc = detect_c_device(c, d_base + d_offsets[i], (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
+      }
+      if (rc != 0) return -1;
+      total.carts += st1.cart_total_n; total.out += st1.face_patch_n; total.carts_scan += st1.scan_cart_n;
+      total.win_scan += st1.scan_patch_n; total.tail += st1.handoff_n; total.gpu_ms += st1.gpu_ms; total.scan_ms += st1.scan_ms;
+      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes;
+      for (int t = 0; t < 16 && t < kMaxStages; t++) total.stage_done[t] += st1.stage_done_n[t];
+      patch_n += st1.patch_n; post_ms += st1.host_ms;
+    }
+    return finish();
+  };
+  if (c->hm.multi_scale()) return fallback();
+  RaggedJob job;
+  job.n = n; job.widths = widths; job.heights = heights; job.host_imgs = host_imgs; job.d_base = d_base; job.d_offsets = d_offsets;
+  const int prep = ragged_prepare(c, &job, scale, min_size, max_size);
+  if (prep < 0) return -1;
+  if (prep > 0) return fallback();
+  if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
+    for (int i = 0; i < n; i++) out[i] = empty_result(L);
+    return finish();
+  }
+
+  // ---- chunks: as many images as make ragged_chunk_windows windows (<= 65535 images, the queues pack the index
+  //      in 16 bits), walked through kLanes lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
+  //      the host builds and issues chunk i and post-processes chunk i-3 ----
+  const DevPlan& hp = job.pe->hp;
+  std::vector<int> starts;
+  {
+    long long wsum = 0; int cnt = 0;
+    const long long target = std::max<long long>(1, c->kn.ragged_chunk_windows);
+    starts.push_back(0);
+    for (int i = 0; i < n; i++) {
+      long long wi = 0;
+      for (int l = 0; l < job.n_lv[i]; l++)
+        wi += (long long)((widths[i] - hp.lv[l].win) / hp.lv[l].step + 1) * ((heights[i] - hp.lv[l].win) / hp.lv[l].step + 1);
+      if (wi > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
+      if (cnt > 0 && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
+      wsum += wi; cnt++;
+    }
+    starts.push_back(n);
+  }
+  const int n_chunks = (int)starts.size() - 1;
+  const int lanes = std::min(kLanes, n_chunks);
+  struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
+  std::vector<Slot> slots(lanes);
+  for (int l = 0; l < lanes; l++) if (!ensure_lane(c, l)) return -1;
+  job.pe->pins++;                                   // (nothing else creates plans during the job; belt and braces)
+  bool ok = true;
+  auto collect = [&](Slot& sl) -> bool {
+    Pass<float>& p = sl.pass;
+    sl.busy = false;
+    if (!p.after_tail() || !p.issue_counters() || !p.after_counters() || !p.collect()) return false;
+    float ms_scan = 0, ms_all = 0;
+    (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+    (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    sl.rs.scan_ms += ms_scan; sl.rs.gpu_ms += ms_all;
+    post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+    add_stats(&total, sl.rs);
+    patch_n += sl.ch.windows;
+    return true;
+  };
+  for (int ci = 0; ci < n_chunks && ok; ci++) {
+    const int lane = ci % lanes;
+    Slot& sl = slots[lane];
+    if (sl.busy && !collect(sl)) { ok = false; break; }
+    sl.dets = RawDets<float>(); sl.rs = RunStats();
+    if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], lane, &sl.ch)) { ok = false; break; }
+    if (sl.ch.windows == 0) {                        // images too small for any window
+      post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+      continue;
+    }
+    // workspace: every lane holds a whole chunk
+    Workspace<float>& ws = c->wf;
+    if (!(ws.cap >= (size_t)sl.ch.windows && ws.dim == c->hm.dim() && ws.lanes >= lanes)) {
+      for (auto& s2 : slots) if (s2.busy && !collect(s2)) ok = false;       // the carving moves: drain first
+      if (!ok) break;
+      const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(c->kn.ragged_chunk_windows, 0x7fffffffLL))
+                                       : (size_t)sl.ch.windows;
+      if (!ensure_workspace<float>(c, want, false, lanes)) { ok = false; break; }
+    }
+    Pass<float>& p = sl.pass;
+    p = Pass<float>();
+    p.c = c; p.pe = job.pe; p.trace = nullptr; p.dets = &sl.dets; p.rs = &sl.rs; p.apply_th = true; p.th = th; p.multi = false;
+    p.lane = lane; p.solo = lanes == 1; p.st = c->stream[lane]; p.ev = c->ev[lane];
+    p.h_cnt = c->h_counters + (size_t)lane * kCntShards * kCntStride;
+    p.w = ws.w[lane]; p.cap = ws.cap;
+    p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
+    p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
+    p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+    if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { ok = false; break; }
+    sl.busy = true;
+  }
+  // drain in chunk order
+  for (int k = 0; k < lanes && ok; k++) {
+    Slot& sl = slots[(n_chunks + k) % lanes];
+    if (sl.busy && !collect(sl)) ok = false;
+  }
+  if (!ok) {
+    for (auto& sl : slots) if (sl.busy) (void)hipStreamSynchronize(sl.pass.st);
+    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
+  }
+  job.pe->pins--;
+  if (!ok) return -1;
+  for (int i = 0; i < n; i++)
+    if (!out[i].bboxes) out[i] = empty_result(L);     // (chunks fill every image; belt and braces)
+  return finish();
+}
+
 }  // namespace jda
 
 // =============================================================================
@@ -1658,7 +2155,10 @@ void jdaCascadorRelease(void* cascador) {
     c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
     for (auto& b : c->submit_frames) b.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
-    for (int l = 0; l < kLanes; l++) { c->h_gid[l].release(); c->h_score[l].release(); c->h_shape[l].release(); }
+    for (int l = 0; l < kLanes; l++) {
+      c->h_gid[l].release(); c->h_score[l].release(); c->h_shape[l].release();
+      c->rag_frames[l].release(); c->rag_raw[l].release(); c->rag_tab[l].release(); c->h_tab[l].release(); c->h_raw[l].release();
+    }
     for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_user) (void)hipEventDestroy(c->ev_user);
     for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
@@ -1799,6 +2299,32 @@ int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, in
   if (!ensure_device(c)) return -1;
   if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   return detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, n, width, height, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatchRagged(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
+                         float scale, float step, int min_size, int max_size, float th,
+                         const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !images || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRagged runs dialect C"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->pending_host = nullptr;
+  return detect_ragged(c, images, nullptr, nullptr, widths, heights, n, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatchRaggedDevice(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
+                               const int* heights, int n, float scale, float step, int min_size, int max_size, float th,
+                               const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedDevice runs dialect C"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->pending_host = nullptr;
+  return detect_ragged(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, out);
 }
 
 jdaResult jdaDetect(void* cascador, unsigned char* data, int width, int height,

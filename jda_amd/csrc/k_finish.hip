@@ -120,7 +120,8 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
   const int wn = (int)(wf & 0xffffu), frame = (int)(wf >> 16);
   *win = wn;
-  v0->img = w.frames + (size_t)frame * w.frame_stride; v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
+  v0->img = w.img_off != nullptr ? w.frames + w.img_off[frame] : w.frames + (size_t)frame * w.frame_stride;   // ragged batch: per-image offset
+  v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
   v0->pw = wn;
   if (multi) {
     v1->img = w.half + (size_t)frame * w.half_stride; v1->w = w.hw; v1->h = w.hh;

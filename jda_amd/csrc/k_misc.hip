@@ -101,6 +101,39 @@ hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw
 }
 
 // =============================================================================
+// ragged batches: tight images -> one common row pitch
+// =============================================================================
+
+// Every image of a ragged batch is staged with the same row pitch (a multiple of 16 bytes): k_scan's LDS-DMA tile
+// loads need 16-byte aligned rows and its global-pixel node offsets are resolved for ONE pitch.  The images arrive
+// tight (row stride = width, the `data` of reference c/jda.c:445-448); this copies them into place, one
+// workgroup per (image, 4 rows), a dword of output per thread and step.
+__global__ __launch_bounds__(256) void k_repack(const uint8_t* __restrict__ raw, uint8_t* __restrict__ dst,
+                                                const RagImg* __restrict__ imgs, int pitch) {
+  const RagImg im = imgs[blockIdx.y];
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y >= im.h) return;
+  const uint8_t* s = raw + im.src_off + (size_t)y * im.w;
+  uint32_t* d = (uint32_t*)(dst + im.dst_off + (size_t)y * pitch);
+  const int nd = (im.w + 3) >> 2;
+  for (int j = threadIdx.x & 63; j < nd; j += 64) {
+    const int x = 4 * j;
+    uint32_t v = s[x];
+    if (x + 1 < im.w) v |= (uint32_t)s[x + 1] << 8;
+    if (x + 2 < im.w) v |= (uint32_t)s[x + 2] << 16;
+    if (x + 3 < im.w) v |= (uint32_t)s[x + 3] << 24;
+    d[j] = v;
+  }
+}
+
+hipError_t launch_repack(const uint8_t* raw, uint8_t* dst, const RagImg* imgs, int n, int max_h, int pitch, hipStream_t stream) {
+  if (n <= 0 || max_h <= 0) return hipSuccess;
+  // (gridDim.y is limited to 65535: a pass holds at most that many images, the queues pack the index in 16 bits)
+  hipLaunchKernelGGL(k_repack, dim3((unsigned)((max_h + 3) / 4), (unsigned)n), dim3(256), 0, stream, raw, dst, imgs, pitch);
+  return hipGetLastError();
+}
+
+// =============================================================================
 // stage-0 offset table
 // =============================================================================
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 
 void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                                 const S0Node* __restrict__ table, WorkT<Real> w,
                                                 int level, int tiles_total, int pix_bytes, int handoff, int chunk,
-                                                int cp_max, int opts) {
+                                                int cp_max, int opts, int blk_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr bool GLB = MODE == 2;
   constexpr bool WIDE = MODE != 1;
@@ -142,31 +142,46 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   // (MI355X dispatches block b to XCD b % 8), so the 8 frames of a group each
   // stay inside one XCD's L2.
   // level < 0: one launch covers every level of this pixel mode; tiles_total = their tiles per frame.
-  int tiles_per_frame = tiles_total;
-  if (level >= 0) tiles_per_frame = plan->lv[level].tiles_x * plan->lv[level].tiles_y;
-  const int b = blockIdx.x;
-  const int group = b / (8 * tiles_per_frame);
-  const int r = b - group * (8 * tiles_per_frame);
-  const int frame = group * 8 + (r & 7);
-  int trel = r >> 3;
-  if (frame >= w.n_frames) return;
-  if (level < 0) {
-    level = 0;
-    for (int i = 0; i < plan->n_levels; i++) {
-      const DevLevel* c = &plan->lv[i];
-      if (c->tiled != MODE) continue;
-      const int cnt = c->tiles_x * c->tiles_y;
-      if (trel < cnt) { level = i; break; }
-      trel -= cnt;
+  // Ragged batch (w.segs): the host's block map names the (image, level) segment and the tile.
+  int frame, trel, gid0;
+  DevLevel lv;
+  const uint8_t* img;
+  if (w.segs != nullptr) {
+    const RagBlk bs = w.blk[blk_base + blockIdx.x];
+    const RagSeg sg = w.segs[bs.seg];
+    lv = plan->lv[sg.level];
+    lv.nx = sg.nx; lv.ny = sg.ny; lv.tiles_x = sg.tiles_x;
+    level = sg.level;
+    frame = sg.image; trel = (int)bs.tile; gid0 = (int)sg.gid_base;
+    img = w.frames + sg.img_off;
+  } else {
+    int tiles_per_frame = tiles_total;
+    if (level >= 0) tiles_per_frame = plan->lv[level].tiles_x * plan->lv[level].tiles_y;
+    const int b = blockIdx.x;
+    const int group = b / (8 * tiles_per_frame);
+    const int r = b - group * (8 * tiles_per_frame);
+    frame = group * 8 + (r & 7);
+    trel = r >> 3;
+    if (frame >= w.n_frames) return;
+    if (level < 0) {
+      level = 0;
+      for (int i = 0; i < plan->n_levels; i++) {
+        const DevLevel* c = &plan->lv[i];
+        if (c->tiled != MODE) continue;
+        const int cnt = c->tiles_x * c->tiles_y;
+        if (trel < cnt) { level = i; break; }
+        trel -= cnt;
+      }
     }
+    lv = plan->lv[level];
+    gid0 = frame * plan->windows + lv.base;
+    img = w.frames + (size_t)frame * w.frame_stride;
   }
-  const DevLevel lv = plan->lv[level];
   const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
   const int wx0 = tx * lv.tw, wy0 = ty * lv.th;                 // first window of the tile
   const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
   const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;             // tile origin in the frame
   const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
-  const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
 
   // ---- stage the pixel tile (LDS-DMA when the frame is 16-byte aligned) and the first table chunk ----
   const int W = plan->width;
@@ -189,7 +204,6 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   int cur = 0;
   bool queued = false;                   // the live windows are in queue `cur` (else: the whole tile, phase 0)
   unsigned my_carts = 0;
-  const int gid0 = frame * plan->windows + lv.base;
 
   // A tile of few windows (big windows) goes through the pair phases from the start: its valid
   // windows are queued here.
@@ -564,7 +578,7 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
     if (lds_req > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
     hipLaunchKernelGGL(kern, grid, block, lds_req, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
-                       pix_bytes, handoff, chunk, cp_max, opts);
+                       pix_bytes, handoff, chunk, cp_max, opts, 0);
   };
   if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);
   else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK>);
@@ -597,6 +611,53 @@ hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max,
   };
   return trace ? pick(std::true_type{}) : pick(std::false_type{});
 }
+
+namespace {
+template <typename Real, bool TRACE, int MODE, int BLOCK>
+hipError_t launch_scan_ragged_mode(const DevPlan* d_plan, const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w,
+                                   int pix_bytes, int blk_base, int blk_n, int handoff, int cp_max, int opts,
+                                   hipStream_t stream) {
+  if (MODE == 2) pix_bytes = 0;
+  const int chunk = std::min(std::min(m.K, handoff), scan_handoff_cap(m.node_n, m.leaf_n, (int)sizeof(Real)));
+  const ScanLds<Real, TRACE> L(pix_bytes, chunk, m.node_n, m.leaf_n, kScanMaxWindows, BLOCK * 8);
+  if (L.total > 160 * 1024) return hipErrorInvalidValue;
+  auto go = [&](auto kern) {
+    if (L.total > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blk_n), dim3(BLOCK), L.total, stream, d_plan, m, table, w, -1, 0,
+                       pix_bytes, handoff, chunk, cp_max, opts, blk_base);
+  };
+  if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);
+  else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK>);
+  else go(k_scan<Real, 0, TRACE, MODE, BLOCK>);
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename Real>
+hipError_t launch_scan_ragged(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
+                              const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w, int pix_bytes,
+                              int blk_base, int blk_n, hipStream_t stream) {
+  if (blk_n <= 0) return hipSuccess;
+  if (!w.segs || !w.blk) return hipErrorInvalidValue;
+  auto pick = [&](auto trace_tag) {
+    constexpr bool TR = decltype(trace_tag)::value;
+    switch (mode) {
+      case 1:
+        return block == 512 ? launch_scan_ragged_mode<Real, TR, 1, 512>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream)
+                            : launch_scan_ragged_mode<Real, TR, 1, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+      case 2: return launch_scan_ragged_mode<Real, TR, 2, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+      case 3: return launch_scan_ragged_mode<Real, TR, 3, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+      default: return hipErrorInvalidValue;
+    }
+  };
+  return trace ? pick(std::true_type{}) : pick(std::false_type{});
+}
+
+template hipError_t launch_scan_ragged<float>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<float>&, const S0Node*,
+                                              const WorkT<float>&, int, int, int, hipStream_t);
+template hipError_t launch_scan_ragged<double>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<double>&, const S0Node*,
+                                               const WorkT<double>&, int, int, int, hipStream_t);
 
 template hipError_t launch_scan<float>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
                                        const S0Node*, const WorkT<float>&, hipStream_t);

@@ -41,6 +41,27 @@ struct DevPlan {
   DevLevel lv[kMaxLevels];
 };
 
+// Ragged batches (images of different sizes in one pass, the FDDB loop of reference src/test.cpp:100-170 as ONE
+// job): every image is staged with the same row pitch (DevPlan::width), the pyramid levels are a global list
+// (DevPlan::lv: window size, step, tile shape, stage-0 table -- the window sizes of c/jda.c:331-333 do not depend on
+// the image, an image only uses the prefix that fits it), and what does depend on the image sits in one record per
+// (image, level).  A workgroup of k_scan finds its tile through RagBlk: blockIdx -> (segment, tile).
+struct RagSeg {
+  unsigned long long img_off;   // byte offset of the image inside WorkT::frames
+  uint32_t gid_base;            // gid of this level's first window of this image (scan order: image, level, y, x)
+  uint16_t nx, ny;              // windows per row / column (c/jda.c:335-336)
+  uint16_t tiles_x;             // tiles per row of windows
+  uint16_t level;               // index into DevPlan::lv
+  uint16_t image;               // image index inside the pass (the queues pack it in 16 bits)
+  uint16_t pad0; uint32_t pad1, pad2;
+};
+static_assert(sizeof(RagSeg) == 32, "RagSeg is read as two 16-byte words");
+struct RagBlk { uint32_t seg, tile; };
+struct RagImg {                 // k_repack: one image of a ragged batch, tight rows -> common row pitch
+  unsigned long long src_off, dst_off;
+  int w, h;
+};
+
 // Split node as k_finish reads it: 32 bytes, two 16-byte loads (the
 // reference's jdaNode is also 32 bytes, c/jda.c:114-127).
 struct NodeF {
@@ -122,6 +143,8 @@ struct WorkT {
   // per-window trace (all null when off), indexed by gid
   int* tr_carts; Real* tr_score; uint32_t* tr_hash; Real* tr_shape;
   unsigned cap;                                                // capacity of every per-window array
+  // ragged batch (all null otherwise): (image, level) segments, the block map of the scan launches, image offsets
+  const RagSeg* segs; const RagBlk* blk; const unsigned long long* img_off;
 #ifdef JDA_SCAN_TIMING
   unsigned long long* dbg;                                     // [65536][16] shader-clock stamps of k_scan workgroups
 #endif
@@ -179,6 +202,17 @@ template <typename Real>
 hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
                        const DevPlan& h_plan, const DevModelT<Real>& m, const S0Node* table,
                        const WorkT<Real>& w, hipStream_t stream);
+
+// The same for a ragged batch: one launch over blocks [blk_base, blk_base + blk_n) of WorkT::blk, all of pixel mode
+// `mode` with workgroups of `block` threads and pixel tiles of at most pix_bytes.
+template <typename Real>
+hipError_t launch_scan_ragged(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
+                              const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w, int pix_bytes,
+                              int blk_base, int blk_n, hipStream_t stream);
+
+// Tight images (row stride = width) at raw + src_off -> rows of `pitch` bytes at dst + dst_off, n images of at most
+// max_h rows.
+hipError_t launch_repack(const uint8_t* raw, uint8_t* dst, const RagImg* imgs, int n, int max_h, int pitch, hipStream_t stream);
 
 // Stages [t_begin, t_end) for every queued window: t_begin == 0 reads the hand-off queue,
 // t_begin > 0 the mid queue; survivors go to the mid queue (t_end < T) or the detection list.
