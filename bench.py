@@ -401,6 +401,73 @@ def main():
         casc.close()
         return windows_step * steps / el
 
+    # ---- BASELINE.json configs[3] / the metric's "FDDB images/sec": an FDDB-shaped job (2,845 images <= 450x450 of
+    #      varied aspect, the reference's one-Detect-per-image loop, src/test.cpp:100-170) as ONE ragged job
+    #      (jdaDetectBatchRaggedDevice), images resident in HBM, sharded over the ranks in contiguous blocks,
+    #      detections gathered on rank 0 inside the timed region.  A FIXED job: strong scaling. ----
+    def fddb_leg(reps):
+        n_img = 2845
+        rng = np.random.default_rng(0)
+        sizes = []
+        for _ in range(n_img):
+            long_side = int(rng.integers(300, 451)); short = int(rng.integers(225, long_side + 1))
+            sizes.append((long_side, short) if rng.random() < 0.5 else (short, long_side))
+        lo, hi = jdist.shard_range(n_img, rank, world)
+        base = synth.make_frames(64, 450, 450, seed=7)          # images = crops of 64 synthetic 450x450 frames
+        imgs = [np.ascontiguousarray(base[i % 64][:sizes[i][1], :sizes[i][0]]) for i in range(lo, hi)]
+        offs, tot = [], 0
+        for im in imgs:
+            offs.append(tot); tot += im.size
+        buf = np.concatenate([im.reshape(-1) for im in imgs]) if imgs else np.zeros(0, np.uint8)
+        ws, hs = [sizes[i][0] for i in range(lo, hi)], [sizes[i][1] for i in range(lo, hi)]
+        d_buf = torch.from_numpy(buf).to(dev)
+        casc = api.Cascador(casc_model, device=local_rank)
+        gather, _ = make_gather()
+        kw = dict(scale=call["scale"], min_size=call["min_size"], max_size=call["max_size"], th=call["th"])
+
+        def job(src):
+            rows, st = casc.detect_ragged_packed(src, offs, ws, hs, stats=True, keep_results="packed", frame_offset=lo, **kw)
+            if world > 1:
+                gather.start(rows)
+            return rows, st
+        for _ in range(2):
+            job(d_buf)
+        gather.drain()
+        barrier(); t0 = time.perf_counter()
+        for _ in range(reps):
+            rows, st = job(d_buf)
+        gather.drain()
+        barrier(); el = time.perf_counter() - t0
+        windows = st["patch_n"]
+        if world > 1:
+            t = torch.tensor([el, float(windows)], dtype=torch.float64, device=gather_dev)
+            tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); el = float(tm[0].item())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM); windows = int(t[1].item())
+        info = {"images": n_img, "images_per_s": n_img * reps / el, "windows_per_s": windows * reps / el,
+                "ms_per_job": el / reps * 1e3, "jobs_timed": reps, "windows_per_job": windows, "scaling": "strong",
+                "entry": "jdaDetectBatchRaggedDevice (images resident in HBM), one host thread per GPU",
+                "sharding": "contiguous blocks of images over %d rank(s)" % world,
+                "data": "synthetic, FDDB-like sizes (long side 300-450, short side >= 225)"}
+        if world == 1:
+            job(buf)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                job(buf)
+            info["host_images_per_s"] = n_img * reps / (time.perf_counter() - t0)
+            info["host_entry"] = "jdaDetectBatchRagged, the images in one pageable host buffer (PCIe-inclusive)"
+        casc.close()
+        if hasattr(gather, "close"):
+            gather.close()
+        return info
+
+    fddb_info = None
+    try:
+        fddb_info = fddb_leg(max(1, min(5, args.steps)))
+    except Exception as e:
+        if world > 1:
+            raise
+        fddb_info = {"error": repr(e)}
+
     host_info = None
     if world == 1:
         hs = max(2, min(30, args.steps))
@@ -472,12 +539,14 @@ def main():
                 traffic = None
         scan_bytes_alg = roof_info["scan_lds_carts_per_step"] * ((D - 1) * 34 + 16)
         line = {
-            "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path)",
+            "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path); FDDB images/sec in fddb_images_per_s",
             "value": casc_info["windows_per_s"], "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": casc_info["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "images_per_s": casc_info["images_per_s"],
+            "fddb_images_per_s": fddb_info.get("images_per_s") if fddb_info else None,
+            "fddb": fddb_info,
             "config": {"workload": "BASELINE.json configs[1]: batch=%d %dx%d frames per GPU, synthetic %dx%d-cart "
                                    "%d-landmark depth-%d model, cascade regime, jdaDetect(1.25,0.1,40,-1,-0.5)"
                                    % (B, W, H, T, K, L, D),

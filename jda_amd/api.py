@@ -358,7 +358,7 @@ class Cascador:
         return (out, st.asdict()) if stats else out
 
     def detect_ragged_packed(self, buf, offsets, widths, heights, scale=1.25, min_size=40, max_size=-1, th=-0.5,
-                             nms=True, stats=False, keep_results=True):
+                             nms=True, stats=False, keep_results=True, frame_offset=0):
         """The same for images packed in ONE buffer (image i = buf[offsets[i] : offsets[i] + w*h], rows back to
         back): a numpy uint8 array (host entry, jdaDetectBatchRagged) or a torch uint8 CUDA tensor
         (jdaDetectBatchRaggedDevice)."""
@@ -379,7 +379,7 @@ class Cascador:
                                                 min_size, max_size, th, C.byref(o), res)
         if rc != 0:
             raise JdaError(last_error())
-        out = self._collect(res, n, keep_results)
+        out = self._collect(res, n, keep_results, frame_offset)
         return (out, st.asdict()) if stats else out
 
     # -- two batches in flight from one thread -----------------------------------

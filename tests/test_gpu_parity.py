@@ -857,7 +857,7 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["achieved"] > 0 and d["regimes"]["cascade"]["detections_after_nms"] > 0
-    assert "gather" in d["config"]
+    assert "gather" in d["config"] and d["fddb_images_per_s"] > 0
 
 
 def test_bench_plain_invocation_one_gpu(built, gpu):
@@ -880,6 +880,7 @@ def test_bench_plain_invocation_one_gpu(built, gpu):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert 0 < d["roofline"]["frac"] <= 1
+    assert d["fddb_images_per_s"] > 0 and d["fddb"]["images"] == 2845                 # BASELINE metric: "FDDB images/sec"
 
 
 def test_pipelined_gather_device_path_over_rccl_group_of_one(built, gpu):
