@@ -79,6 +79,9 @@ JDA_API void jdaCascadorRelease(void *cascador);
  *   max_size  <= 0 means min(width, height) (c/jda.c:460)
  *   th        final score cut (c/jda.c:414)
  * Output order: scan order (level, y, x) of the windows that survive NMS.
+ * Re-entrant like the reference (no globals, no locks in c/jda.c:443-480): any number of threads may call it -- and
+ * every other detect entry below -- on ONE cascador at the same time; each call takes a lane (stream + workspace)
+ * from the cascador's pool, the model and the scan plans are shared read-only.
  * Runs the cascade on the GPU (HIP device selected with jdaSetDevice, default
  * the current device).  There is no CPU fallback: if no HIP device is usable
  * the call returns an empty result, sets jdaGetLastError() and prints the
@@ -124,8 +127,8 @@ JDA_API int jdaCascadorInfo(void *cascador, jdaModelInfo *info);
 JDA_API int jdaSetDevice(void *cascador, int device);
 
 /* Tuning options of a cascador.  They start from the JDA_* environment variables (read once, when the cascador
- * is created) and can be changed here while no submitted batch is pending; a change drops the
- * cached scan plans.  None of them changes results.  Documented keys:
+ * is created) and can be changed here while NO call is running and no submitted batch is pending
+ * on this cascador (refused otherwise); a change drops the cached scan plans.  None of them changes results.  Documented keys:
  *   "handoff"       carts of stage 0 the scan kernel evaluates before the finishing kernel takes over (128)
  *   "lanes"         sub-batches of one synchronous call that run side by side on their own streams (2)
  *   "dense"         whole-stage tile kernel for models that reject little: 0 off, 1 auto, 2 always (1)
@@ -133,7 +136,7 @@ JDA_API int jdaSetDevice(void *cascador, int device);
  *   "plan_cache"    scan plans (one per frame size and call parameters) kept per cascador (64)
  *   "predict"       size the finishing launches from the previous pass instead of a host round trip (1)
  * (the other keys of DESIGN.md section 8 are accepted as well; they are experiment switches).
- * Returns 0, or -1 for an unknown key / a pending batch.  jdaGetOption returns the value (-1: unknown key). */
+ * Returns 0, or -1 for an unknown key / a running call or pending batch.  jdaGetOption returns the value (-1: unknown key). */
 JDA_API int jdaSetOption(void *cascador, const char *key, long long value);
 JDA_API long long jdaGetOption(void *cascador, const char *key);
 
@@ -217,17 +220,16 @@ JDA_API int jdaDetectBatchRaggedDevice(void *cascador, const unsigned char *d_ba
                                        jdaResult *out);
 
 /* Up to three batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
- * Submit queues the stage-0 scan of a batch of device-resident frames and returns at once with a
- * ticket (0..2; -1 on error: every ticket in use, the workspace would have to grow while another
- * batch is pending, multi-scale model); Wait walks that batch through the rest of the pipeline,
- * post-processes it and fills out[0..n) exactly like jdaDetectBatchDevice.  Submitting batch i+1
- * before waiting for batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i
- * (queue-length reads, D2H, sort, NMS, result assembly) run (one batch ahead is enough for frames that are
- * already on the device; frames coming from the host want two ahead, see jdaDetectBatchSubmitHost).
- * The frames must stay valid until Wait
- * returns; the other entry points refuse to run while a ticket is pending.  opt->stats is ignored by
- * Submit; Wait takes the stats pointer (gpu_ms = that batch's own device span, call_ms = submit to
- * the end of wait). */
+ * Submit queues a batch of device-resident frames on a lane of its own (stream + workspace) and returns at once with
+ * a ticket (0..2; -1 on error: every ticket in use, multi-scale model); Wait collects that batch, post-processes it
+ * and fills out[0..n) exactly like jdaDetectBatchDevice.  When earlier passes on this frame size have shown how many
+ * windows survive the scan, the WHOLE batch (scan, finishing launches, copies of the results) is queued by Submit and
+ * Wait is a single host wait.  Submitting batch i+1 before waiting for batch i keeps the GPU busy with batch i+1
+ * while the host parts of batch i (D2H, sort, NMS, result assembly) run (one batch ahead is enough for frames that
+ * are already on the device; frames coming from the host want two ahead, see jdaDetectBatchSubmitHost).
+ * The frames must stay valid until Wait returns.  The other entry points keep working while tickets are pending
+ * (they run on other lanes).  opt->stats is ignored by Submit; Wait takes the stats pointer (gpu_ms = that batch's
+ * own device span, call_ms = submit to the end of wait). */
 JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, size_t frame_stride, int n,
                                  int width, int height, float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt);

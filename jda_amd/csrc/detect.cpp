@@ -202,22 +202,10 @@ constexpr int kFinishTileWin = -1;
 // the copy is one more dependent step in front of them (measured: 1.816 ms of GPU time per step with tiles of 46, 57
 // or 72 pixels against 1.806 without)
 constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
-// sub-batches in flight at once, each on its own stream + workspace: two inside one synchronous call; three tickets
-// of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms, the
-// copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight)
-constexpr int kLanes = 3;
-
-template <typename Real>
-struct Workspace {
-  DevBuf buf;
-  DevBuf frames;     // staging for host-frame entry points
-  DevBuf pyr;        // half + quarter images (multi-scale models)
-  WorkT<Real> w[kLanes] = {};   // one carving per lane (run_device)
-  size_t cap = 0;
-  bool trace = false;
-  int dim = 0;
-  int lanes = 0;
-};
+// tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms,
+// the copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight); also the chunks of a
+// ragged job that are in flight at once
+constexpr int kTickets = 3;
 
 struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
 
@@ -240,58 +228,96 @@ struct HostPinned {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
 };
 
+// One caller's share of the device: a stream with its events, a workspace and the staging buffers of a pass.
+// A call takes lanes from the cascador's pool for as long as it runs (a big synchronous batch takes two, a ragged job
+// up to three, a submitted batch holds one until its Wait) and gives them back; the pool grows with the number of
+// concurrent callers.  Nothing in a lane is touched by anybody but its current holder, which is what makes
+// jdaDetect re-entrant on ONE cascador (the reference has no globals and no locks, c/jda.c:443-480).
+struct Lane {
+  bool busy = false;
+  hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;                // global-pixel scan launch of a lone lane, next to its LDS-tiled launches
+  hipEvent_t ev[5] = {};
+  hipEvent_t ev_side[2] = {};
+  hipEvent_t ev_user = nullptr;
+  unsigned long long* h_cnt = nullptr;       // pinned copy of the work counters
+  HostPinned h_gid, h_score, h_shape;        // detections of the lane's pass
+  DevBuf ws;                                 // per-window arrays, carved for one dialect at a time
+  size_t cap = 0; bool trace = false; int dim = 0, real_bytes = 0;
+  WorkT<float> wf{};
+  WorkT<double> wd{};
+  DevBuf frames;                             // staging of host frames (the call's first lane holds the whole batch)
+  DevBuf pyr;                                // half + quarter images (multi-scale models), method-0 levels
+  // ragged passes: images at the common pitch, tight images, tables (segments, block map, image records)
+  DevBuf rag_frames, rag_raw, rag_tab;
+  HostPinned h_tab, h_raw;
+  bool create() {
+    JDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& e : ev) JDA_HIP(hipEventCreate(&e));
+    JDA_HIP(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+    JDA_HIP(hipHostMalloc((void**)&h_cnt, sizeof(unsigned long long) * kCntShards * kCntStride, hipHostMallocDefault));
+    return true;
+  }
+  bool ensure_side() {
+    if (side) return true;
+    JDA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (auto& e : ev_side) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return true;
+  }
+  void destroy() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (side) (void)hipStreamSynchronize(side);
+    ws.release(); frames.release(); pyr.release(); rag_frames.release(); rag_raw.release(); rag_tab.release();
+    h_gid.release(); h_score.release(); h_shape.release(); h_tab.release(); h_raw.release();
+    if (h_cnt) (void)hipHostFree(h_cnt);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
+    if (ev_user) (void)hipEventDestroy(ev_user);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (side) (void)hipStreamDestroy(side);
+  }
+};
+
 struct Cascador {
   HostModel hm;
   Knobs kn;
+  // Guards the shared parts only -- device/model initialisation, the plan cache, the lane pool, the tickets and the
+  // hints below -- for the few microseconds those take; no device work runs under it.
   std::mutex mu;
   // queue lengths of the last pass as fractions of its windows (hand-off queue, detections): a new plan starts from
   // them, see PlanEntry::pred_tail
   double pred_tail = -1, pred_out = -1;
   bool last_dense = false;
-  HostPinned h_gid[kLanes], h_score[kLanes], h_shape[kLanes];   // detections of a lane's pass
-  // ragged passes, per lane: images at the common pitch, tight images, tables (segments, block map, image records)
-  DevBuf rag_frames[kLanes], rag_raw[kLanes], rag_tab[kLanes];
-  HostPinned h_tab[kLanes], h_raw[kLanes];
   int similarity = 0;          // dialect CPP: Config::with_similarity_transform (reference common.cpp:214)
   int device = -1;
-  int n_cus = 256;             // compute units of the device (persistent kernels launch one workgroup each)
+  int n_cus = 256;             // compute units of the device
   bool dev_init = false;
-  hipStream_t stream[kLanes] = {};                                  // one per lane, see Pass / run_device
-  hipEvent_t ev[kLanes][5] = {};
-  hipEvent_t ev_user = nullptr;
-  hipStream_t side[kLanes] = {};                            // global-pixel scan launch of a lane, next to its LDS-tiled launches
-  hipEvent_t ev_side[kLanes][2] = {};
+  hipStream_t aux = nullptr;   // stage-0 table builds (under mu)
+  std::vector<std::unique_ptr<Lane>> lanes;
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
   struct PlanBuffers { DevPlan* dp; S0Node* table; size_t table_cap; };
   std::vector<PlanBuffers> plan_pool;     // device allocations of evicted plans (hipFree + hipMalloc per miss cost ~0.1 ms)
   unsigned long long plan_clock = 0;
-  Workspace<float> wf;
-  Workspace<double> wd;
-  unsigned long long* h_counters = nullptr;  // pinned
-  PendingBatch* pending = nullptr;           // [kLanes], allocated by the first submit
-  // host frames whose H2D copies run_device issues per sub-batch (set by stage_frames(.., defer), consumed
-  // by the next run_device): the copies of one sub-batch then overlap the kernels of the other lane
-  DevBuf submit_frames[kLanes];              // staging of jdaDetectBatchSubmitHost, one per ticket
-  const unsigned char* const* pending_host = nullptr;
-  size_t pending_fbytes = 0;
+  PendingBatch* pending = nullptr;           // [kTickets], allocated by the first submit
 };
 
 template <typename Real> struct Sel;
 template <> struct Sel<float> {
   static ModelOnDevice<float>& model(Cascador* c) { return c->mf; }
-  static Workspace<float>& ws(Cascador* c) { return c->wf; }
+  static WorkT<float>& work(Lane* l) { return l->wf; }
   static constexpr int dialect = JDA_DIALECT_C;
 };
 template <> struct Sel<double> {
   static ModelOnDevice<double>& model(Cascador* c) { return c->md; }
-  static Workspace<double>& ws(Cascador* c) { return c->wd; }
+  static WorkT<double>& work(Lane* l) { return l->wd; }
   static constexpr int dialect = JDA_DIALECT_CPP;
 };
 
-// ---------------------------------------------------------------- device init
+// ---------------------------------------------------------------- device init, lanes
 
+// Makes the cascador's device current for the calling thread; first use picks the device (caller holds c->mu then).
 static bool ensure_device(Cascador* c) {
   if (c->dev_init) {
     JDA_HIP(hipSetDevice(c->device));
@@ -312,29 +338,55 @@ static bool ensure_device(Cascador* c) {
   if (c->device >= n) { fail("device ordinal out of range"); return false; }
   JDA_HIP(hipSetDevice(c->device));
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
-  // lane 0 now; the second lane's stream and events when a batch first needs them (ensure_lane):
-  // cascadors that only see single frames (one per host thread in the FDDB harness) keep one stream
-  JDA_HIP(hipStreamCreateWithFlags(&c->stream[0], hipStreamNonBlocking));
-  for (auto& ev : c->ev[0]) JDA_HIP(hipEventCreate(&ev));
-  JDA_HIP(hipEventCreate(&c->ev_user));
-  JDA_HIP(hipHostMalloc((void**)&c->h_counters, sizeof(unsigned long long) * kCntShards * kCntStride * kLanes, hipHostMallocDefault));
+  JDA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
   c->dev_init = true;
   return true;
 }
 
-static bool ensure_lane(Cascador* c, int lane) {
-  if (c->stream[lane]) return true;
-  JDA_HIP(hipStreamCreateWithFlags(&c->stream[lane], hipStreamNonBlocking));
-  for (auto& ev : c->ev[lane]) JDA_HIP(hipEventCreate(&ev));
-  return true;
+// A free lane (caller holds c->mu): the one whose workspace fits `want_cap` windows most tightly, else the largest,
+// else a new one.
+static Lane* acquire_lane_locked(Cascador* c, size_t want_cap) {
+  Lane* best = nullptr;
+  for (auto& up : c->lanes) {
+    Lane* l = up.get();
+    if (l->busy) continue;
+    if (!best) { best = l; continue; }
+    const bool fit = l->cap >= want_cap, bfit = best->cap >= want_cap;
+    if (fit != bfit ? fit : (fit ? l->cap < best->cap : l->cap > best->cap)) best = l;
+  }
+  if (!best) {
+    std::unique_ptr<Lane> l(new (std::nothrow) Lane());
+    if (!l || !l->create()) { if (l) l->destroy(); return nullptr; }
+    best = l.get();
+    c->lanes.push_back(std::move(l));
+  }
+  best->busy = true;
+  return best;
 }
 
-static bool ensure_side(Cascador* c, int lane) {
-  if (c->side[lane]) return true;
-  JDA_HIP(hipStreamCreateWithFlags(&c->side[lane], hipStreamNonBlocking));
-  for (auto& ev : c->ev_side[lane]) JDA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  return true;
-}
+// The lanes a call holds; given back when it leaves.
+struct LaneSet {
+  Cascador* c;
+  std::vector<Lane*> v;
+  explicit LaneSet(Cascador* c_) : c(c_) {}
+  LaneSet(const LaneSet&) = delete;
+  LaneSet& operator=(const LaneSet&) = delete;
+  bool take(int n, size_t want_cap = 0) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    while ((int)v.size() < n) {
+      Lane* l = acquire_lane_locked(c, want_cap);
+      if (!l) return false;
+      v.push_back(l);
+    }
+    return true;
+  }
+  Lane* detach(size_t i) { Lane* l = v[i]; v.erase(v.begin() + i); return l; }   // the caller keeps it (submitted batch)
+  ~LaneSet() {
+    if (v.empty()) return;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (Lane* l : v) l->busy = false;
+  }
+};
 
 template <typename Real>
 static bool upload_model(Cascador* c) {
@@ -610,9 +662,11 @@ static void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& k
   }
 }
 
+// The plan of (frame size, call parameters), built on first use.  Caller holds c->mu.  The plan comes back PINNED
+// (PlanEntry::pins): it is not evicted -- its device tables are not recycled -- until unpin_plan.
 static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out, bool ragged = false) {
   auto it = c->plans.find(key);
-  if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; *out = &it->second; return true; }
+  if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; it->second.pins++; *out = &it->second; return true; }
   // bounded cache: a stream of differently sized images (FDDB) must not pile up device tables
   const size_t cap = (size_t)std::max<long long>(2, c->kn.plan_cache);
   while (c->plans.size() >= cap) {
@@ -621,7 +675,7 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     auto victim = c->plans.end();
     for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
       if (p->second.pins == 0 && (victim == c->plans.end() || p->second.last_use < victim->second.last_use)) victim = p;
-    if (victim == c->plans.end()) break;        // every plan is pinned (at most kLanes are): exceed the cap for now
+    if (victim == c->plans.end()) break;        // every plan is in use: exceed the cap for now
     c->plan_pool.push_back({victim->second.dp, victim->second.table, victim->second.table_cap});
     c->plans.erase(victim);
   }
@@ -658,16 +712,23 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     }
     const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
     const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
-    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->stream[0]));
-    // the scans that read the table run on other streams (second lane, caller's stream)
-    JDA_HIP(hipStreamSynchronize(c->stream[0]));
+    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->aux));
+    // the scans that read the table run on the lanes' streams
+    JDA_HIP(hipStreamSynchronize(c->aux));
   }
   pe.last_use = ++c->plan_clock;
   pe.pred_tail = c->pred_tail; pe.pred_out = c->pred_out;      // a new frame size starts from the cascador's last pass
   pe.dense_hint = c->last_dense;
+  pe.pins = 1;
   auto ins = c->plans.emplace(key, std::move(pe));
   *out = &ins.first->second;
   return true;
+}
+
+static void unpin_plan(Cascador* c, PlanEntry* pe) {
+  if (!pe) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (pe->pins > 0) pe->pins--;
 }
 
 // ---------------------------------------------------------------- workspace
@@ -679,13 +740,15 @@ static size_t bytes_per_window(int dim, bool trace) {
   return b;
 }
 
+// The lane's per-window arrays for `cap` windows of dialect Real (grow-only; the lane is idle: its holder has
+// collected whatever ran on it).
 template <typename Real>
-static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
-  Workspace<Real>& ws = Sel<Real>::ws(c);
-  const int dim = c->hm.dim();
-  if (ws.cap >= cap && (ws.trace || !trace) && ws.dim == dim && ws.lanes >= lanes) return true;
-  auto carve_lane = [&](Carver& cv, int lane) {
-    WorkT<Real>& w = ws.w[lane];
+static bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim) {
+  if (ln->cap >= cap && (ln->trace || !trace) && ln->dim == dim && ln->real_bytes == (int)sizeof(Real)) return true;
+  trace = trace || (ln->trace && ln->dim == dim && ln->real_bytes == (int)sizeof(Real));
+  cap = std::max(cap, ln->real_bytes == (int)sizeof(Real) && ln->dim == dim ? ln->cap : (size_t)0);
+  WorkT<Real>& w = Sel<Real>::work(ln);
+  auto carve = [&](Carver& cv) {
     w.q_gid = cv.take<uint32_t>(cap);
     w.q_score = cv.take<Real>(cap);
     w.q_kstart = cv.take<uint32_t>(cap);
@@ -713,21 +776,20 @@ static bool ensure_workspace(Cascador* c, size_t cap, bool trace, int lanes) {
       w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
     }
   };
-  auto carve = [&](Carver& cv) { for (int l = 0; l < lanes; l++) carve_lane(cv, l); };
-  for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);   // nothing may still use the old carving
+  if (ln->stream) (void)hipStreamSynchronize(ln->stream);      // nothing may still use the old carving
+  w = WorkT<Real>{};
   Carver sz(nullptr);
   carve(sz);
-  if (!ws.buf.reserve(sz.off + 256)) {
-    // the old allocation is gone: forget every pointer carved out of it, so that a later, smaller
-    // request carves afresh instead of passing the `ws.cap >= cap` test on dangling pointers
-    ws.cap = 0; ws.lanes = 0; ws.trace = false;
-    for (auto& w : ws.w) w = WorkT<Real>{};
+  if (!ln->ws.reserve(sz.off + 256)) {
+    // the old allocation is gone: forget every pointer carved out of it
+    ln->cap = 0; ln->trace = false; ln->real_bytes = 0;
+    ln->wf = WorkT<float>{}; ln->wd = WorkT<double>{};
     return false;
   }
-  Carver cv(ws.buf.p);
+  Carver cv(ln->ws.p);
   carve(cv);
-  for (int l = 0; l < lanes; l++) ws.w[l].cap = (unsigned)cap;
-  ws.cap = cap; ws.trace = trace; ws.dim = dim; ws.lanes = lanes;
+  w.cap = (unsigned)cap;
+  ln->cap = cap; ln->trace = trace; ln->dim = dim; ln->real_bytes = (int)sizeof(Real);
   return true;
 }
 
@@ -802,8 +864,17 @@ template <typename Real>
 struct Pass {
   Cascador* c; PlanEntry* pe; const TraceOut<Real>* trace; RawDets<Real>* dets; RunStats* rs;
   bool apply_th; Real th; bool multi = false;   // multi: hm().multi_scale(), a scan of the model: computed once
-  int lane = 0; bool solo = true;   // solo: the only lane of this call
+  Lane* ln = nullptr; int lane = 0; bool solo = true;   // lane: index inside the call; solo: the only lane of this call
   hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
+  // the plan's hints as they stood when the pass was set up (the plan is shared with concurrent callers: read and
+  // written under c->mu only, see bind())
+  bool hint_dense = false; double pred_tail = -1, pred_out = -1;
+  void bind(Lane* l, int index, hipStream_t stream) {
+    ln = l; lane = index; st = stream ? stream : l->stream; ev = l->ev; h_cnt = l->h_cnt;
+    w = Sel<Real>::work(l); cap = l->cap;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out;
+  }
   WorkT<Real> w; size_t cap = 0;
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
@@ -893,7 +964,7 @@ struct Pass {
     //      the results do not depend on the choice. ----
     int pix_cap, lds_max;
     const bool ok = dense_ok(&pix_cap, &lds_max);
-    dense = ok && (kn().dense == 2 || pe->dense_hint);
+    dense = ok && (kn().dense == 2 || hint_dense);
     if (dense) {
       JDA_HIP(hipEventRecord(ev[1], st));
       JDA_HIP(hipEventRecord(ev[2], st));
@@ -929,11 +1000,11 @@ struct Pass {
       // hand-off count is read, so that it runs next to the LDS-tiled launches (with two lanes the other
       // lane already provides that mix; measured slower there)
       auto fork_glb = [&]() -> bool {
-        hipStream_t sd = c->side[lane];
-        JDA_HIP(hipEventRecord(c->ev_side[lane][0], st));
-        JDA_HIP(hipStreamWaitEvent(sd, c->ev_side[lane][0], 0));
+        hipStream_t sd = ln->side;
+        JDA_HIP(hipEventRecord(ln->ev_side[0], st));
+        JDA_HIP(hipStreamWaitEvent(sd, ln->ev_side[0], 0));
         if (!scan(2, -1, sd)) return false;
-        JDA_HIP(hipEventRecord(c->ev_side[lane][1], sd));
+        JDA_HIP(hipEventRecord(ln->ev_side[1], sd));
         any_glb = false;
         side_pending = true;
         return true;
@@ -942,14 +1013,14 @@ struct Pass {
       if (small) {
         // small job (a frame or a few): all levels of a pixel mode in one launch -- every workgroup
         // is resident at once anyway, so per-level launches would only serialise their latency
-        if (any_glb && solo && kn().side_small && ensure_side(c, lane) && !fork_glb()) return false;
+        if (any_glb && solo && kn().side_small && ln->ensure_side() && !fork_glb()) return false;
         if (lds_blocks > 0 && !scan(1, -1, st)) return false;
         if (any_wide && !scan(3, -1, st)) return false;
       } else {
         // odd lanes go through the levels in the opposite order (big windows first): the launches of
         // one lane then run next to different ones of the other instead of next to their twins
         const bool rev = (lane & 1) && kn().lanes_reverse;
-        if (any_glb && solo && kn().side_stream && ensure_side(c, lane) && !fork_glb()) return false;
+        if (any_glb && solo && kn().side_stream && ln->ensure_side() && !fork_glb()) return false;
         if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
@@ -963,7 +1034,7 @@ struct Pass {
       lds_span = !side_pending && !(((lane & 1) && kn().lanes_reverse) && !small);   // LDS launches first, back to back
       if (lds_span) JDA_HIP(hipEventRecord(ev[4], st));
       if (any_glb && !scan(2, -1, st)) return false;
-      if (side_pending) JDA_HIP(hipStreamWaitEvent(st, c->ev_side[lane][1], 0));
+      if (side_pending) JDA_HIP(hipStreamWaitEvent(st, ln->ev_side[1], 0));
     }
     JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();
@@ -975,13 +1046,13 @@ struct Pass {
   // host reads the queue length first (after_tail).
   bool issue_rest() {
     int pix_cap, lds_max;
-    if (kn().predict && pe->pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pe->pred_tail >= 0.4)) {
+    if (kn().predict && pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pred_tail >= 0.4)) {
       const long long nw = windows();
-      const long long guess = std::min<long long>((long long)cap, (long long)(pe->pred_tail * (double)nw * 1.1) + 64);
+      const long long guess = std::min<long long>((long long)cap, (long long)(pred_tail * (double)nw * 1.1) + 64);
       if (!launch_finishers(guess)) return false;
       predicted = true;
       if (!issue_counters()) return false;
-      const double po = pe->pred_out >= 0 ? pe->pred_out : 0.0;
+      const double po = pred_out >= 0 ? pred_out : 0.0;
       return issue_results(0, std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64));
     }
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
@@ -993,18 +1064,18 @@ struct Pass {
   bool issue_scan_ragged() {
     const DevModelT<Real>& m = model();
     const RaggedChunk& ch = *rag;
-    uint8_t* tab = (uint8_t*)c->rag_tab[lane].p;
-    JDA_HIP(hipMemcpyAsync(tab, c->h_tab[lane].p, ch.table_bytes, hipMemcpyHostToDevice, st));
+    uint8_t* tab = (uint8_t*)ln->rag_tab.p;
+    JDA_HIP(hipMemcpyAsync(tab, ln->h_tab.p, ch.table_bytes, hipMemcpyHostToDevice, st));
     const uint8_t* raw = ch.d_raw;
     if (ch.host_imgs) {
       // tight images -> device: one copy when they lie back to back in the caller's memory, else through the lane's
       // pinned staging buffer (filled by build_chunk)
-      const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : c->h_raw[lane].p;
-      JDA_HIP(hipMemcpyAsync(c->rag_raw[lane].p, src, ch.raw_bytes, hipMemcpyHostToDevice, st));
-      raw = (const uint8_t*)c->rag_raw[lane].p;
+      const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : ln->h_raw.p;
+      JDA_HIP(hipMemcpyAsync(ln->rag_raw.p, src, ch.raw_bytes, hipMemcpyHostToDevice, st));
+      raw = (const uint8_t*)ln->rag_raw.p;
     }
-    JDA_HIP(launch_repack(raw, (uint8_t*)c->rag_frames[lane].p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
-    w.frames = (const uint8_t*)c->rag_frames[lane].p; w.frame_stride = 0; w.n_frames = ch.n;
+    JDA_HIP(launch_repack(raw, (uint8_t*)ln->rag_frames.p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
+    w.frames = (const uint8_t*)ln->rag_frames.p; w.frame_stride = 0; w.n_frames = ch.n;
     w.segs = (const RagSeg*)(tab + ch.off_segs); w.blk = (const RagBlk*)(tab + ch.off_blk);
     w.img_off = (const unsigned long long*)(tab + ch.off_imgoff);
     if (!clear_counters()) return false;
@@ -1058,7 +1129,7 @@ struct Pass {
     if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
       // most windows are still alive after the scan: start over in dense mode (the scan's work
       // is a small part of T*K carts per window) and remember the choice for the next pass
-      pe->dense_hint = true;
+      { std::lock_guard<std::mutex> lk(c->mu); pe->dense_hint = true; }
       if (rag) return launch_finishers(n_tail);   // (a ragged pass finishes window by window; the NEXT job runs image by image, dense)
       dense = true; finished = true;
       if (!clear_counters()) return false;
@@ -1083,7 +1154,7 @@ struct Pass {
   bool issue_results(size_t from, size_t to) {
     const int dim = hm().dim();
     if (!dets || to <= from) return true;
-    HostPinned &hg = c->h_gid[lane], &hs = c->h_score[lane], &hh = c->h_shape[lane];
+    HostPinned &hg = ln->h_gid, &hs = ln->h_score, &hh = ln->h_shape;
     if (!hg.reserve(to * 4, from * 4) || !hs.reserve(to * sizeof(Real), from * sizeof(Real)) ||
         !hh.reserve(to * dim * sizeof(Real), from * dim * sizeof(Real))) return false;
     const size_t n = to - from;
@@ -1110,26 +1181,30 @@ struct Pass {
     rs->tail += (long long)h_cnt[kCntTail];
     const double nw = (double)windows();
     const double dense_frac = (double)kn().dense_pct / 100.0;
-    if (dense) {
-      rs->dense_passes++;
-      // fall back to the sparse pipeline when stage 0 rejects most windows after all
-      if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * nw) pe->dense_hint = false;
-    } else {
-      // what the next pass on this plan (and a new plan of this cascador) may expect; a prediction decays slowly,
-      // so that one quiet batch does not undersize the launches of the next busy one
-      const double ft = (double)h_cnt[kCntTail] / nw;
-      pe->pred_tail = std::max(ft, pe->pred_tail * 0.9);
-      c->pred_tail = pe->pred_tail;
-      int pix_cap, lds_max;
-      if (predicted && kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && ft >= dense_frac && h_cnt[kCntTail] > 4096)
-        pe->dense_hint = true;       // this pass went through k_finish window by window; the next one runs dense
-    }
-    c->last_dense = pe->dense_hint;
     n_tail = (long long)h_cnt[kCntTail];
     n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;
     if (n_out > cap) { fail("internal: more detections than windows"); return false; }
-    if (!dense) { pe->pred_out = std::max((double)n_out / nw, pe->pred_out * 0.9); c->pred_out = pe->pred_out; }
+    if (dense) rs->dense_passes++;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);            // the plan and the cascador's hints are shared with concurrent callers
+      if (dense) {
+        // fall back to the sparse pipeline when stage 0 rejects most windows after all
+        if ((double)h_cnt[kCntStage0] < 0.5 * dense_frac * nw) pe->dense_hint = false;
+      } else {
+        // what the next pass on this plan (and a new plan of this cascador) may expect; a prediction decays slowly,
+        // so that one quiet batch does not undersize the launches of the next busy one
+        const double ft = (double)h_cnt[kCntTail] / nw;
+        pe->pred_tail = std::max(ft, pe->pred_tail * 0.9);
+        c->pred_tail = pe->pred_tail;
+        pe->pred_out = std::max((double)n_out / nw, pe->pred_out * 0.9);
+        c->pred_out = pe->pred_out;
+        int pix_cap, lds_max;
+        if (predicted && kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && ft >= dense_frac && h_cnt[kCntTail] > 4096)
+          pe->dense_hint = true;       // this pass went through k_finish window by window; the next one runs dense
+      }
+      c->last_dense = pe->dense_hint;
+    }
     if (n_out > out_copied && !issue_results(out_copied, n_out)) return false;   // the prediction fell short (or there was none)
     return true;
   }
@@ -1143,9 +1218,9 @@ struct Pass {
       if (results_pending) JDA_HIP(hipStreamSynchronize(st));
       results_pending = false;
       if (kn().debug_times) fprintf(stderr, "[jda] lane %d: results D2H wait %.3f ms (%zu detections)\n", lane, now_ms() - t_dbg, n_out);
-      const uint32_t* g = (const uint32_t*)c->h_gid[lane].p;
-      const Real* sc = (const Real*)c->h_score[lane].p;
-      const Real* sh = (const Real*)c->h_shape[lane].p;
+      const uint32_t* g = (const uint32_t*)ln->h_gid.p;
+      const Real* sc = (const Real*)ln->h_score.p;
+      const Real* sh = (const Real*)ln->h_shape.p;
       // back into scan order: sort (gid, arrival index) packed in one word -- gids are unique
       std::vector<unsigned long long> key(n_out);
       for (size_t i = 0; i < n_out; i++) key[i] = ((unsigned long long)g[i] << 32) | (unsigned long long)i;
@@ -1174,22 +1249,29 @@ struct Pass {
 };
 
 struct PendingBatch {
-  bool active = false;
+  bool active = false;       // submitted, not yet collected
+  bool reserved = false;     // a submit is filling this slot
+  bool waiting = false;      // a Wait is collecting it
+  Lane* lane = nullptr;      // held (busy) from Submit to the end of Wait
   Pass<float> pass;
   RawDets<float> dets;
   RunStats rs;
-  PlanEntry* pe = nullptr;
+  PlanEntry* pe = nullptr;   // pinned from Submit to the end of Wait
   ScanPlan sp;
   int n = 0;
   bool opt_set = false;
   jdaDetectOptions opt{};
   double t_submit = 0;
-  // host-frame submits: the H2D copy (blocking for pageable memory) and the scan launches run on the cascador's
-  // copier thread, so that the submitting thread is free to collect the other ticket meanwhile
+  // host-frame submits: the H2D copy (blocking for pageable memory) and the scan launches run on a helper thread,
+  // so that the submitting thread is free to collect the other ticket meanwhile
   std::thread issuer;
   bool issue_ok = true;
   std::string issue_err;
   void join_issuer() { if (issuer.joinable()) issuer.join(); }
+  void reset() {             // (keeps `reserved`; the issuer has been joined)
+    lane = nullptr; pass = Pass<float>(); dets = RawDets<float>(); rs = RunStats(); pe = nullptr; sp = ScanPlan();
+    n = 0; opt_set = false; opt = jdaDetectOptions{}; t_submit = 0; issue_ok = true; issue_err.clear();
+  }
 };
 
 // test hook: JDA_TEST_WPF_SCALE pretends every frame has that many times more windows (the gid-overflow guard
@@ -1199,28 +1281,34 @@ static bool jda_gid_overflow(const Knobs& kn, long long n, long long wpf) {
   return (double)n * (double)wpf * (double)scale > 4294967295.0;
 }
 
-// Runs the device pipeline over n frames resident in device memory.  Large batches are split
-// into sub-batches that alternate between two lanes (streams with their own workspace), see Pass.
+// Frames of a call that are still in host memory: run_device copies them sub-batch by sub-batch into the staging buffer
+// of the call's first lane (the copies of one sub-batch then overlap the kernels of the other lane).
+struct HostFrames {
+  const unsigned char* const* ptrs = nullptr;
+  size_t fbytes = 0;
+};
+
+// Runs the device pipeline over n frames in device memory (d_frames; with host.ptrs set they are copied there first,
+// sub-batch by sub-batch).  `lanes` holds the call's first lane; a large batch takes a second one from the pool and
+// is split into sub-batches that alternate between the two (streams with their own workspace), see Pass.
 template <typename Real>
-static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
                        bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
-                       const TraceOut<Real>* trace, RunStats* rs) {
+                       const TraceOut<Real>* trace, RunStats* rs, HostFrames host = HostFrames()) {
   constexpr int dialect = Sel<Real>::dialect;
   const HostModel& hm = c->hm;
   const int dim = hm.dim();
   const long long wpf = pe->sp.windows;
   const bool want_trace = trace != nullptr;
   const bool multi = hm.multi_scale();
-  const unsigned char* const* host_frames = c->pending_host;   // set by stage_frames(.., defer = true)
-  const size_t host_fbytes = c->pending_fbytes;
-  c->pending_host = nullptr; c->pending_fbytes = 0;
-  if (host_frames && d_frames != (const uint8_t*)Sel<Real>::ws(c).frames.p) host_frames = nullptr;   // stale: not this call's staging
-  for (int i = 0; c->pending && i < kLanes; i++)
-    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return false; }
+  const unsigned char* const* host_frames = host.ptrs;
+  const size_t host_fbytes = host.fbytes;
   if (n == 0) return true;
+  if (lanes_held.v.empty() && !lanes_held.take(1)) return false;
   if (wpf == 0) {     // nothing to scan; still honour the staging contract
-    if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(d_frames), stride, host_frames, n, host_fbytes, c->stream[0])) return false;
-    if (host_frames) JDA_HIP(hipStreamSynchronize(c->stream[0]));
+    Lane* l0 = lanes_held.v[0];
+    if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(d_frames), stride, host_frames, n, host_fbytes, l0->stream)) return false;
+    if (host_frames) JDA_HIP(hipStreamSynchronize(l0->stream));
     return true;
   }
 
@@ -1228,7 +1316,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
   const long long lanes_min = c->kn.lanes_min_windows;
   int lanes = (int)c->kn.lanes;
   if (lanes < 1) lanes = 1;
-  if (lanes > kLanes) lanes = kLanes;
+  if (lanes > 2) lanes = 2;
   if (n < 2 || (long long)n * wpf < lanes_min * 2) lanes = 1;
   // frames still on the host: smaller sub-batches on two lanes, so that the (host-blocking, pageable)
   // copy of one sub-batch overlaps the kernels of the previous one
@@ -1252,8 +1340,9 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     return false;
   }
   const size_t cap = (size_t)fpp * (size_t)wpf;
-  if (!ensure_workspace<Real>(c, cap, want_trace, lanes)) return false;
-  Workspace<Real>& ws = Sel<Real>::ws(c);
+  if (!lanes_held.take(lanes, cap)) return false;
+  for (int l = 0; l < lanes; l++)
+    if (!ensure_workspace<Real>(lanes_held.v[l], cap, want_trace, dim)) return false;
 
   int hw = 0, hh = 0, qw = 0, qh = 0;
   size_t hs = 0, qs = 0;
@@ -1267,22 +1356,15 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     qw = pe->sp.width / 2; qh = pe->sp.height / 2;
     if (hw < 1 || hh < 1 || qw < 1 || qh < 1) { fail("frame too small for the half/quarter images"); return false; }
     hs = ((size_t)hw * hh + 255) & ~(size_t)255; qs = ((size_t)qw * qh + 255) & ~(size_t)255;
-    if (!ws.pyr.reserve((hs + qs) * (size_t)fpp * (size_t)lanes + 512)) return false;
+    for (int l = 0; l < lanes; l++)
+      if (!lanes_held.v[l]->pyr.reserve((hs + qs) * (size_t)fpp + 512)) return false;
   }
 
   // lane 0 runs on the caller's stream when one was given; the other lane is ordered after the
   // work already queued there
-  hipStream_t lane_stream[kLanes];
-  for (int l = 0; l < lanes; l++) {
-    if (!ensure_lane(c, l)) return false;
-    lane_stream[l] = c->stream[l];
-  }
-  if (user_stream) {
-    lane_stream[0] = user_stream;
-    if (lanes > 1) {
-      JDA_HIP(hipEventRecord(c->ev_user, user_stream));
-      for (int l = 1; l < lanes; l++) JDA_HIP(hipStreamWaitEvent(lane_stream[l], c->ev_user, 0));
-    }
+  if (user_stream && lanes > 1) {
+    JDA_HIP(hipEventRecord(lanes_held.v[0]->ev_user, user_stream));
+    for (int l = 1; l < lanes; l++) JDA_HIP(hipStreamWaitEvent(lanes_held.v[l]->stream, lanes_held.v[0]->ev_user, 0));
   }
 
   std::vector<Pass<Real>> ps;
@@ -1292,9 +1374,9 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
     for (int l = 0; l < lanes && f0 < n; l++) {
       Pass<Real> p;
       p.c = c; p.pe = pe; p.trace = trace; p.dets = dets; p.rs = rs; p.apply_th = apply_th; p.th = th; p.multi = multi;
-      p.lane = l; p.solo = lanes == 1; p.st = lane_stream[l]; p.ev = c->ev[l];
-      p.h_cnt = c->h_counters + (size_t)l * kCntShards * kCntStride;
-      p.w = ws.w[l]; p.cap = cap;
+      p.solo = lanes == 1;
+      p.bind(lanes_held.v[l], l, l == 0 ? user_stream : nullptr);
+      p.cap = cap;
       p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);
       p.w.frames = d_frames + (size_t)f0 * stride; p.w.frame_stride = stride; p.w.n_frames = p.nf;
       if (host_frames) { p.host_frames = host_frames + f0; p.host_fbytes = host_fbytes; }
@@ -1304,7 +1386,7 @@ static bool run_device(Cascador* c, PlanEntry* pe, const uint8_t* d_frames, size
       ps.push_back(std::move(p));
     }
     for (auto& p : ps) {
-      uint8_t* hbuf = multi ? (uint8_t*)ws.pyr.p + (hs + qs) * (size_t)fpp * (size_t)p.lane : nullptr;
+      uint8_t* hbuf = multi ? (uint8_t*)p.ln->pyr.p : nullptr;
       if (!p.issue_scan(hbuf, hs, hbuf ? hbuf + hs * (size_t)fpp : nullptr, qs, nullptr)) return false;
     }
     for (auto& p : ps) if (!p.after_tail()) return false;
@@ -1524,35 +1606,92 @@ static double post_c(Cascador* c, const ScanPlan& sp, const RawDets<float>& dets
   return now_ms() - t0;
 }
 
-// Validation + plan of a dialect-C call (shared by the synchronous and the submit/wait entries).
+// Validation + plan of a dialect-C call (shared by the synchronous and the submit/wait entries).  Takes c->mu for
+// the shared parts (device, model, plan cache); the plan comes back pinned.
 static bool plan_c_call(Cascador* c, size_t stride, int width, int height, float scale, int min_size, int max_size,
                         ScanPlan* sp, PlanEntry** pe) {
   std::string err;
   if (!plan_dialect_c(width, height, scale, min_size, max_size, sp, &err)) { fail(err); return false; }
   if (stride < (size_t)width * height) { fail("frame_stride smaller than a frame"); return false; }
+  std::lock_guard<std::mutex> lk(c->mu);
   if (!ensure_device(c) || !upload_model<float>(c)) return false;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
   return get_plan(c, key, *sp, JDA_DIALECT_C, pe);
 }
 
-// dialect C batch on device-resident frames -> per-frame jdaResult
+struct PlanPin {           // unpins on scope exit
+  Cascador* c; PlanEntry* pe;
+  ~PlanPin() { unpin_plan(c, pe); }
+};
+
+// The shared part of an entry, under c->mu: device, the model of dialect Real on the device, the plan (pinned).
+template <typename Real>
+static bool begin_call(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** pe) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!ensure_device(c) || !upload_model<Real>(c)) return false;
+  return get_plan(c, key, sp, dialect, pe);
+}
+
+// Dialect CPP walks stages [0, current_stage_idx) and then carts [0, current_cart_idx] of the next one
+// (cascador.cpp:178,199-209): header ints 5, 6 of the model file (cascador.cpp:93-104).  A complete model carries
+// (T, -1); the float files of the C library carry (T+1, -1) (c/jda.c:662-665), which the reference's own C++ loader
+// would walk out of bounds with -- both mean "every stage" here.  Training snapshots (fewer stages, or a stage cut
+// at a cart) are refused by the dialect-CPP entries instead of being silently run to the end; dialect C ignores the
+// header like c/jda.c:499-505 does.
+static bool cpp_model_complete(const Cascador* c) {
+  const HostModel& h = c->hm;
+  if ((h.hdr_stage == h.T || h.hdr_stage == h.T + 1) && h.hdr_cart == -1) return true;
+  fail("partial model (training snapshot: header says stage " + std::to_string(h.hdr_stage) + ", cart " + std::to_string(h.hdr_cart) +
+       " of T=" + std::to_string(h.T) + "): the dialect-CPP entries run complete models only");
+  return false;
+}
+
+// ... without a plan (entries that only need a lane)
+static bool begin_device(Cascador* c) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  return ensure_device(c);
+}
+
+// Reserves the lane's staging buffer for n host frames.  defer = false: copies them now and waits; defer = true:
+// leaves the copies to run_device (per sub-batch).
+static bool stage_frames(Lane* ln, const unsigned char* const* frames, int n, size_t fbytes, size_t* stride,
+                         bool defer = false) {
+  *stride = (fbytes + 255) & ~(size_t)255;
+  for (int i = 0; i < n; i++)
+    if (!frames[i]) { fail("null frame pointer"); return false; }
+  if (!ln->frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
+  if (defer) return true;
+  if (!copy_frames_h2d((uint8_t*)ln->frames.p, *stride, frames, n, fbytes, ln->stream)) return false;
+  JDA_HIP(hipStreamSynchronize(ln->stream));
+  return true;
+}
+
+// dialect C batch -> per-frame jdaResult.  Frames on the device (d_frames) or, with host_frames set, in host memory
+// (staged through the call's first lane).
 static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
                            float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
-                           jdaResult* out) {
+                           jdaResult* out, const unsigned char* const* host_frames = nullptr) {
   const double t_call = now_ms();
-  // caller holds c->mu
   if (!c || !out || n < 0) { fail("bad arguments"); return -1; }
   const int L = c->hm.L;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
-  for (int i = 0; c->pending && i < kLanes; i++)
-    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return -1; }
+  if (host_frames) stride = (size_t)width * height;
   ScanPlan sp;
   PlanEntry* pe = nullptr;
   if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &sp, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  HostFrames host;
+  if (host_frames) {
+    if (!lanes.take(1, (size_t)std::max<long long>(1, sp.windows))) return -1;
+    if (!stage_frames(lanes.v[0], host_frames, n, (size_t)width * height, &stride, true)) return -1;
+    d_frames = (const uint8_t*)lanes.v[0]->frames.p;
+    host.ptrs = host_frames; host.fbytes = (size_t)width * height;
+  }
   RawDets<float> dets;
   RunStats rs;
-  if (!run_device<float>(c, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs))
+  if (!run_device<float>(c, lanes, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs, host))
     return -1;
   const double post_ms = post_c(c, sp, dets, n, opt, out);
   fill_stats(opt ? opt->stats : nullptr, rs, sp.windows * n, c->hm.T, c->hm.K, post_ms);
@@ -1560,70 +1699,77 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   return 0;
 }
 
-// ---- submit / wait: two batches in flight on one cascador, driven by one host thread ----
-// Submit queues the scan of a batch (no host wait) on a free lane; Wait walks that batch through the
-// rest of the pipeline and post-processes it.  A caller that submits batch i+1 before it waits for
-// batch i keeps the GPU busy with the scan of i+1 while the host parts of batch i run.
+// ---- submit / wait: batches in flight on one cascador, driven by one host thread ----
+// Submit queues a batch (no host wait) on a lane of its own; Wait collects and post-processes it.  A caller that
+// submits batch i+1 before it waits for batch i keeps the GPU busy with batch i+1 while the host parts of batch i run.
 static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
                            float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
                            const unsigned char* const* host_frames = nullptr) {
   if (!c || n <= 0 || (!d_frames && !host_frames)) { fail("bad arguments"); return -1; }
   if (host_frames) stride = (((size_t)width * height) + 255) & ~(size_t)255;      // frames of the staging buffer
   if (c->hm.multi_scale()) { fail("submit/wait supports models whose split nodes read the original image only"); return -1; }
-  if (!c->pending) c->pending = new PendingBatch[kLanes];
-  int slot = -1;
-  for (int i = 0; i < kLanes; i++) if (!c->pending[i].active) { slot = i; break; }
-  if (slot < 0) { fail("every submit slot is in use: wait for a batch first"); return -1; }
-  PendingBatch& pb = c->pending[slot];
-  pb.join_issuer();
-  pb = PendingBatch();
-  if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &pb.sp, &pb.pe)) return -1;
-  PlanEntry* const plan_entry = pb.pe;
-  const long long wpf = pb.sp.windows;
+  ScanPlan sp;
+  PlanEntry* pe = nullptr;
+  if (!plan_c_call(c, stride, width, height, scale, min_size, max_size, &sp, &pe)) return -1;
+  PlanPin pin{c, pe};                       // released on the error paths; handed to the ticket on success
+  const long long wpf = sp.windows;
   if (wpf <= 0) { fail("no candidate window in these frames"); return -1; }
   if ((long long)n * wpf > 0x7fffffffLL || n > 65535) { fail("batch too large for one submit: split it"); return -1; }
   const size_t cap = (size_t)n * (size_t)wpf;
-  bool other_active = false;
-  for (int i = 0; i < kLanes; i++) other_active = other_active || (i != slot && c->pending[i].active);
-  Workspace<float>& ws = c->wf;
-  const bool fits = ws.cap >= cap && ws.dim == c->hm.dim() && ws.lanes >= kLanes;
-  if (!fits) {
-    if (other_active) { fail("the workspace must grow for this batch while another one is pending: wait for it first"); return -1; }
-    if (!ensure_workspace<float>(c, cap, false, kLanes)) return -1;
-  }
-  if (!ensure_lane(c, slot)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1, cap)) return -1;
+  Lane* ln = lanes.v[0];
+  if (!ensure_workspace<float>(ln, cap, false, c->hm.dim())) return -1;
   if (host_frames) {
-    // frames still on the host: this ticket's own staging buffer, filled on this ticket's stream (the copy of
-    // batch i+1 then runs next to the kernels of batch i, which live on the other ticket's stream)
+    // frames still on the host: the ticket's lane stages them on its own stream (the copy of batch i+1 then runs next
+    // to the kernels of batch i, which live on the other ticket's stream)
     for (int i = 0; i < n; i++) if (!host_frames[i]) { fail("null frame pointer"); return -1; }
-    if (!c->submit_frames[slot].reserve(stride * (size_t)n)) return -1;
-    d_frames = (const uint8_t*)c->submit_frames[slot].p;
+    if (!ln->frames.reserve(stride * (size_t)n)) return -1;
+    d_frames = (const uint8_t*)ln->frames.p;
   }
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pending) c->pending = new PendingBatch[kTickets];
+    for (int i = 0; i < kTickets; i++) if (!c->pending[i].active && !c->pending[i].reserved) { slot = i; break; }
+    if (slot >= 0) c->pending[slot].reserved = true;
+  }
+  if (slot < 0) { fail("every submit slot is in use: wait for a batch first"); return -1; }
+  PendingBatch& pb = c->pending[slot];
+  pb.join_issuer();
+  pb.reset();
+  pb.sp = sp; pb.pe = pe;
   pb.n = n; pb.opt_set = opt != nullptr; if (opt) pb.opt = *opt;
   pb.opt.stats = nullptr;
   pb.t_submit = now_ms();
   Pass<float>& p = pb.pass;
+  p = Pass<float>();
   p.c = c; p.pe = pb.pe; p.trace = nullptr; p.dets = &pb.dets; p.rs = &pb.rs; p.apply_th = true; p.th = th; p.multi = false;
-  p.lane = slot; p.solo = true; p.st = c->stream[slot]; p.ev = c->ev[slot];
-  p.h_cnt = c->h_counters + (size_t)slot * kCntShards * kCntStride;
-  p.w = ws.w[slot]; p.cap = ws.cap;
+  p.solo = true;
+  p.bind(ln, 0, nullptr);
   p.f0 = 0; p.nf = n;
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
   p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
   p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
   if (host_frames) { p.host_frames = host_frames; p.host_fbytes = (size_t)width * height; }
+  auto give_up = [&]() { std::lock_guard<std::mutex> lk(c->mu); pb.reserved = false; return -1; };
   // opt->hip_stream: the stream the caller produced the frames on -- the scan is ordered behind the work
   // already queued there (the batch itself still runs on the lane's own stream)
   if (opt && opt->hip_stream) {
-    if (hipEventRecord(c->ev_user, (hipStream_t)opt->hip_stream) != hipSuccess ||
-        hipStreamWaitEvent(p.st, c->ev_user, 0) != hipSuccess) { fail("cannot order the batch behind opt->hip_stream"); return -1; }
+    if (hipEventRecord(ln->ev_user, (hipStream_t)opt->hip_stream) != hipSuccess ||
+        hipStreamWaitEvent(p.st, ln->ev_user, 0) != hipSuccess) { fail("cannot order the batch behind opt->hip_stream"); return give_up(); }
   }
+  auto commit = [&]() {
+    std::lock_guard<std::mutex> lk(c->mu);
+    pb.lane = lanes.detach(0);             // the ticket holds the lane (still busy) and the plan pin until its Wait
+    pin.pe = nullptr;
+    pb.active = true; pb.reserved = false;
+  };
   if (host_frames && c->kn.host_submit_thread) {
     // the copy + scan launches of this ticket on their own thread (joined by Wait): a pageable H2D copy blocks
     // its caller for the whole transfer (1.8 ms per 256 frames 640x480), time in which the submitting thread can
     // already collect and post-process the other ticket
-    pb.active = true;
-    plan_entry->pins++;
+    commit();
     pb.issue_ok = true; pb.issue_err.clear();
     PendingBatch* pbp = &pb;
     const int dev = c->device;
@@ -1635,53 +1781,49 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
     });
     return slot;
   }
-  if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) return -1;
-  pb.active = true;
-  plan_entry->pins++;
+  if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { (void)hipStreamSynchronize(ln->stream); return give_up(); }
+  commit();
   return slot;
 }
 
 static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
-  if (!c || slot < 0 || slot >= kLanes || !out || !c->pending || !c->pending[slot].active) { fail("no pending batch in this slot"); return -1; }
+  if (!c || slot < 0 || slot >= kTickets || !out) { fail("no pending batch in this slot"); return -1; }
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->pending || !c->pending[slot].active || c->pending[slot].waiting) { fail("no pending batch in this slot"); return -1; }
+    c->pending[slot].waiting = true;           // (two threads waiting for one ticket: the second is refused)
+    if (!ensure_device(c)) { c->pending[slot].waiting = false; return -1; }   // the waiting thread's current device may differ
+  }
   PendingBatch& pb = c->pending[slot];
-  if (!ensure_device(c)) return -1;           // the waiting thread's current device may differ (multi-GPU process)
   const int L = c->hm.L, n = pb.n;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   Pass<float>& p = pb.pass;
   pb.join_issuer();
-  pb.active = false;
-  if (pb.pe && pb.pe->pins > 0) pb.pe->pins--;
-  if (!pb.issue_ok) { fail(pb.issue_err); return -1; }
-  p.dets = &pb.dets; p.rs = &pb.rs;              // (the PendingBatch may have moved since submit: re-point)
-  if (!p.after_tail() || !p.after_mid() || !p.issue_counters() || !p.after_counters() || !p.collect()) return -1;
-  float ms_scan = 0, ms_all = 0;
-  (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
-  (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
-  pb.rs.scan_ms += ms_scan; pb.rs.gpu_ms += ms_all;
-  if (p.lds_span) { float ms = 0; if (hipEventElapsedTime(&ms, p.ev[1], p.ev[4]) == hipSuccess) pb.rs.scan_lds_ms += ms; }
-  const double post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
-  fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
-  if (stats) stats->call_ms = now_ms() - pb.t_submit;
-  return 0;
-}
-
-// Reserves the staging buffer for n host frames.  defer = false: copies them now (callers that touch
-// the staged frames before run_device); defer = true: leaves the copies to run_device (per sub-batch).
-template <typename Real>
-static bool stage_frames(Cascador* c, const unsigned char* const* frames, int n, size_t fbytes, size_t* stride,
-                         bool defer = false) {
-  Workspace<Real>& ws = Sel<Real>::ws(c);
-  *stride = (fbytes + 255) & ~(size_t)255;
-  for (int i = 0; i < n; i++)
-    if (!frames[i]) { fail("null frame pointer"); return false; }
-  if (ws.frames.bytes < *stride * (size_t)std::max(n, 1))
-    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
-  if (!ws.frames.reserve(*stride * (size_t)std::max(n, 1))) return false;
-  c->pending_host = nullptr; c->pending_fbytes = 0;
-  if (defer) { c->pending_host = frames; c->pending_fbytes = fbytes; return true; }
-  if (!copy_frames_h2d((uint8_t*)ws.frames.p, *stride, frames, n, fbytes, c->stream[0])) return false;
-  JDA_HIP(hipStreamSynchronize(c->stream[0]));
-  return true;
+  bool ok = pb.issue_ok;
+  if (!ok) fail(pb.issue_err);
+  p.dets = &pb.dets; p.rs = &pb.rs;
+  ok = ok && p.after_tail() && p.after_mid() && p.issue_counters() && p.after_counters() && p.collect();
+  if (!ok) (void)hipStreamSynchronize(pb.lane->stream);
+  double post_ms = 0;
+  if (ok) {
+    float ms_scan = 0, ms_all = 0;
+    (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+    (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    pb.rs.scan_ms += ms_scan; pb.rs.gpu_ms += ms_all;
+    if (p.lds_span) { float ms = 0; if (hipEventElapsedTime(&ms, p.ev[1], p.ev[4]) == hipSuccess) pb.rs.scan_lds_ms += ms; }
+    post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
+    fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
+    if (stats) stats->call_ms = now_ms() - pb.t_submit;
+  }
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (pb.pe && pb.pe->pins > 0) pb.pe->pins--;
+    pb.pe = nullptr;
+    if (pb.lane) pb.lane->busy = false;
+    pb.lane = nullptr;
+    pb.active = false; pb.waiting = false;
+  }
+  return ok ? 0 : -1;
 }
 
 // ---------------------------------------------------------------- ragged batches (images of different sizes)
@@ -1755,7 +1897,8 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
   job->levels.windows = 0;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{pitch, nl, 3 /* ragged, dialect C */, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, h};
-  if (!get_plan(c, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!get_plan(c, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
   if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
   if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
   for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;
@@ -1764,7 +1907,7 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
 
 // Tables of images [i0, i0 + n) into the lane's pinned table buffer (and, for host images that do not lie back to
 // back, the images into the lane's pinned staging buffer).
-static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, int lane, RaggedChunk* ch) {
+static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
   const DevPlan& hp = job.pe->hp;
   const int nl = hp.n_levels;
   ch->i0 = i0; ch->n = n; ch->pitch = job.pitch;
@@ -1791,8 +1934,8 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
   ch->off_rimg = o; o = align_up(o + (size_t)n * sizeof(RagImg), 256);
   ch->table_bytes = o;
-  if (!c->h_tab[lane].reserve(o) || !c->rag_tab[lane].reserve(o)) return false;
-  uint8_t* tab = (uint8_t*)c->h_tab[lane].p;
+  if (!ln->h_tab.reserve(o) || !ln->rag_tab.reserve(o)) return false;
+  uint8_t* tab = (uint8_t*)ln->h_tab.p;
   RagSeg* segs = (RagSeg*)(tab + ch->off_segs);
   RagBlk* blk = (RagBlk*)(tab + ch->off_blk);
   unsigned long long* img_off = (unsigned long long*)(tab + ch->off_imgoff);
@@ -1836,12 +1979,12 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   ch->windows = gid; ch->frame_bytes = dst + 256; ch->max_h = max_h;
   ch->raw_bytes = job.host_imgs ? src : 0;
   ch->host_contiguous = contiguous;
-  if (!c->rag_frames[lane].reserve(ch->frame_bytes)) return false;
+  if (!ln->rag_frames.reserve(ch->frame_bytes)) return false;
   if (job.host_imgs) {
-    if (!c->rag_raw[lane].reserve(src + 16)) return false;
+    if (!ln->rag_raw.reserve(src + 16)) return false;
     if (!contiguous) {
-      if (!c->h_raw[lane].reserve(src + 16)) return false;
-      uint8_t* hr = (uint8_t*)c->h_raw[lane].p;
+      if (!ln->h_raw.reserve(src + 16)) return false;
+      uint8_t* hr = (uint8_t*)ln->h_raw.p;
       for (int i = 0; i < n; i++) std::memcpy(hr + rimg[i].src_off, job.host_imgs[i0 + i], (size_t)rimg[i].w * rimg[i].h);
     }
   }
@@ -1968,10 +2111,11 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   if (!c || !out || n < 0 || !widths || !heights || (!host_imgs && !(d_base && d_offsets))) { fail("bad arguments"); return -1; }
   const int L = c->hm.L;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
-  for (int i = 0; c->pending && i < kLanes; i++)
-    if (c->pending[i].active) { fail("a submitted batch is still pending on this cascador: collect it with jdaDetectBatchWait first"); return -1; }
   if (n == 0) return 0;
-  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  }
   RunStats total;
   long long patch_n = 0;
   double post_ms = 0;
@@ -1992,12 +2136,9 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
       if (W <= 0 || H <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
       int rc;
       if (host_imgs) {
-        size_t stride = 0;
         const unsigned char* one[1] = {host_imgs[i]};
-        if (!stage_frames<float>(c, one, 1, (size_t)W * H, &stride, true)) return -1;
-        rc = detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
+        rc = detect_c_device(c, nullptr, 0, 1, W, H, scale, min_size, max_size, th, &o1, out + i, one);
       } else {
-        c->pending_host = nullptr;
         rc = detect_c_device(c, d_base + d_offsets[i], (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
       }
       if (rc != 0) return -1;
@@ -2013,6 +2154,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   RaggedJob job;
   job.n = n; job.widths = widths; job.heights = heights; job.host_imgs = host_imgs; job.d_base = d_base; job.d_offsets = d_offsets;
   const int prep = ragged_prepare(c, &job, scale, min_size, max_size);
+  PlanPin pin{c, job.pe};
   if (prep < 0) return -1;
   if (prep > 0) return fallback();
   if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
@@ -2021,7 +2163,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   }
 
   // ---- chunks: as many images as make ragged_chunk_windows windows (<= 65535 images, the queues pack the index
-  //      in 16 bits), walked through kLanes lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
+  //      in 16 bits), walked through up to three lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
   //      the host builds and issues chunk i and post-processes chunk i-3 ----
   const DevPlan& hp = job.pe->hp;
   std::vector<int> starts;
@@ -2040,11 +2182,11 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     starts.push_back(n);
   }
   const int n_chunks = (int)starts.size() - 1;
-  const int lanes = std::min(kLanes, n_chunks);
+  const int lanes = std::min(kTickets, n_chunks);
   struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
-  for (int l = 0; l < lanes; l++) if (!ensure_lane(c, l)) return -1;
-  job.pe->pins++;                                   // (nothing else creates plans during the job; belt and braces)
+  LaneSet held(c);
+  if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0)) return -1;
   bool ok = true;
   auto collect = [&](Slot& sl) -> bool {
     Pass<float>& p = sl.pass;
@@ -2064,26 +2206,23 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     Slot& sl = slots[lane];
     if (sl.busy && !collect(sl)) { ok = false; break; }
     sl.dets = RawDets<float>(); sl.rs = RunStats();
-    if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], lane, &sl.ch)) { ok = false; break; }
+    Lane* ln = held.v[lane];
+    if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
     if (sl.ch.windows == 0) {                        // images too small for any window
       post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
       continue;
     }
-    // workspace: every lane holds a whole chunk
-    Workspace<float>& ws = c->wf;
-    if (!(ws.cap >= (size_t)sl.ch.windows && ws.dim == c->hm.dim() && ws.lanes >= lanes)) {
-      for (auto& s2 : slots) if (s2.busy && !collect(s2)) ok = false;       // the carving moves: drain first
-      if (!ok) break;
+    // workspace: every lane holds a whole chunk (its previous chunk has been collected above)
+    {
       const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(c->kn.ragged_chunk_windows, 0x7fffffffLL))
                                        : (size_t)sl.ch.windows;
-      if (!ensure_workspace<float>(c, want, false, lanes)) { ok = false; break; }
+      if (!ensure_workspace<float>(ln, want, false, c->hm.dim())) { ok = false; break; }
     }
     Pass<float>& p = sl.pass;
     p = Pass<float>();
     p.c = c; p.pe = job.pe; p.trace = nullptr; p.dets = &sl.dets; p.rs = &sl.rs; p.apply_th = true; p.th = th; p.multi = false;
-    p.lane = lane; p.solo = lanes == 1; p.st = c->stream[lane]; p.ev = c->ev[lane];
-    p.h_cnt = c->h_counters + (size_t)lane * kCntShards * kCntStride;
-    p.w = ws.w[lane]; p.cap = ws.cap;
+    p.solo = lanes == 1;
+    p.bind(ln, lane, nullptr);
     p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
     p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
     p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
@@ -2096,11 +2235,9 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     if (sl.busy && !collect(sl)) ok = false;
   }
   if (!ok) {
-    for (auto& sl : slots) if (sl.busy) (void)hipStreamSynchronize(sl.pass.st);
-    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
+    for (Lane* l : held.v) (void)hipStreamSynchronize(l->stream);
+    return -1;
   }
-  job.pe->pins--;
-  if (!ok) return -1;
   for (int i = 0; i < n; i++)
     if (!out[i].bboxes) out[i] = empty_result(L);     // (chunks fill every image; belt and braces)
   return finish();
@@ -2144,26 +2281,14 @@ void jdaCascadorSerializeTo(void* cascador, const char* model) {
 void jdaCascadorRelease(void* cascador) {
   Cascador* c = (Cascador*)cascador;
   if (!c) return;
-  for (int i = 0; c->pending && i < kLanes; i++) c->pending[i].join_issuer();    // a submitted batch nobody waited for
+  for (int i = 0; c->pending && i < kTickets; i++) c->pending[i].join_issuer();    // a submitted batch nobody waited for
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
-    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
+    for (auto& l : c->lanes) l->destroy();
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
     for (auto& b : c->plan_pool) { if (b.dp) (void)hipFree(b.dp); if (b.table) (void)hipFree(b.table); }
     c->mf.buf.release(); c->md.buf.release();
-    c->wf.buf.release(); c->wf.frames.release(); c->wf.pyr.release();
-    c->wd.buf.release(); c->wd.frames.release(); c->wd.pyr.release();
-    for (auto& b : c->submit_frames) b.release();
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    for (int l = 0; l < kLanes; l++) {
-      c->h_gid[l].release(); c->h_score[l].release(); c->h_shape[l].release();
-      c->rag_frames[l].release(); c->rag_raw[l].release(); c->rag_tab[l].release(); c->h_tab[l].release(); c->h_raw[l].release();
-    }
-    for (auto& lane : c->ev) for (auto& ev : lane) if (ev) (void)hipEventDestroy(ev);
-    if (c->ev_user) (void)hipEventDestroy(c->ev_user);
-    for (auto& st : c->stream) if (st) (void)hipStreamDestroy(st);
-    for (auto& st : c->side) if (st) (void)hipStreamDestroy(st);
-    for (auto& l : c->ev_side) for (auto& ev : l) if (ev) (void)hipEventDestroy(ev);
   }
   delete[] c->pending;
   delete c;
@@ -2181,6 +2306,8 @@ int jdaSetSimilarityTransform(void* cascador, int on) {
   Cascador* c = (Cascador*)cascador;
   if (!c) return -1;
   std::lock_guard<std::mutex> lock(c->mu);
+  for (auto& l : c->lanes)
+    if (l->busy) { fail("jdaSetSimilarityTransform while a call is running on this cascador"); return -1; }
   on = on ? 1 : 0;
   if (c->similarity != on) {
     c->similarity = on;
@@ -2203,14 +2330,13 @@ int jdaSetOption(void* cascador, const char* key, long long value) {
   Cascador* c = (Cascador*)cascador;
   if (!c || !key) { fail("jdaSetOption: null cascador or key"); return -1; }
   std::lock_guard<std::mutex> lock(c->mu);
-  for (int i = 0; c->pending && i < kLanes; i++)
-    if (c->pending[i].active) { fail("jdaSetOption while a submitted batch is pending"); return -1; }
+  for (auto& l : c->lanes)
+    if (l->busy) { fail("jdaSetOption while a call is running or a submitted batch is pending on this cascador"); return -1; }
+  for (auto& kv : c->plans)
+    if (kv.second.pins) { fail("jdaSetOption while a call is running on this cascador"); return -1; }
   if (!c->kn.set(key, value)) { fail(std::string("jdaSetOption: unknown option '") + key + "'"); return -1; }
-  // scan plans (tile shapes, table chunking) depend on the knobs: rebuild them on next use
-  if (c->dev_init) {
-    (void)hipSetDevice(c->device);
-    for (auto& st : c->stream) if (st) (void)hipStreamSynchronize(st);
-  }
+  // scan plans (tile shapes, table chunking) depend on the knobs: rebuild them on next use (no lane is busy, so
+  // nothing runs on the old ones)
   for (auto& kv : c->plans) c->plan_pool.push_back({kv.second.dp, kv.second.table, kv.second.table_cap});
   c->plans.clear();
   return 0;
@@ -2245,8 +2371,6 @@ int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t f
   g_err.clear();
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchDevice runs dialect C; use jdaDetectBatchCpp"); return -1; }
   if (!cascador) { fail("null cascador"); return -1; }
-  std::lock_guard<std::mutex> lock(((Cascador*)cascador)->mu);
-  ((Cascador*)cascador)->pending_host = nullptr;      // frames are already on the device
   return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
 }
 
@@ -2258,8 +2382,6 @@ int jdaDetectBatchSubmit(void* cascador, const unsigned char* d_frames, size_t f
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmit runs dialect C"); return -1; }
   if (!cascador) { fail("null cascador"); return -1; }
   Cascador* c = (Cascador*)cascador;
-  std::lock_guard<std::mutex> lock(c->mu);
-  c->pending_host = nullptr;
   return submit_c_device(c, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt);
 }
 
@@ -2272,9 +2394,6 @@ int jdaDetectBatchSubmitHost(void* cascador, const unsigned char* const* frames,
   if (!cascador || !frames) { fail("null cascador or frames"); return -1; }
   if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
   Cascador* c = (Cascador*)cascador;
-  std::lock_guard<std::mutex> lock(c->mu);
-  c->pending_host = nullptr;
-  if (!ensure_device(c)) return -1;
   return submit_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, frames);
 }
 
@@ -2282,7 +2401,6 @@ int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* o
   g_err.clear();
   if (!cascador) { fail("null cascador"); return -1; }
   Cascador* c = (Cascador*)cascador;
-  std::lock_guard<std::mutex> lock(c->mu);
   return wait_c_device(c, ticket, stats, out);
 }
 
@@ -2294,11 +2412,8 @@ int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, in
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
   if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
-  size_t stride = 0;
-  std::lock_guard<std::mutex> lock(c->mu);
-  if (!ensure_device(c)) return -1;
-  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
-  return detect_c_device(c, (const uint8_t*)c->wf.frames.p, stride, n, width, height, scale, min_size, max_size, th, opt, out);
+  for (int i = 0; i < n; i++) if (!frames[i]) { fail("null frame pointer"); return -1; }
+  return detect_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, out, frames);
 }
 
 int jdaDetectBatchRagged(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
@@ -2309,8 +2424,6 @@ int jdaDetectBatchRagged(void* cascador, const unsigned char* const* images, con
   Cascador* c = (Cascador*)cascador;
   if (!c || !images || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRagged runs dialect C"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
-  c->pending_host = nullptr;
   return detect_ragged(c, images, nullptr, nullptr, widths, heights, n, scale, min_size, max_size, th, opt, out);
 }
 
@@ -2322,8 +2435,6 @@ int jdaDetectBatchRaggedDevice(void* cascador, const unsigned char* d_base, cons
   Cascador* c = (Cascador*)cascador;
   if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedDevice runs dialect C"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
-  c->pending_host = nullptr;
   return detect_ragged(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, out);
 }
 
@@ -2353,19 +2464,20 @@ int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
   ScanPlan sp; std::string err;
   if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
-  if (!ensure_device(c) || !upload_model<float>(c)) return -1;
-  size_t stride = 0;
-  if (!stage_frames<float>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
   PlanEntry* pe = nullptr;
-  if (!get_plan(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
+  if (!begin_call<float>(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
   TraceOut<float> tr{carts_n, score, path_hash, shapes};
   RunStats rs;
-  if (!run_device<float>(c, pe, (const uint8_t*)c->wf.frames.p, stride, n, false, 0.f, nullptr, nullptr, &tr, &rs)) return -1;
+  if (!run_device<float>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.f, nullptr, nullptr, &tr, &rs,
+                         HostFrames{frames, (size_t)width * height})) return -1;
   return 0;
 }
 
@@ -2378,18 +2490,20 @@ int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int he
   const int w1 = (int)((float)width * r), h1 = (int)((float)height * r), w2 = width / 2, h2 = height / 2;
   if (hw) *hw = w1; if (hh) *hh = h1; if (qw) *qw = w2; if (qh) *qh = h2;
   if (!half && !quarter) return 0;
-  std::lock_guard<std::mutex> lock(c->mu);
-  if (!ensure_device(c)) return -1;
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
   const unsigned char* frames[1] = {data};
   size_t stride = 0;
-  if (!stage_frames<float>(c, frames, 1, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames(ln, frames, 1, (size_t)width * height, &stride)) return -1;
   auto one = [&](unsigned char* dst, int dw, int dh) -> bool {
     if (!dst || dw < 1 || dh < 1) return true;
-    if (!c->wf.pyr.reserve((size_t)dw * dh + 256)) return false;
-    JDA_HIP(launch_resize((const uint8_t*)c->wf.frames.p, stride, 1, width, height, (uint8_t*)c->wf.pyr.p,
-                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, c->stream[0]));
-    JDA_HIP(hipMemcpyAsync(dst, c->wf.pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, c->stream[0]));
-    JDA_HIP(hipStreamSynchronize(c->stream[0]));
+    if (!ln->pyr.reserve((size_t)dw * dh + 256)) return false;
+    JDA_HIP(launch_resize((const uint8_t*)ln->frames.p, stride, 1, width, height, (uint8_t*)ln->pyr.p,
+                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, ln->stream));
+    JDA_HIP(hipMemcpyAsync(dst, ln->pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, ln->stream));
+    JDA_HIP(hipStreamSynchronize(ln->stream));
     return true;
   };
   if (!one(half, w1, h1) || !one(quarter, w2, h2)) return -1;
@@ -2402,19 +2516,21 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
+  if (!cpp_model_complete(c)) return -1;
   ScanPlan sp; std::string err;
   if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
-  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
-  size_t stride = 0;
-  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
   PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
-  if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
   TraceOut<double> tr{carts_n, score, path_hash, shapes};
   RunStats rs;
-  if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs)) return -1;
+  if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs,
+                          HostFrames{frames, (size_t)width * height})) return -1;
   return 0;
 }
 
@@ -2422,17 +2538,19 @@ int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !data || !out || width <= 0 || height <= 0 || ow <= 0 || oh <= 0) { fail("bad arguments"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
-  if (!ensure_device(c)) return -1;
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
   const unsigned char* frames[1] = {data};
   size_t stride = 0;
-  if (!stage_frames<double>(c, frames, 1, (size_t)width * height, &stride)) return -1;
+  if (!stage_frames(ln, frames, 1, (size_t)width * height, &stride)) return -1;
   auto run = [&]() -> bool {
-    if (!c->wd.pyr.reserve((size_t)ow * oh + 256)) return false;
-    JDA_HIP(launch_resize_cv((const uint8_t*)c->wd.frames.p, stride, 1, width, height, (uint8_t*)c->wd.pyr.p,
-                             (size_t)ow * oh, ow, oh, c->stream[0]));
-    JDA_HIP(hipMemcpyAsync(out, c->wd.pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, c->stream[0]));
-    JDA_HIP(hipStreamSynchronize(c->stream[0]));
+    if (!ln->pyr.reserve((size_t)ow * oh + 256)) return false;
+    JDA_HIP(launch_resize_cv((const uint8_t*)ln->frames.p, stride, 1, width, height, (uint8_t*)ln->pyr.p,
+                             (size_t)ow * oh, ow, oh, ln->stream));
+    JDA_HIP(hipMemcpyAsync(out, ln->pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, ln->stream));
+    JDA_HIP(hipStreamSynchronize(ln->stream));
     return true;
   };
   return run() ? 0 : -1;
@@ -2444,14 +2562,17 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
   const int L = c->hm.L, dim = c->hm.dim();
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   if (origin_size < 1 || step < 1 || !(factor > 1.0)) { fail("origin_size/step must be positive and factor > 1"); return -1; }
   if (c->hm.multi_scale()) { fail("method 0 supports only scale==0 split nodes (its per-window half/quarter patches are not reproduced)"); return -1; }
-  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
+  if (!cpp_model_complete(c)) return -1;
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
   size_t stride0 = 0;
-  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride0)) return -1;
+  if (!stage_frames(ln, frames, n, (size_t)width * height, &stride0)) return -1;
 
   // per level: rects (already scaled back), scores, normalised shapes, per frame, in scan order
   struct Cand { int rect[4]; double score; size_t shape_at; };
@@ -2464,7 +2585,7 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
   const size_t lvl_stride = ((size_t)width * height + 255) & ~(size_t)255;
   auto body = [&]() -> bool {
     if (!levels.reserve(2 * lvl_stride * (size_t)std::max(n, 1))) return false;
-    const uint8_t* cur = (const uint8_t*)c->wd.frames.p;
+    const uint8_t* cur = (const uint8_t*)ln->frames.p;
     size_t cur_stride = stride0;
     int w = width, h = height, li = 0;
     double scale = 1.;
@@ -2473,10 +2594,11 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
       if (!plan_single_level(w, h, origin_size, step, &sp, &err)) { fail(err); return false; }
       PlanKey key{w, h, 2 /* method 0 level */, origin_size, step, c->similarity, 0ull};
       PlanEntry* pe = nullptr;
-      if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return false;
+      if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return false;
+      PlanPin pin{c, pe};
       RawDets<double> dets;
       RunStats rs;
-      if (!run_device<double>(c, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return false;
+      if (!run_device<double>(c, lanes, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return false;
       rs_total.carts += rs.carts; rs_total.out += rs.out; rs_total.gpu_ms += rs.gpu_ms; rs_total.scan_ms += rs.scan_ms;
       rs_total.carts_scan += rs.carts_scan; rs_total.win_scan += rs.win_scan; rs_total.scan_launches += rs.scan_launches;
       rs_total.tail += rs.tail;
@@ -2497,8 +2619,8 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
       const int nw = (int)(w / factor), nh = (int)(h / factor);   // cascador.cpp:300-301
       if (nw < 1 || nh < 1) break;
       uint8_t* nxt = (uint8_t*)levels.p + (size_t)(li & 1) * lvl_stride * (size_t)n;
-      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, c->stream[0]));   // cascador.cpp:302
-      JDA_HIP(hipStreamSynchronize(c->stream[0]));
+      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, ln->stream));   // cascador.cpp:302
+      JDA_HIP(hipStreamSynchronize(ln->stream));
       cur = nxt; cur_stride = lvl_stride; w = nw; h = nh; li++;
     }
     return true;
@@ -2610,8 +2732,8 @@ long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int 
 // timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
 __attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {
   Cascador* c = (Cascador*)cascador;
-  if (!c || !c->wf.w[0].dbg) return -1;
-  return hipMemcpy(out, c->wf.w[0].dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  if (!c || c->lanes.empty() || !c->lanes[0]->wf.dbg) return -1;
+  return hipMemcpy(out, c->lanes[0]->wf.dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -2627,21 +2749,23 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
-  std::lock_guard<std::mutex> lock(c->mu);
   const int L = c->hm.L, dim = c->hm.dim();
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  if (!cpp_model_complete(c)) return -1;
   ScanPlan sp; std::string err;
   if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
-  if (!ensure_device(c) || !upload_model<double>(c)) return -1;
-  size_t stride = 0;
-  if (!stage_frames<double>(c, frames, n, (size_t)width * height, &stride, true)) return -1;
   unsigned long long fb; std::memcpy(&fb, &factor, 8);
   PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
   PlanEntry* pe = nullptr;
-  if (!get_plan(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
   RawDets<double> dets;
   RunStats rs;
-  if (!run_device<double>(c, pe, (const uint8_t*)c->wd.frames.p, stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return -1;
+  if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, &dets, nullptr, &rs,
+                          HostFrames{frames, (size_t)width * height})) return -1;
   const double t0 = now_ms();
   std::vector<size_t> first(n + 1, dets.gid.size());
   {

@@ -945,8 +945,7 @@ def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
     assert {ta, tb, ta2} == {0, 1, 2}
     with pytest.raises(api.JdaError):                       # every ticket in use
         c.submit_batch_device(fc)
-    with pytest.raises(api.JdaError):                       # synchronous entries refuse while a ticket is pending
-        c.detect_batch_device(fa)
+    check(c.detect_batch_device(fa, stats=True), "a")       # a synchronous call next to the pending tickets (its own lane)
     check(c.wait_batch(tb, stats=True), "b")                # collected out of order
     tc = c.submit_batch_device(fc)
     check(c.wait_batch(ta, stats=True), "a")

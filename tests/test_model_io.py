@@ -118,3 +118,20 @@ def test_shipped_dims_plumbing_cpu(built, tmp_path):
     assert os.path.getsize(p4) == 5389448
     c2 = api.Cascador(p4, "float")
     assert (c2.T, c2.K, c2.L, c2.D) == S_DIMS
+
+
+def test_partial_model_headers_are_refused_by_the_cpp_entries(built, tmp_path):
+    """Header ints 5, 6 (current_stage_idx, current_cart_idx; cascador.cpp:93-104): dialect CPP's Validate stops
+    there (cascador.cpp:178,199-209), so a training snapshot must not be run to the end silently.  Dialect C ignores
+    the header (c/jda.c:499-505).  No GPU needed: the refusal comes before any device work."""
+    import numpy as np
+    from jda_amd import api, synth
+    m = synth.make_model(3, 8, 5, 3, seed=2)
+    full = str(tmp_path / "full.model"); m.save(full, 8)
+    snap = str(tmp_path / "snap.model"); m.save(snap, 8, header_stage=1, header_cart=4)     # jda_xxxx_stage_2_cart_5.model
+    frame = np.zeros((1, 60, 80), np.uint8)
+    c = api.Cascador(snap)
+    for call in (lambda: c.detect_batch_cpp(frame), lambda: c.trace_cpp(frame), lambda: c.detect_batch_cpp_pyramid(frame)):
+        with pytest.raises(api.JdaError, match="partial model"):
+            call()
+    assert api.Cascador(full).T == 3

@@ -1,0 +1,131 @@
+"""jdaDetect is re-entrant on ONE cascador, like the reference's (no globals, no locks: c/jda.c:443-480, SURVEY 8b
+"Threading"): concurrent callers each take a lane (stream + workspace) from the cascador's pool; the model and the
+scan plans are shared."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import S_DIMS, same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _eq(a, b, what=""):
+    for k in ("bboxes", "scores", "shapes"):
+        assert same(a[k], b[k]), (what, k)
+
+
+def test_concurrent_callers_share_one_cascador(built, gpu, tmp_path):
+    """8 threads call jdaDetect on one cascador (single 640x480 frames, shipped dimensions, cascade regime): every
+    result equals the single-threaded one, and the call rate is at least 3x that of one thread."""
+    from jda_amd import api, synth
+    frames = synth.make_frames(16, 640, 480, seed=3)
+    m = synth.make_model(*S_DIMS, seed=1)
+    synth.calibrate_thresholds(m, synth.make_frames(8, 640, 480, seed=0, first=10_000_000))
+    p = str(tmp_path / "s.model"); m.save(p, 8)
+    c = api.Cascador(p)
+    want = [c.detect(f) for f in frames]
+    reps = 40
+    t0 = time.perf_counter()
+    for r in range(reps):
+        c.detect(frames[r % 16])
+    one = reps / (time.perf_counter() - t0)
+    n_thr = 8
+    errors = []
+    got = [[None] * reps for _ in range(n_thr)]
+
+    def work(t):
+        try:
+            for r in range(reps):
+                got[t][r] = c.detect(frames[(t + r) % 16])
+        except Exception as e:           # noqa: BLE001
+            errors.append(repr(e))
+    for _ in range(2):                   # (the first round creates the lanes)
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        many = n_thr * reps / (time.perf_counter() - t0)
+    assert not errors, errors
+    for t in range(n_thr):
+        for r in range(reps):
+            _eq(got[t][r], want[(t + r) % 16], (t, r))
+    print("jdaDetect calls/s: 1 thread %.0f, %d threads on one cascador %.0f (%.1fx)" % (one, n_thr, many, many / one))
+    assert many >= 3.0 * one, (one, many)
+
+
+def test_mixed_entries_run_side_by_side_on_one_cascador(built, gpu, model_file):
+    """Batches, ragged jobs, traces, submit/wait tickets and single frames from different threads at once: same
+    results as alone; a pending ticket no longer blocks the other entry points."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=71, cart_th=-0.9, norm_every=9)
+    c = api.Cascador(p)
+    batch = synth.make_frames(12, 240, 180, seed=1)
+    imgs = [synth.make_frames(1, 100 + 13 * i, 90 + 7 * i, seed=2, first=i)[0] for i in range(9)]
+    d_batch = torch.from_numpy(batch).to(gpu)
+    want_batch = c.detect_batch(batch)
+    want_rag = c.detect_ragged(imgs)
+    want_tr = c.trace(batch[:2])
+    errors = []
+
+    def guard(fn):
+        def run():
+            try:
+                for _ in range(6):
+                    fn()
+            except Exception as e:       # noqa: BLE001
+                errors.append(repr(e))
+        return run
+
+    def do_batch():
+        for a, b in zip(c.detect_batch(batch), want_batch):
+            _eq(a, b, "batch")
+
+    def do_ragged():
+        for a, b in zip(c.detect_ragged(imgs), want_rag):
+            _eq(a, b, "ragged")
+
+    def do_trace():
+        tr = c.trace(batch[:2])
+        for k in want_tr:
+            assert same(tr[k], want_tr[k]), k
+
+    def do_single():
+        for i in (0, 5, 11):
+            _eq(c.detect(batch[i]), want_batch[i], "single")
+
+    lock = threading.Lock()              # (api.Cascador keeps its tickets in one dict)
+
+    def do_tickets():
+        with lock:
+            t1 = c.submit_batch_device(d_batch)
+            t2 = c.submit_batch_host(batch)
+        r1 = c.wait_batch(t1)
+        r2 = c.wait_batch(t2)
+        for a, b, w in zip(r1, r2, want_batch):
+            _eq(a, w, "ticket dev"); _eq(b, w, "ticket host")
+
+    ths = [threading.Thread(target=guard(f)) for f in (do_batch, do_ragged, do_trace, do_single, do_single, do_tickets)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    # a pending ticket and a synchronous call on the same cascador
+    t = c.submit_batch_device(d_batch)
+    for a, b in zip(c.detect_batch(batch), want_batch):
+        _eq(a, b)
+    for a, b in zip(c.wait_batch(t), want_batch):
+        _eq(a, b)

@@ -45,7 +45,8 @@ def main():
     t0 = time.time()
     grays = [fddb.load_gray(os.path.join(d, "images", job[i][1] + ".jpg")) for i in range(lo, hi)]
     decode_s = time.time() - t0
-    cascs = [api.Cascador(mp, device=local) for _ in range(args.threads)]
+    casc = api.Cascador(mp, device=local)           # ONE cascador for every host thread: jdaDetect is re-entrant
+    cascs = [casc] * args.threads
     def work(t):
         out = []
         for j in range(t, len(grays), args.threads):
