@@ -103,10 +103,11 @@ def _load():
     lib.jdaDetectBatchDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
                                          C.POINTER(jdaResult)]
-    lib.jdaDetectBatchRagged.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+    if hasattr(lib, "jdaDetectBatchRagged"):        # (older builds, loaded through JDA_LIB_PATH for A/B runs, lack it)
+      lib.jdaDetectBatchRagged.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
                                          C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
                                          C.POINTER(jdaResult)]
-    lib.jdaDetectBatchRaggedDevice.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+      lib.jdaDetectBatchRaggedDevice.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                                                C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                                C.c_float, C.POINTER(jdaDetectOptions), C.POINTER(jdaResult)]
     lib.jdaDetectBatchSubmit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,

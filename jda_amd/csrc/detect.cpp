@@ -82,10 +82,12 @@ static long long env_ll(const char* name, long long dflt) {
   X(dense_pix, "JDA_DENSE_PIX", 16 * 1024)                                                             \
   X(dense_pct, "JDA_DENSE_PCT", 50)                                                                    \
   X(merge_blocks, "JDA_MERGE_BLOCKS", 2048) /* workgroups below which the LDS-tiled levels share one launch */ \
-  X(side_small, "JDA_SIDE_SMALL", 0)                                                                   \
+  X(side_small, "JDA_SIDE_SMALL", 1)                                                                   \
   X(side_stream, "JDA_SIDE_STREAM", 1)                                                                 \
   X(lanes_reverse, "JDA_LANES_REVERSE", 1)                                                             \
   X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
+  X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
+  X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
   X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
   X(fin_g1, "JDA_FIN_G1", 1)                                                                           \
   X(fin_g2, "JDA_FIN_G2", 0)                                                                           \
@@ -869,11 +871,14 @@ struct Pass {
   // the plan's hints as they stood when the pass was set up (the plan is shared with concurrent callers: read and
   // written under c->mu only, see bind())
   bool hint_dense = false; double pred_tail = -1, pred_out = -1;
+  int busy_lanes = 1;               // lanes of the cascador in use when the pass was set up (concurrent callers)
   void bind(Lane* l, int index, hipStream_t stream) {
     ln = l; lane = index; st = stream ? stream : l->stream; ev = l->ev; h_cnt = l->h_cnt;
     w = Sel<Real>::work(l); cap = l->cap;
     std::lock_guard<std::mutex> lk(c->mu);
     hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out;
+    busy_lanes = 0;
+    for (auto& up : c->lanes) busy_lanes += up->busy ? 1 : 0;
   }
   WorkT<Real> w; size_t cap = 0;
   int f0 = 0, nf = 0;
@@ -1013,7 +1018,9 @@ struct Pass {
       if (small) {
         // small job (a frame or a few): all levels of a pixel mode in one launch -- every workgroup
         // is resident at once anyway, so per-level launches would only serialise their latency
-        if (any_glb && solo && kn().side_small && ln->ensure_side() && !fork_glb()) return false;
+        // (a side stream per caller costs concurrent single-frame callers throughput: only while the cascador is
+        // otherwise quiet, like k_finish_wide)
+        if (any_glb && solo && kn().side_small && busy_lanes <= kn().wide_busy_max && ln->ensure_side() && !fork_glb()) return false;
         if (lds_blocks > 0 && !scan(1, -1, st)) return false;
         if (any_wide && !scan(3, -1, st)) return false;
       } else {
@@ -1099,6 +1106,15 @@ struct Pass {
     const int gm = kn().fin_gm > 0 ? (int)kn().fin_gm : stage_groups();
     const int g2 = kn().fin_g2 > 0 ? (int)kn().fin_g2 : stage_groups();
     n_grid = std::max<long long>(n_grid, 1);
+    // (k_finish_wide is the LATENCY form: a whole CU per window.  With several callers on the cascador at once the
+    // machine is shared and throughput counts: they get the one-wave-per-window kernel)
+    if (n_grid <= kn().wide_max && busy_lanes <= kn().wide_busy_max && finish_wide_ok(hm().dim(), hm().K, hm().leaf_n(), (int)sizeof(Real), multi, Sel<Real>::dialect == JDA_DIALECT_CPP && c->similarity)) {
+      // a small job (a frame or a few): the call's time is the latency of one window's chain through the stages --
+      // every queued window gets a whole workgroup (k_wide.hip)
+      JDA_HIP(launch_finish_wide<Real>(want_trace(), apply_th, th, pe->dp, model(), w, n_grid, s0_tbl(), st));
+      finished = true;
+      return true;
+    }
     if (T == 1 || n_grid <= kn().finish_merge) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch less)

@@ -101,7 +101,10 @@ __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const u
 
 // Registers: three 512-thread workgroups per CU are 6 waves per SIMD, which 80 VGPRs still allow and 82 do not (a
 // two-register creep cost 0.17 ms per step in an r02 experiment) -- the occupancy the LDS footprint permits is pinned.
-template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK>
+// RAGGED: the block map of a ragged batch names the tile (kernels.h: RagSeg / RagBlk).  A template parameter, not a
+// run-time test: with the two ways of finding the tile in one kernel the uniform batch ran 13 % slower (r03, same
+// opcode counts -- the level record no longer stayed where the hot loop wants it).
+template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK, bool RAGGED = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 6 : 4)))
 void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                                 const S0Node* __restrict__ table, WorkT<Real> w,
@@ -143,40 +146,46 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   // stay inside one XCD's L2.
   // level < 0: one launch covers every level of this pixel mode; tiles_total = their tiles per frame.
   // Ragged batch (w.segs): the host's block map names the (image, level) segment and the tile.
-  int frame, trel, gid0;
-  DevLevel lv;
-  const uint8_t* img;
-  if (w.segs != nullptr) {
+  int frame_, trel_, gid0_, level_ = level;
+  unsigned long long img_off_ = 0;
+  RagSeg sg{};
+  if constexpr (RAGGED) {
+    // (wave-uniform values, but loaded through vector memory: readfirstlane puts them where the uniform batch has
+    // them, in SGPRs -- the tile geometry derived from them feeds the address arithmetic of the hot loop)
+    auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
     const RagBlk bs = w.blk[blk_base + blockIdx.x];
-    const RagSeg sg = w.segs[bs.seg];
-    lv = plan->lv[sg.level];
-    lv.nx = sg.nx; lv.ny = sg.ny; lv.tiles_x = sg.tiles_x;
-    level = sg.level;
-    frame = sg.image; trel = (int)bs.tile; gid0 = (int)sg.gid_base;
-    img = w.frames + sg.img_off;
+    const RagSeg g = w.segs[uni(bs.seg)];
+    sg.nx = (uint16_t)uni(g.nx); sg.ny = (uint16_t)uni(g.ny); sg.tiles_x = (uint16_t)uni(g.tiles_x);
+    level_ = (int)uni(g.level);
+    frame_ = (int)uni(g.image); trel_ = (int)uni(bs.tile); gid0_ = (int)uni(g.gid_base);
+    img_off_ = (unsigned long long)uni((unsigned)(g.img_off & 0xffffffffu)) | ((unsigned long long)uni((unsigned)(g.img_off >> 32)) << 32);
   } else {
     int tiles_per_frame = tiles_total;
     if (level >= 0) tiles_per_frame = plan->lv[level].tiles_x * plan->lv[level].tiles_y;
     const int b = blockIdx.x;
     const int group = b / (8 * tiles_per_frame);
     const int r = b - group * (8 * tiles_per_frame);
-    frame = group * 8 + (r & 7);
-    trel = r >> 3;
-    if (frame >= w.n_frames) return;
+    frame_ = group * 8 + (r & 7);
+    trel_ = r >> 3;
+    if (frame_ >= w.n_frames) return;
     if (level < 0) {
-      level = 0;
+      level_ = 0;
       for (int i = 0; i < plan->n_levels; i++) {
         const DevLevel* c = &plan->lv[i];
         if (c->tiled != MODE) continue;
         const int cnt = c->tiles_x * c->tiles_y;
-        if (trel < cnt) { level = i; break; }
-        trel -= cnt;
+        if (trel_ < cnt) { level_ = i; break; }
+        trel_ -= cnt;
       }
     }
-    lv = plan->lv[level];
-    gid0 = frame * plan->windows + lv.base;
-    img = w.frames + (size_t)frame * w.frame_stride;
   }
+  level = level_;
+  DevLevel lv_ = plan->lv[level];
+  if constexpr (RAGGED) { lv_.nx = sg.nx; lv_.ny = sg.ny; lv_.tiles_x = sg.tiles_x; }
+  const DevLevel lv = lv_;
+  const int frame = frame_, trel = trel_;
+  const int gid0 = RAGGED ? gid0_ : frame * plan->windows + lv.base;
+  const uint8_t* img = RAGGED ? w.frames + img_off_ : w.frames + (size_t)frame * w.frame_stride;
   const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
   const int wx0 = tx * lv.tw, wy0 = ty * lv.th;                 // first window of the tile
   const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
@@ -595,9 +604,10 @@ hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max,
   if (w.n_frames == 0) return hipSuccess;
   if (level >= 0 && h_plan.lv[level].tiled != mode) return hipSuccess;
   // 512-thread workgroups where a level's tiles hold more than 256 windows (one window per lane in
-  // phase 0, twice the waves per LDS byte); merged launches use 256
+  // phase 0, twice the waves per LDS byte); a merged launch when any of its levels does
   bool big = false;
-  if (level >= 0 && mode == 1) big = h_plan.lv[level].tw * h_plan.lv[level].th > 256;
+  for (int i = 0; i < h_plan.n_levels && mode == 1; i++)
+    if (h_plan.lv[i].tiled == 1 && (level < 0 || i == level)) big = big || h_plan.lv[i].tw * h_plan.lv[i].th > 256;
   auto pick = [&](auto trace_tag) {
     constexpr bool TR = decltype(trace_tag)::value;
     switch (mode) {
@@ -627,37 +637,35 @@ hipError_t launch_scan_ragged_mode(const DevPlan* d_plan, const DevModelT<Real>&
     hipLaunchKernelGGL(kern, dim3((unsigned)blk_n), dim3(BLOCK), L.total, stream, d_plan, m, table, w, -1, 0,
                        pix_bytes, handoff, chunk, cp_max, opts, blk_base);
   };
-  if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);
-  else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK>);
-  else go(k_scan<Real, 0, TRACE, MODE, BLOCK>);
+  if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, true>);
+  else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, true>);
+  else go(k_scan<Real, 0, TRACE, MODE, BLOCK, true>);
   return hipGetLastError();
 }
 }  // namespace
 
-template <typename Real>
-hipError_t launch_scan_ragged(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
-                              const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w, int pix_bytes,
-                              int blk_base, int blk_n, hipStream_t stream) {
+// (dialect C, no trace: ragged passes are jdaDetectBatchRagged's; everything else runs image by image)
+template <>
+hipError_t launch_scan_ragged<float>(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
+                                     const DevModelT<float>& m, const S0Node* table, const WorkT<float>& w, int pix_bytes,
+                                     int blk_base, int blk_n, hipStream_t stream) {
+  using Real = float;
   if (blk_n <= 0) return hipSuccess;
-  if (!w.segs || !w.blk) return hipErrorInvalidValue;
-  auto pick = [&](auto trace_tag) {
-    constexpr bool TR = decltype(trace_tag)::value;
-    switch (mode) {
-      case 1:
-        return block == 512 ? launch_scan_ragged_mode<Real, TR, 1, 512>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream)
-                            : launch_scan_ragged_mode<Real, TR, 1, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
-      case 2: return launch_scan_ragged_mode<Real, TR, 2, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
-      case 3: return launch_scan_ragged_mode<Real, TR, 3, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
-      default: return hipErrorInvalidValue;
-    }
-  };
-  return trace ? pick(std::true_type{}) : pick(std::false_type{});
+  if (!w.segs || !w.blk || trace) return hipErrorInvalidValue;
+  switch (mode) {
+    case 1:
+      return block == 512 ? launch_scan_ragged_mode<Real, false, 1, 512>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream)
+                          : launch_scan_ragged_mode<Real, false, 1, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+    case 2: return launch_scan_ragged_mode<Real, false, 2, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+    case 3: return launch_scan_ragged_mode<Real, false, 3, 256>(d_plan, m, table, w, pix_bytes, blk_base, blk_n, handoff, cp_max, opts, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
-
-template hipError_t launch_scan_ragged<float>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<float>&, const S0Node*,
-                                              const WorkT<float>&, int, int, int, hipStream_t);
-template hipError_t launch_scan_ragged<double>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<double>&, const S0Node*,
-                                               const WorkT<double>&, int, int, int, hipStream_t);
+template <>
+hipError_t launch_scan_ragged<double>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<double>&, const S0Node*,
+                                      const WorkT<double>&, int, int, int, hipStream_t) {
+  return hipErrorInvalidValue;
+}
 
 template hipError_t launch_scan<float>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
                                        const S0Node*, const WorkT<float>&, hipStream_t);

@@ -225,6 +225,15 @@ hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th
 // < 0: the largest side that leaves the workgroup within kFinishLdsPerGroup)
 constexpr size_t kFinishLdsPerGroup = 7680;
 
+// The finishing path of small jobs: one WORKGROUP per queued window (k_wide.hip), every remaining cart, stage and the
+// final cut; reads the hand-off queue.  finish_wide_ok: the model fits (single-scale nodes, no similarity transform,
+// a weight row within the LDS row buffer).
+bool finish_wide_ok(int dim, int K, int leaf_n, int real_bytes, bool multi, bool similarity);
+template <typename Real>
+hipError_t launch_finish_wide(bool trace, bool apply_final_th, Real final_th, const DevPlan* d_plan,
+                              const DevModelT<Real>& m, const WorkT<Real>& w, long long n_hint, const S0Node* s0_table,
+                              hipStream_t stream);
+
 // Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
 // pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).
 template <typename Real>

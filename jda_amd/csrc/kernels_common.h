@@ -238,52 +238,97 @@ __device__ __forceinline__ void dma_to_lds(unsigned char* lds_dst, const void* _
   stage_to_lds<unsigned char, BLOCK, 4>(lds_dst + done, g + done, nbytes - done, tid);
 }
 
+// lane-masked move: r = (bit `lane` of m) ? s : mine, one v_cndmask per dword with the mask in an SGPR pair (no compare,
+// no VCC round trip)
+__device__ __forceinline__ float capture_lane(float mine, float s, unsigned long long m) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(mine), "v"(s), "s"(m));
+  return r;
+}
+__device__ __forceinline__ double capture_lane(double mine, double s, unsigned long long m) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(mine)), "v"(__double2loint(s)), "s"(m));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(mine)), "v"(__double2hiint(s)), "s"(m));
+  return __hiloint2double(hi, lo);
+}
+
+// value of the lane below (lane l gets lane l-1's; lane 0 keeps `old`): one DPP move per dword, wave_shr:1
+__device__ __forceinline__ float lane_below(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_below(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // Score recurrence of c/jda.c:395-399 over the carts held by lanes [jbeg, jend)
 // of one 64-cart group, replayed strictly in cart order.  ls/th_k/mean_k/std_k/lf
 // are per-lane values of cart (group base + lane).  Returns the lane of the
 // rejecting cart or -1; score/hash are left as they stood at that cart.
+//
+// A systolic chain over the lanes: p[j] = f_j(p[j-1]) with f_j = "add cart j's leaf score (and normalise, where cart j
+// does)", every lane applying its own f to the value of the lane below (DPP wave_shr:1), lane jbeg pinned to
+// f(score).  After i rounds the lanes up to jbeg + i hold exactly the scores of the scalar loop -- each is computed from
+// its predecessor's final value by the same operations in the same order; the earlier, unfinished values are
+// overwritten.  jend - jbeg - 1 rounds of one DPP add (+ one masked move) instead of a read-lane, an add, a compare
+// and a mask update per cart; then ALL lanes compare at once and the first set bit of the ballot is the rejecting cart.
+// (r02's form cost 84 clocks per cart -- 48 k clocks per 540-cart stage; this one 40, measured with shader-clock
+// stamps: tools/wide_timing.py.  Also measured, slower or equal: a wave-uniform running score fed by v_readlane with a
+// masked move per cart (52-60 clocks), row_shr/row_bcast steps instead of wave_shr (equal).)
 template <typename Real, bool TRACE>
 __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real ls, Real th_k, Real mean_k, Real std_k,
                                              unsigned long long normmask, int lf, int jbeg, int jend) {
-  if (jbeg == 0 && jend == 64 && normmask == 0ull) {
-    // Common case, branch-free: the running score is wave-uniform; after every
-    // add ALL lanes compare it with their own cart's threshold and only bit j
-    // of that ballot is kept.  Same adds in the same order as the scalar loop.
-    Real s = score;
-    unsigned long long rej = 0ull;
-    for (int j0 = 0; j0 < 64 && rej == 0ull; j0 += 16) {      // stop at the 16-cart block that rejects
+  if (jbeg >= jend) return -1;                                        // no cart of this group is still to be scored
+  const int lane = wave_lane();
+  const bool norm = (normmask >> lane) & 1ull;
+  auto f_plain = [&](Real below) { return below + ls; };              // c/jda.c:396
+  auto f_norm = [&](Real below) {                                     // ... and c/jda.c:397 where this lane's cart normalises
+    const Real v = below + ls;
+    const Real n = (v - mean_k) / std_k;
+    return norm ? n : v;
+  };
+  const unsigned long long pin = 1ull << jbeg;
+  const int rounds = jend - jbeg - 1;
+  Real p;
+  if (normmask == 0ull && jbeg == 0 && sizeof(Real) == 4) {
+    // the common case in ONE dependent instruction per cart: v_add_f32_dpp adds the lane's leaf score to the value of
+    // the lane below; lane 0 has no lane below, so the instruction leaves it alone (bound_ctrl off) and it keeps
+    // score + ls.  (s_nop 1: a DPP operand must have been written two wait states earlier.)
+    float pf = (float)f_plain(score);
+    const float lsf = (float)ls;
+    if (rounds == 63) {
 #pragma unroll
-      for (int jj = 0; jj < 16; jj++) {
-        const int j = j0 + jj;
-        s = s + rl(ls, j);                                     // c/jda.c:396
-        rej |= __ballot(s < th_k) & (1ull << j);               // c/jda.c:399
-      }
+      for (int i = 0; i < 63; i++)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pf) : "v"(lsf));
+    } else {
+      for (int i = 0; i < rounds; i++)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(pf) : "v"(lsf));
     }
-    if (rej == 0ull) {
-      if (TRACE) {
-#pragma unroll 8
-        for (int j = 0; j < 64; j++) hash = fnv_step(hash, rl(lf, j));
-      }
-      score = s;
-      return -1;
-    }
-    const int jr = __ffsll((long long)rej) - 1;
-    Real s2 = score;
-    for (int j = 0; j <= jr; j++) {                            // the score as it stood at the rejecting cart
-      s2 = s2 + rl(ls, j);
-      if (TRACE) hash = fnv_step(hash, rl(lf, j));
-    }
-    score = s2;
-    return jr;
+    p = (Real)pf;
+  } else if (normmask == 0ull) {
+    const Real first = f_plain(score);                                // what lane jbeg holds
+    p = first;
+    for (int i = 0; i < rounds; i++) p = capture_lane(f_plain(lane_below(first, p)), first, pin);
+  } else {                                                            // rare: a group with a normalising cart
+    const Real first = f_norm(score);
+    p = first;
+    for (int i = 0; i < rounds; i++) p = capture_lane(f_norm(lane_below(first, p)), first, pin);
   }
-  for (int j = jbeg; j < jend; j++) {
-    Real s = score + rl(ls, j);                                                     // c/jda.c:396
-    if ((normmask >> j) & 1ull) s = (s - rl(mean_k, j)) / rl(std_k, j);             // c/jda.c:397
-    score = s;
-    if (TRACE) hash = fnv_step(hash, rl(lf, j));
-    if (s < rl(th_k, j)) return j;                                                  // c/jda.c:399
+  const unsigned long long rej = __ballot(lane >= jbeg && lane < jend && p < th_k);   // c/jda.c:399
+  if (rej == 0ull) {
+    if (TRACE) {
+      for (int j = jbeg; j < jend; j++) hash = fnv_step(hash, rl(lf, j));
+    }
+    score = rl(p, jend - 1);
+    return -1;
   }
-  return -1;
+  const int jr = __ffsll((long long)rej) - 1;
+  score = rl(p, jr);                                                  // the score as it stood at the rejecting cart
+  if (TRACE) {
+    for (int j = jbeg; j <= jr; j++) hash = fnv_step(hash, rl(lf, j));
+  }
+  return jr;
 }
 
 }  // namespace

@@ -918,6 +918,46 @@ print("OK")
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
 
 
+# ---------------------------------------------------------------- small jobs: workgroup = window
+
+@pytest.mark.parametrize("dims,kw", [((3, 70, 9, 5), dict(cart_th=-0.9, norm_every=9)), ((2, 130, 27, 4), dict(cart_th=-0.6)),
+                                     ((2, 600, 5, 3), dict(cart_th=-1.5, norm_every=50)), ((3, 20, 150, 4), dict(cart_th=-0.8)),
+                                     ((2, 64, 68, 6), dict(cart_th=-0.7))])
+def test_wide_finish_equals_wave_finish_and_the_oracle(built, gpu, model_file, dims, kw):
+    """Small jobs finish with one WORKGROUP per window (k_finish_wide: thread = cart, weight rows through LDS), large
+    ones with one wave per window (k_finish).  Same per-window trace (reject cart, score bits, leaf-path hash, shape
+    bits) from both, equal to the oracle's (c/jda.c:357-426; Validate, cascador.cpp:166-211), in both dialects."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file(dims, 8, seed=91, **kw)
+    frames = synth.make_frames(2, 260, 190, seed=92)
+    o = Oracle(p)
+    wide, wave = api.Cascador(p), api.Cascador(p)
+    wave.set_option("wide_max", 0)
+    assert wide.get_option("wide_max") > 0
+    _compare_trace(wide, o, frames[:1])
+    tw, tv = wide.trace(frames), wave.trace(frames)
+    for k in tw:
+        assert same(tw[k], tv[k]), k
+    (dw, sw), (dv, sv) = wide.detect_batch(frames, stats=True), wave.detect_batch(frames, stats=True)
+    for a, b in zip(dw, dv):
+        _compare_detect(a, b)
+    for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n", "handoff_n"):
+        assert sw[k] == sv[k], k
+    assert list(sw["stage_done_n"]) == list(sv["stage_done_n"])
+    assert sum(len(d["scores"]) for d in dw) > 0
+    # dialect CPP (fp64: the rows go through registers instead of LDS-DMA, the delta is summed from zero)
+    cw, cv = wide.trace_cpp(frames, 20, 5, 1.2), wave.trace_cpp(frames, 20, 5, 1.2)
+    for k in cw:
+        assert same(cw[k], cv[k]), ("cpp", k)
+    r = o.trace_cpp(frames[0], 20, 5, 1.2)
+    for k in ("carts_n", "score", "path_hash", "shapes"):
+        assert same(r[k], cw[k][:len(r[k])]), ("cpp oracle", k)
+    for a, b in zip(wide.detect_batch_cpp(frames), wave.detect_batch_cpp(frames)):
+        for k in ("rects", "scores", "shapes"):
+            assert same(a[k], b[k]), ("cpp", k)
+
+
 # ---------------------------------------------------------------- submit / wait
 
 def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
