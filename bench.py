@@ -500,11 +500,21 @@ def main():
                       "bound": "hbm", "achieved": xalg / xel / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": xalg / xel / 1e9 / HBM_PEAK_GBPS,
                       "algorithmic_bytes_per_window": xalg / max(1, xs["patch_n"]),
-                      "traffic": None, "traffic_source": "profiles/r02_x_allpass.txt (builder-run rocprofv3 --pmc FETCH_SIZE of "
-                                 "tools/x_allpass.py: 2.55e9 KiB per k_finish dispatch), not measured in this run",
+                      "traffic": None, "traffic_source": None,
                       "note": "achieved = SURVEY 8(d) algorithmic bytes (10.2 MB per window: 186 B per cart + K weight rows per stage) "
                               "/ wall time of one jdaDetectBatchDevice call; the 34.8 MB of a stage's weight rows exceed L2 (4 MB per "
                               "XCD) and are served by the Infinity Cache / HBM"}
+            xt = os.path.join(ROOT, "profiles", "x_allpass_traffic.json")
+            if os.path.exists(xt):
+                tj = json.load(open(xt))
+                x_info["traffic"] = tj["traffic_line_bytes"]
+                x_info["traffic_over_algorithmic"] = tj["traffic_line_bytes"] / tj["algorithmic_bytes"]
+                x_info["traffic_GBps_in_profiled_run"] = tj["traffic_line_bytes"] / tj["duration_s"] / 1e9
+                x_info["traffic_useful_equivalent"] = tj["traffic_useful_equivalent_bytes"]
+                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json + profiles/r03_x_allpass.txt -- builder-run, NOT measured in this run: "
+                                            "fabric read requests of the k_finish dispatch x 128 B (= FETCH_SIZE x 2), FETCH_SIZE calibrated on a gather of "
+                                            "544-byte rows of known size (0.65 counted bytes per useful byte); Infinity-Cache hits are included, no counter "
+                                            "separates them from HBM reads")
         except Exception as e:
             x_info = {"error": repr(e)}
 
