@@ -47,7 +47,10 @@ JDA_API int jdaGatherResults(void *dist, const jdaResult *results, int n, int fr
  * communicator's own stream); Collect finishes the OLDEST started gather (at most two may be in
  * flight) and returns its rows like jdaDistGatherRows.  A rank with more than block_rows rows makes
  * every rank fall back to the exact two-step exchange for that gather (the counts are gathered, so
- * all ranks agree). */
+ * all ranks agree).  That fallback queues further collectives inside Collect, so -- as for any collective --
+ * EVERY rank must call Start and Collect (and jdaDistGatherRows / jdaGatherResults) the same number of times in
+ * the same order; a rank that skips or reorders a call hangs the others.  Counts travel as fp32 (exact up to
+ * 2^24 rows per rank and step). */
 JDA_API int jdaDistGatherStart(void *dist, const float *rows, int n_rows);
 JDA_API int jdaDistGatherCollect(void *dist, float **all_rows, int *n_all);
 JDA_API int jdaDistPending(void *dist);

@@ -102,7 +102,8 @@ static long long env_ll(const char* name, long long dflt) {
   X(host_chunk, "JDA_HOST_CHUNK", 128)      /* frames per sub-batch when the frames come from host memory */ \
   X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
-  X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */
+  X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */ \
+  X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */
 
 struct Knobs {
 #define X(name, env, dflt) long long name = (dflt);
@@ -575,11 +576,9 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
       const int pw = s.win + (tw - 1) * s.step, ph = s.win + (th - 1) * s.step;
       int xs = 0;
       if (ragged) {
-        // images of any width share the tile shape: the worst lead-in of a tile origin x0 = tx * tw * step over ALL
-        // tx, i.e. the largest multiple of gcd(tw * step, 16) below 16
-        int g = (tw * s.step) & 15, h = 16;
-        while (g) { const int t = h % g; h = g; g = t; }
-        xs = ((tw * s.step) & 15) ? 16 - h : 0;
+        // images of any width share the tile's LDS pitch: the worst lead-in of a tile origin x0 = tx * tw * step
+        // (and an image may re-cut the tile narrower, ragged_tile: any lead-in below 16 can occur)
+        xs = 15;
       } else {
         for (int tx = 0; tx < tiles_x; tx++) xs = std::max(xs, (tx * tw * s.step) & 15);
       }
@@ -1921,6 +1920,24 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
   return 0;
 }
 
+// The level's tile re-cut for an image's own grid of nx x ny windows: as few tiles per row as the level's widest tile
+// allows, evenly wide; the slack of a narrower tile goes into its height (up to 512 windows and the LDS the level's
+// launch may use), again evenly.  An FDDB-sized image (77 x 64 windows of 46 pixels) gets 2 x 5 tiles of 39 x 13 windows
+// (99 % of a 512-lane first phase) instead of 2 x 7 of 50 x 10 (60 %).
+static void ragged_tile(const DevLevel& d, int nx, int ny, int th_lds, int* tw, int* th) {
+  if (d.tiled == 2) { *tw = d.tw; *th = d.th; return; }            // global-pixel "tiles" are only window groups
+  const int tx = (nx + d.tw - 1) / d.tw;
+  *tw = (nx + tx - 1) / tx;
+  const int cap = std::max(1, std::min(th_lds, 512 / *tw));
+  const int ty = (ny + cap - 1) / cap;
+  *th = (ny + ty - 1) / ty;
+}
+// rows of windows a tile of level d may hold within lds_budget bytes of pixels
+static int ragged_th_lds(const DevLevel& d, int pix_budget) {
+  const int rows = pix_budget / std::max(1, d.pitch);
+  return std::max(d.th, (rows - d.win) / std::max(1, d.step) + 1);
+}
+
 // Tables of images [i0, i0 + n) into the lane's pinned table buffer (and, for host images that do not lie back to
 // back, the images into the lane's pinned staging buffer).
 static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
@@ -1931,6 +1948,23 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   ch->host_imgs = job.host_imgs ? job.host_imgs + i0 : nullptr;
   ch->d_raw = job.d_base;
   // ---- counts ----
+  // How far a re-cut tile's pixels may outgrow the level's nominal tile (taller, narrower tiles for narrow images): as
+  // far as the workgroups per CU stay what the nominal tile allows -- measured, a flat 1.4x took the 71/88-pixel levels
+  // from 2 workgroups per CU to 1 and cost more than the fuller first phase gained.
+  int th_lds[kMaxLevels];
+  {
+    const HostModel& hm = c->hm;
+    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), 4));
+    for (int l = 0; l < nl; l++) {
+      const DevLevel& d = hp.lv[l];
+      if (d.tiled == 2) { th_lds[l] = d.th; continue; }
+      const int nominal = d.pitch * (d.win + (d.th - 1) * d.step);
+      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), 4, false, d.tw * d.th > 256 ? 512 : 256);
+      const int per_cu = std::max(1, (160 * 1024) / (fixed + nominal));
+      const int room = (160 * 1024) / per_cu - fixed - 64;
+      th_lds[l] = ragged_th_lds(d, std::max(nominal, std::min(room, nominal * (int)c->kn.ragged_tile_grow_pct / 100)));
+    }
+  }
   int n_segs = 0;
   long long n_blk = 0;
   for (int i = 0; i < n; i++) {
@@ -1939,7 +1973,9 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     for (int l = 0; l < job.n_lv[i0 + i]; l++) {
       const DevLevel& d = hp.lv[l];
       const int nx = (W - d.win) / d.step + 1, ny = (H - d.win) / d.step + 1;
-      n_blk += (long long)((nx + d.tw - 1) / d.tw) * ((ny + d.th - 1) / d.th);
+      int tw, th;
+      ragged_tile(d, nx, ny, th_lds[l], &tw, &th);
+      n_blk += (long long)((nx + tw - 1) / tw) * ((ny + th - 1) / th);
     }
   }
   if (n_blk > 0x7fffffffLL) { fail("ragged chunk has too many tiles"); return false; }
@@ -1984,8 +2020,11 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
       RagSeg& sg = segs[si++];
       sg.img_off = img_off[i]; sg.gid_base = (uint32_t)gid;
       sg.nx = (uint16_t)((W - d.win) / d.step + 1); sg.ny = (uint16_t)((H - d.win) / d.step + 1);
-      sg.tiles_x = (uint16_t)((sg.nx + d.tw - 1) / d.tw);
-      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = sg.pad2 = 0;
+      int tw, th;
+      ragged_tile(d, sg.nx, sg.ny, th_lds[l], &tw, &th);
+      sg.tw = (uint16_t)tw; sg.th = (uint16_t)th;
+      sg.tiles_x = (uint16_t)((sg.nx + tw - 1) / tw);
+      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = 0;
       gid += (long long)sg.nx * sg.ny;
     }
   }
@@ -2018,7 +2057,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
         tiles[i - g0] = 0; seg[i - g0] = -1;
         if (l < job.n_lv[i0 + i]) {
           const RagSeg& sg = segs[seg_first[i] + l];
-          tiles[i - g0] = (int)sg.tiles_x * ((sg.ny + d.th - 1) / d.th);
+          tiles[i - g0] = (int)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
           seg[i - g0] = seg_first[i] + l;
           most = std::max(most, tiles[i - g0]);
         }
@@ -2028,11 +2067,17 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
           if (t < tiles[j]) { blk[bi].seg = (uint32_t)seg[j]; blk[bi].tile = (uint32_t)t; bi++; }
     }
   };
-  auto pix_of = [&](int l) { const DevLevel& d = hp.lv[l]; return d.pitch * (d.win + (d.th - 1) * d.step); };
+  // pixel bytes / windows of the largest tile any image of the chunk cut from level l
+  int th_max[kMaxLevels], win_max[kMaxLevels];
+  for (int l = 0; l < nl; l++) { th_max[l] = 1; win_max[l] = 1; }
   long long lds_blocks = 0;
   for (int i = 0; i < n; i++)
-    for (int l = 0; l < job.n_lv[i0 + i]; l++)
-      if (hp.lv[l].tiled == 1) { const RagSeg& sg = segs[seg_first[i] + l]; lds_blocks += (long long)sg.tiles_x * ((sg.ny + hp.lv[l].th - 1) / hp.lv[l].th); }
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const RagSeg& sg = segs[seg_first[i] + l];
+      th_max[l] = std::max<int>(th_max[l], sg.th); win_max[l] = std::max<int>(win_max[l], (int)sg.tw * sg.th);
+      if (hp.lv[l].tiled == 1) lds_blocks += (long long)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
+    }
+  auto pix_of = [&](int l) { const DevLevel& d = hp.lv[l]; return d.pitch * (d.win + (th_max[l] - 1) * d.step); };
   const bool small = lds_blocks <= c->kn.merge_blocks;
   auto merged = [&](int mode) {
     RaggedChunk::Launch L{mode, 256, 0, bi, 0};
@@ -2044,7 +2089,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   else
     for (int l = 0; l < nl; l++)
       if (hp.lv[l].tiled == 1) {
-        RaggedChunk::Launch L{1, hp.lv[l].tw * hp.lv[l].th > 256 ? 512 : 256, pix_of(l), bi, 0};
+        RaggedChunk::Launch L{1, win_max[l] > 256 ? 512 : 256, pix_of(l), bi, 0};
         emit_level(l);
         L.blk_n = bi - L.blk_base;
         if (L.blk_n > 0) ch->launches.push_back(L);

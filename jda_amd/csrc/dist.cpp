@@ -40,7 +40,20 @@ struct Dist {
   Slot slot[2];
   int head = 0, tail = 0;          // ring of started gathers: collect at tail, start at head
   int* d_counts = nullptr; int* h_counts = nullptr;     // exact path
+  float* d_send = nullptr; float* d_recv = nullptr;     // ... its grow-only row buffers
+  size_t send_cap = 0, recv_cap = 0;
 };
+
+// grow-only device buffer of the exact path (no hipMalloc / hipFree -- device-wide synchronisations -- per gather)
+int reserve_dev(float** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = bytes + bytes / 2;
+  D_HIP(hipMalloc((void**)p, want));
+  *cap = want;
+  return 0;
+}
 
 int gather_exact(Dist* d, const float* rows, int n_rows, float** all_rows, int* n_all) {
   *all_rows = nullptr; *n_all = 0;
@@ -55,38 +68,44 @@ int gather_exact(Dist* d, const float* rows, int n_rows, float** all_rows, int* 
   D_HIP(hipStreamSynchronize(d->stream));
   long long total = 0;
   for (int r = 0; r < d->world; r++) total += h[r];
-  // rows: grouped ncclSend -> 0 / ncclRecv x (world - 1)
-  float* d_send = nullptr; float* d_recv = nullptr;
+  // rows: grouped ncclSend -> 0 / ncclRecv x (world - 1), through the handle's grow-only buffers.  Everything that can
+  // fail locally (allocations, the copy of this rank's rows) happens BEFORE the group is opened; inside it every
+  // call is attempted and the group is always closed, so a failing rank does not leave an open group behind (the
+  // next collective would hang on it).
   if (n_rows > 0 && d->rank != 0) {
-    D_HIP(hipMalloc((void**)&d_send, (size_t)n_rows * rowb));
-    D_HIP(hipMemcpyAsync(d_send, rows, (size_t)n_rows * rowb, hipMemcpyHostToDevice, d->stream));
+    if (reserve_dev(&d->d_send, &d->send_cap, (size_t)n_rows * rowb) != 0) return -1;
+    D_HIP(hipMemcpyAsync(d->d_send, rows, (size_t)n_rows * rowb, hipMemcpyHostToDevice, d->stream));
   }
-  if (d->rank == 0 && total > 0) D_HIP(hipMalloc((void**)&d_recv, (size_t)total * rowb));
-  D_NCCL(ncclGroupStart());
+  if (d->rank == 0 && total > h[0] && reserve_dev(&d->d_recv, &d->recv_cap, (size_t)total * rowb) != 0) return -1;
+  float* out = nullptr;
+  if (d->rank == 0) {
+    out = (float*)std::malloc(std::max<size_t>(1, (size_t)total * rowb));
+    if (!out) { fail("out of memory"); return -1; }
+  }
+  ncclResult_t bad = ncclSuccess;
+  auto keep = [&](ncclResult_t r) { if (r != ncclSuccess && bad == ncclSuccess) bad = r; };
+  keep(ncclGroupStart());
   if (d->rank == 0) {
     long long off = h[0];
     for (int r = 1; r < d->world; r++) {
-      if (h[r] > 0) D_NCCL(ncclRecv(d_recv + off * d->row_floats, (size_t)h[r] * d->row_floats, ncclFloat, r, d->comm, d->stream));
+      if (h[r] > 0) keep(ncclRecv(d->d_recv + off * d->row_floats, (size_t)h[r] * d->row_floats, ncclFloat, r, d->comm, d->stream));
       off += h[r];
     }
   } else if (n_rows > 0) {
-    D_NCCL(ncclSend(d_send, (size_t)n_rows * d->row_floats, ncclFloat, 0, d->comm, d->stream));
+    keep(ncclSend(d->d_send, (size_t)n_rows * d->row_floats, ncclFloat, 0, d->comm, d->stream));
   }
-  D_NCCL(ncclGroupEnd());
+  keep(ncclGroupEnd());
+  if (bad != ncclSuccess) { std::free(out); fail(std::string("RCCL exact gather: ") + ncclGetErrorString(bad)); return -1; }
+  hipError_t e = hipSuccess;
   if (d->rank == 0) {
-    float* out = (float*)std::malloc(std::max<size_t>(1, (size_t)total * rowb));
-    if (!out) { fail("out of memory"); return -1; }
     if (h[0] > 0) std::memcpy(out, rows, (size_t)h[0] * rowb);                       // rank 0's own rows never leave the host
     if (total > h[0])
-      D_HIP(hipMemcpyAsync(out + (size_t)h[0] * d->row_floats, d_recv + (size_t)h[0] * d->row_floats,
-                           (size_t)(total - h[0]) * rowb, hipMemcpyDeviceToHost, d->stream));
-    D_HIP(hipStreamSynchronize(d->stream));
-    *all_rows = out; *n_all = (int)total;
-  } else {
-    D_HIP(hipStreamSynchronize(d->stream));
+      e = hipMemcpyAsync(out + (size_t)h[0] * d->row_floats, d->d_recv + (size_t)h[0] * d->row_floats,
+                         (size_t)(total - h[0]) * rowb, hipMemcpyDeviceToHost, d->stream);
   }
-  if (d_send) (void)hipFree(d_send);
-  if (d_recv) (void)hipFree(d_recv);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+  if (e != hipSuccess) { std::free(out); fail(std::string("exact gather: ") + hipGetErrorString(e)); return -1; }
+  if (d->rank == 0) { *all_rows = out; *n_all = (int)total; }
   return 0;
 }
 
@@ -144,6 +163,8 @@ void jdaDistDestroy(void* dist) {
     if (s.done) (void)hipEventDestroy(s.done);
   }
   if (d->d_counts) (void)hipFree(d->d_counts);
+  if (d->d_send) (void)hipFree(d->d_send);
+  if (d->d_recv) (void)hipFree(d->d_recv);
   if (d->h_counts) (void)hipHostFree(d->h_counts);
   if (d->comm) (void)ncclCommDestroy(d->comm);
   if (d->stream) (void)hipStreamDestroy(d->stream);

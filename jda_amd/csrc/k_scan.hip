@@ -156,6 +156,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
     const RagBlk bs = w.blk[blk_base + blockIdx.x];
     const RagSeg g = w.segs[uni(bs.seg)];
     sg.nx = (uint16_t)uni(g.nx); sg.ny = (uint16_t)uni(g.ny); sg.tiles_x = (uint16_t)uni(g.tiles_x);
+    sg.tw = (uint16_t)uni(g.tw); sg.th = (uint16_t)uni(g.th);
     level_ = (int)uni(g.level);
     frame_ = (int)uni(g.image); trel_ = (int)uni(bs.tile); gid0_ = (int)uni(g.gid_base);
     img_off_ = (unsigned long long)uni((unsigned)(g.img_off & 0xffffffffu)) | ((unsigned long long)uni((unsigned)(g.img_off >> 32)) << 32);
@@ -181,7 +182,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   }
   level = level_;
   DevLevel lv_ = plan->lv[level];
-  if constexpr (RAGGED) { lv_.nx = sg.nx; lv_.ny = sg.ny; lv_.tiles_x = sg.tiles_x; }
+  if constexpr (RAGGED) { lv_.nx = sg.nx; lv_.ny = sg.ny; lv_.tiles_x = sg.tiles_x; lv_.tw = sg.tw; lv_.th = sg.th; }
   const DevLevel lv = lv_;
   const int frame = frame_, trel = trel_;
   const int gid0 = RAGGED ? gid0_ : frame * plan->windows + lv.base;

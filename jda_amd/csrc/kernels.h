@@ -53,7 +53,10 @@ struct RagSeg {
   uint16_t tiles_x;             // tiles per row of windows
   uint16_t level;               // index into DevPlan::lv
   uint16_t image;               // image index inside the pass (the queues pack it in 16 bits)
-  uint16_t pad0; uint32_t pad1, pad2;
+  uint16_t tw, th;              // windows per tile in x / y for THIS image: the level's tile (DevLevel::tw x th) re-cut to
+                                // the image's own grid, inside the level's LDS row pitch (the node offsets depend on
+                                // the pitch only)
+  uint16_t pad0; uint32_t pad1;
 };
 static_assert(sizeof(RagSeg) == 32, "RagSeg is read as two 16-byte words");
 struct RagBlk { uint32_t seg, tile; };
