@@ -401,6 +401,12 @@ def main():
         casc.close()
         return windows_step * steps / el
 
+    host_info = None
+    if world == 1:
+        hs = max(2, min(30, args.steps))
+        host_info = {"pageable_windows_per_s": host_leg(False, hs), "pinned_windows_per_s": host_leg(True, hs), "steps": hs,
+                     "entry": "jdaDetectBatchSubmitHost / jdaDetectBatchWait, three tickets (two batches submitted ahead)"}
+
     # ---- BASELINE.json configs[3] / the metric's "FDDB images/sec": an FDDB-shaped job (2,845 images <= 450x450 of
     #      varied aspect, the reference's one-Detect-per-image loop, src/test.cpp:100-170) as ONE ragged job
     #      (jdaDetectBatchRaggedDevice), images resident in HBM, sharded over the ranks in contiguous blocks,
@@ -467,12 +473,6 @@ def main():
         if world > 1:
             raise
         fddb_info = {"error": repr(e)}
-
-    host_info = None
-    if world == 1:
-        hs = max(2, min(30, args.steps))
-        host_info = {"pageable_windows_per_s": host_leg(False, hs), "pinned_windows_per_s": host_leg(True, hs), "steps": hs,
-                     "entry": "jdaDetectBatchSubmitHost / jdaDetectBatchWait, three tickets (two batches submitted ahead)"}
 
     # ---- the regime of this path in which HBM / Infinity Cache traffic is the bound: BASELINE.json configs[4] (T=7, K=2000,
     #      68 landmarks, depth 6: W = 243.7 MB, 34.8 MB per stage) with every window of a 1080p frame walking all 14,000

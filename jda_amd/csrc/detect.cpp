@@ -1468,13 +1468,23 @@ class PostPool {
   // A batch call announces its post-processing job ahead of time (when it starts its GPU work):
   // the workers wake up now and spin until the job arrives or `ms` have passed.
   void prewake(int n, double ms) {
-    if (ms <= 0 || n < 64 || workers_.empty()) return;     // off by default: measured neutral to slightly negative
+    if (ms <= 0 || n < 64 || !ready_.load(std::memory_order_acquire)) return;     // off by default: measured neutral to slightly negative
     { std::lock_guard<std::mutex> lk(mu_); armed_until_.store(now_ms() + ms); }
     cv_.notify_all();
   }
   // heavy: the items are expensive (many detections per frame), worth spreading even a few of them
   void run(int n, const std::function<void(int)>& fn, bool heavy) {
-    const bool use = workers_.empty() ? false : (heavy ? n >= 2 : n >= 64);
+    // a heavy job (thousands of detections: the per-frame NMS is quadratic) starts the workers if nobody did
+    if (heavy && n >= 2 && auto_ && !ready_.load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> lk(spawn_mu_);
+      if (!ready_.load(std::memory_order_acquire)) {
+        const unsigned hwc = std::thread::hardware_concurrency();
+        const int nw = (int)std::min<unsigned>(6, hwc > 2 ? hwc / 2 : 0);
+        for (int i = 0; i < nw; i++) workers_.emplace_back([this]() { loop(); });
+        if (nw > 0) ready_.store(true, std::memory_order_release); else auto_ = false;
+      }
+    }
+    const bool use = !ready_.load(std::memory_order_acquire) ? false : (heavy ? n >= 2 : n >= 64);
     if (!use || !job_mu_.try_lock()) { for (int i = 0; i < n; i++) fn(i); return; }
     auto job = std::make_shared<Job>();
     job->chunk = heavy ? 1 : 8;
@@ -1504,10 +1514,14 @@ class PostPool {
     // Off by default: typically 0.22 -> 0.08 ms per 256-frame batch with 6 workers, but 1 run in ~50 on the
     // shared GPU boxes had a worker descheduled in mid-chunk (a multi-millisecond stall of the whole call);
     // the serial path is deterministic.  Opt in with JDA_POST_THREADS=6 on a quiet host.
-    const long long want = env_ll("JDA_POST_THREADS", 0);
+    // JDA_POST_THREADS: -1 (default) = workers only for heavy jobs, started by the first one; 0 = never; n = n workers
+    // from the start, for light jobs too (see above)
+    const long long want = env_ll("JDA_POST_THREADS", -1);
+    auto_ = want < 0;
     const unsigned hwc = std::thread::hardware_concurrency();
     const int nw = (int)std::max<long long>(0, std::min<long long>(want, hwc > 1 ? hwc - 1 : 0));
     for (int i = 0; i < nw; i++) workers_.emplace_back([this]() { loop(); });
+    ready_.store(nw > 0);
   }
   ~PostPool() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -1537,7 +1551,9 @@ class PostPool {
       if (job) work(*job);        // a finished job hands out no chunk, so its fn is never called late
     }
   }
-  std::mutex mu_, job_mu_;
+  std::mutex mu_, job_mu_, spawn_mu_;
+  bool auto_ = false;
+  std::atomic<bool> ready_{false};        // workers exist
   std::condition_variable cv_;
   std::shared_ptr<Job> job_;
   std::atomic<unsigned long long> gen_{0};
@@ -1617,7 +1633,7 @@ static double post_c(Cascador* c, const ScanPlan& sp, const RawDets<float>& dets
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
-  }, dets.gid.size() < 20000);
+  }, dets.gid.size() < 6000);
   return now_ms() - t0;
 }
 
@@ -2153,7 +2169,7 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
-  }, dets.gid.size() < 20000);
+  }, dets.gid.size() < 6000);
   return now_ms() - t0;
 }
 
@@ -2715,7 +2731,7 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
       std::memcpy(sh, &shape_pool[cs[k].shape_at], dim * sizeof(double));
       relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
     }
-  }, total < 20000);
+  }, total < 6000);
   fill_stats(stats, rs_total, patch_total, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
 }
@@ -2860,7 +2876,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(double));
       relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
     }
-  }, dets.gid.size() < 20000);
+  }, dets.gid.size() < 6000);
   fill_stats(stats, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
 }
