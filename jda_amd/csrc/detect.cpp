@@ -581,6 +581,8 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
         xs = 15;
       } else {
         for (int tx = 0; tx < tiles_x; tx++) xs = std::max(xs, (tx * tw * s.step) & 15);
+        static const long long force_xs = env_ll("JDA_TILE_XS", -1);     // (experiment: the ragged chooser's worst-case lead-in)
+        if (force_xs >= 0) xs = (int)force_xs;
       }
       int pitch = (xs + pw + 15) & ~15;
       if ((pitch & 127) == 0) pitch += 16;          // keep tile rows off a 32-bank multiple
@@ -1920,8 +1922,9 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
   for (int l = 0; l < nl; l++) {
     Level& lv = job->levels.levels[l];
     // quantised, so that jobs over similar image sets share a plan
-    const int qx = cnt[l] ? std::max(1, (int)(sx[l] / (double)cnt[l] / 4.0 + 0.5) * 4) : 1;
-    const int qy = cnt[l] ? std::max(1, (int)(sy[l] / (double)cnt[l] / 4.0 + 0.5) * 4) : 1;
+    // (rounded UP: a nominal grid one window narrower than the images' cuts every row of tiles in two)
+    const int qx = cnt[l] ? std::max(1, (int)std::ceil(sx[l] / (double)cnt[l] / 4.0) * 4) : 1;
+    const int qy = cnt[l] ? std::max(1, (int)std::ceil(sy[l] / (double)cnt[l] / 4.0) * 4) : 1;
     lv.nx = qx; lv.ny = qy; lv.base = 0;
     h = (h ^ (unsigned long long)(qx * 65536 + qy)) * 1099511628211ull;
   }
@@ -1941,7 +1944,7 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
 // launch may use), again evenly.  An FDDB-sized image (77 x 64 windows of 46 pixels) gets 2 x 5 tiles of 39 x 13 windows
 // (99 % of a 512-lane first phase) instead of 2 x 7 of 50 x 10 (60 %).
 static void ragged_tile(const DevLevel& d, int nx, int ny, int th_lds, int* tw, int* th) {
-  if (d.tiled == 2) { *tw = d.tw; *th = d.th; return; }            // global-pixel "tiles" are only window groups
+  if (d.tiled == 2) th_lds = 512;                                  // global-pixel "tiles" are only window groups: no LDS limit
   const int tx = (nx + d.tw - 1) / d.tw;
   *tw = (nx + tx - 1) / tx;
   const int cap = std::max(1, std::min(th_lds, 512 / *tw));
@@ -2041,6 +2044,8 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
       sg.tw = (uint16_t)tw; sg.th = (uint16_t)th;
       sg.tiles_x = (uint16_t)((sg.nx + tw - 1) / tw);
       sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = 0;
+      sg.win = d.win; sg.step = d.step; sg.pitch = d.pitch; sg.s0_table = d.s0_table; sg.tiled = d.tiled;
+      sg.pad2 = sg.pad3 = sg.pad4 = 0;
       gid += (long long)sg.nx * sg.ny;
     }
   }
@@ -2064,9 +2069,8 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   //      so that an image's tiles mostly land on one XCD's L2 (block b -> XCD b % 8). ----
   ch->launches.clear();
   int bi = 0;
-  auto emit_level = [&](int l) {
-    const DevLevel& d = hp.lv[l];
-    for (int g0 = 0; g0 < n; g0 += 8) {
+  auto emit_group = [&](int l, int g0) {
+    {
       int tiles[8], seg[8], most = 0;
       const int ge = std::min(n, g0 + 8);
       for (int i = g0; i < ge; i++) {
@@ -2083,6 +2087,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
           if (t < tiles[j]) { blk[bi].seg = (uint32_t)seg[j]; blk[bi].tile = (uint32_t)t; bi++; }
     }
   };
+  auto emit_level = [&](int l) { for (int g0 = 0; g0 < n; g0 += 8) emit_group(l, g0); };
   // pixel bytes / windows of the largest tile any image of the chunk cut from level l
   int th_max[kMaxLevels], win_max[kMaxLevels];
   for (int l = 0; l < nl; l++) { th_max[l] = 1; win_max[l] = 1; }
@@ -2097,7 +2102,11 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   const bool small = lds_blocks <= c->kn.merge_blocks;
   auto merged = [&](int mode) {
     RaggedChunk::Launch L{mode, 256, 0, bi, 0};
-    for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode) { emit_level(l); if (mode != 2) L.pix_bytes = std::max(L.pix_bytes, pix_of(l)); }
+    // (group-major: the eight images of a group go through every level of the launch before the next group starts, so
+    // that they stay in L2 from level to level -- level-major order cost the global-pixel launch 47 %)
+    for (int g0 = 0; g0 < n; g0 += 8)
+      for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode) emit_group(l, g0);
+    for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode && mode != 2) L.pix_bytes = std::max(L.pix_bytes, pix_of(l));
     L.blk_n = bi - L.blk_base;
     if (L.blk_n > 0) ch->launches.push_back(L);
   };

@@ -97,6 +97,47 @@ __device__ __forceinline__ int scan_tree(const S0Node* __restrict__ tbl, const u
   return node;
 }
 
+// N trees in lockstep, written level-major: the N node records of a level first, then the 2N pixels, then the N
+// compares.  scan_tree called N times leaves the interleaving of the N independent chains to the instruction
+// scheduler, which does it for the uniform-batch instantiation and -- two VGPRs of pressure later -- walks the trees
+// one after the other in the RAGGED one (every LDS read followed by lgkmcnt(0): phases 30-60 % slower, stamps and ISA
+// in profiles/r03_ragged_scan.txt).  Same reads, same compares.
+template <int DEPTH, bool WIDE, int N>
+__device__ __forceinline__ void scan_trees(const S0Node* __restrict__ t_nodes, int k, int node_n,
+                                           const uint8_t* __restrict__ pix, int base, int depth_rt, int* lf,
+                                           int kstride = 1, int kmax = 0x7fffffff) {
+  int node[N];
+#pragma unroll
+  for (int u = 0; u < N; u++) node[u] = 0;
+  const int levels = DEPTH > 0 ? DEPTH - 1 : depth_rt - 1;
+#pragma unroll
+  for (int d = 0; d < levels; d++) {
+    S0Node r[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) r[u] = t_nodes[min(k + u * kstride, kmax) * node_n + node[u]];
+    int a[N], b[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+      if (!WIDE) {
+        a[u] = pix[base + (int)(r[u].lo & 0xffffu)];
+        b[u] = pix[base + (int)(r[u].lo >> 16)];
+      } else {
+        const uint32_t o1 = r[u].lo & 0x1fffffu;
+        const uint32_t o2 = __builtin_amdgcn_alignbit(r[u].hi, r[u].lo, 21) & 0x1fffffu;
+        a[u] = pix[base + (int)o1];
+        b[u] = pix[base + (int)o2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+      const bool left = WIDE ? (a[u] - b[u] + 256 <= (int)(r[u].hi >> 10)) : (a[u] - b[u] <= (int)r[u].hi);
+      node[u] = 2 * node[u] + (left ? 1 : 2);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) lf[u] = node[u] - node_n;
+}
+
 }  // namespace
 
 // Registers: three 512-thread workgroups per CU are 6 waves per SIMD, which 80 VGPRs still allow and 82 do not (a
@@ -157,6 +198,8 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
     const RagSeg g = w.segs[uni(bs.seg)];
     sg.nx = (uint16_t)uni(g.nx); sg.ny = (uint16_t)uni(g.ny); sg.tiles_x = (uint16_t)uni(g.tiles_x);
     sg.tw = (uint16_t)uni(g.tw); sg.th = (uint16_t)uni(g.th);
+    sg.win = (int)uni((unsigned)g.win); sg.step = (int)uni((unsigned)g.step); sg.pitch = (int)uni((unsigned)g.pitch);
+    sg.s0_table = (int)uni((unsigned)g.s0_table); sg.tiled = (int)uni((unsigned)g.tiled);
     level_ = (int)uni(g.level);
     frame_ = (int)uni(g.image); trel_ = (int)uni(bs.tile); gid0_ = (int)uni(g.gid_base);
     img_off_ = (unsigned long long)uni((unsigned)(g.img_off & 0xffffffffu)) | ((unsigned long long)uni((unsigned)(g.img_off >> 32)) << 32);
@@ -181,8 +224,14 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
     }
   }
   level = level_;
-  DevLevel lv_ = plan->lv[level];
-  if constexpr (RAGGED) { lv_.nx = sg.nx; lv_.ny = sg.ny; lv_.tiles_x = sg.tiles_x; lv_.tw = sg.tw; lv_.th = sg.th; }
+  DevLevel lv_;
+  if constexpr (RAGGED) {
+    lv_.win = sg.win; lv_.step = sg.step; lv_.pitch = sg.pitch; lv_.s0_table = sg.s0_table; lv_.tiled = sg.tiled;
+    lv_.nx = sg.nx; lv_.ny = sg.ny; lv_.tiles_x = sg.tiles_x; lv_.tw = sg.tw; lv_.th = sg.th;
+    lv_.base = 0; lv_.tiles_y = 0;
+  } else {
+    lv_ = plan->lv[level];
+  }
   const DevLevel lv = lv_;
   const int frame = frame_, trel = trel_;
   const int gid0 = RAGGED ? gid0_ : frame * plan->windows + lv.base;
@@ -257,6 +306,11 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
     // Phases: carts [0,8) [8,16) [16,32) [32,64) [64,128) [128,256) ... (cut at chunk ends); after each
     // the survivors are compacted so that later phases run on full waves.
     for (int c0 = kb; c0 < ke && n_items > 0;) {
+      // No scalar-memory load may be pending when the walk loops start: LDS reads return in order and are waited for
+      // one by one (lgkmcnt(n)), but a scalar load shares that counter and returns out of order -- with one possibly
+      // in flight the compiler falls back to lgkmcnt(0) after EVERY LDS read of the hot loop (seen in the RAGGED
+      // instantiation: 50 x lgkmcnt(0) instead of lgkmcnt(1..4), phases 30-60 % slower).
+      __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0), vmcnt / expcnt untouched
       const bool cart_parallel = queued && n_items <= cp_max && leaf_n <= 256;
       int plen = c0 < first_phase ? first_phase - c0 : min(c0, c0 >= 128 ? 128 : 64);
       if (cart_parallel && plen < 16) plen = 16;
@@ -324,8 +378,12 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
               if (__ballot(alive) == 0ull) break;
               if (alive) {
                 int lf[8];
+                if constexpr (RAGGED) {
+                  scan_trees<DEPTH, WIDE, 8>(t_nodes, k, node_n, pix, base, m.D, lf);
+                } else {
 #pragma unroll
-                for (int u = 0; u < 8; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+                  for (int u = 0; u < 8; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+                }
                 apply(std::integral_constant<int, 8>{}, k, lf, alive, score, hash, gid);
               }
             }
@@ -334,8 +392,12 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
             if (__ballot(alive) == 0ull) break;
             if (alive) {
               int lf[4];
+              if constexpr (RAGGED) {
+                scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf);
+              } else {
 #pragma unroll
-              for (int u = 0; u < 4; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+                for (int u = 0; u < 4; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+              }
               apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
             }
           }
@@ -394,9 +456,13 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
           if (has_item) {
             if (ka + 7 * cstride < r1) {
               int lf8[8];
+              if constexpr (RAGGED) {
+                scan_trees<DEPTH, WIDE, 8>(t_nodes, ka, node_n, pix, base, m.D, lf8, cstride);
+              } else {
 #pragma unroll
-              for (int u = 0; u < 8; u++)
-                lf8[u] = scan_tree<DEPTH, WIDE>(t_nodes + (ka + u * cstride) * node_n, pix, base, m.D) - node_n;
+                for (int u = 0; u < 8; u++)
+                  lf8[u] = scan_tree<DEPTH, WIDE>(t_nodes + (ka + u * cstride) * node_n, pix, base, m.D) - node_n;
+              }
 #pragma unroll
               for (int u = 0; u < 8; u++) lfbuf[item * rc + (ka + u * cstride - r0)] = (uint8_t)lf8[u];
             } else if (ka + cstride >= r1) {
@@ -404,9 +470,13 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
             } else {
               for (int k = ka; k < r1; k += 4 * cstride) {
                 int lf4[4];
+                if constexpr (RAGGED) {
+                  scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf4, cstride, r1 - 1);
+                } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                  lf4[u] = scan_tree<DEPTH, WIDE>(t_nodes + min(k + u * cstride, r1 - 1) * node_n, pix, base, m.D) - node_n;
+                  for (int u = 0; u < 4; u++)
+                    lf4[u] = scan_tree<DEPTH, WIDE>(t_nodes + min(k + u * cstride, r1 - 1) * node_n, pix, base, m.D) - node_n;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                   if (k + u * cstride < r1) lfbuf[item * rc + (k + u * cstride - r0)] = (uint8_t)lf4[u];

@@ -57,8 +57,11 @@ struct RagSeg {
                                 // the image's own grid, inside the level's LDS row pitch (the node offsets depend on
                                 // the pitch only)
   uint16_t pad0; uint32_t pad1;
+  // the level's own record (copied from DevPlan::lv, so that a workgroup's prologue is blk -> seg and not
+  // blk -> seg -> level: three dependent loads in front of the tile load cost the scan 15 % on identical geometry)
+  int win, step, pitch, s0_table, tiled; uint32_t pad2, pad3, pad4;
 };
-static_assert(sizeof(RagSeg) == 32, "RagSeg is read as two 16-byte words");
+static_assert(sizeof(RagSeg) == 64, "RagSeg is read as four 16-byte words");
 struct RagBlk { uint32_t seg, tile; };
 struct RagImg {                 // k_repack: one image of a ragged batch, tight rows -> common row pitch
   unsigned long long src_off, dst_off;
