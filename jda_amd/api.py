@@ -187,6 +187,20 @@ def nms_cpp(rects, scores, overlap=0.3):
     return picked[:n].copy()
 
 
+def _frame_ptrs(frames):
+    """unsigned char*[n] for the frames of a contiguous [n,h,w] array.  From integer addresses: a ctypes cast per frame
+    costs more than a millisecond per 256-frame batch, which is the order of the whole GPU pass."""
+    n = frames.shape[0]
+    base, stride = frames.ctypes.data, frames.strides[0]
+    arr = (C.c_void_p * max(n, 1))(*[base + i * stride for i in range(n)])
+    return C.cast(arr, C.POINTER(C.POINTER(C.c_ubyte)))
+
+
+def _image_ptrs(images):
+    arr = (C.c_void_p * max(len(images), 1))(*[im.ctypes.data for im in images])
+    return C.cast(arr, C.POINTER(C.POINTER(C.c_ubyte)))
+
+
 def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_ubyte))
 
@@ -291,7 +305,7 @@ class Cascador:
     def detect_batch(self, frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True, stats=False):
         frames = np.ascontiguousarray(frames, np.uint8)
         n, h, w = frames.shape
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         res = (jdaResult * max(n, 1))()
         o, st = self._opts(nms, stats)
         rc = lib.jdaDetectBatch(self.h, ptrs, n, w, h, scale, 0.1, min_size, max_size, th, C.byref(o), res)
@@ -347,7 +361,7 @@ class Cascador:
         """jdaDetectBatchRagged: a list of uint8 [h, w] arrays of different sizes in host memory."""
         images = [np.ascontiguousarray(im, np.uint8) for im in images]
         n = len(images)
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(im) for im in images])
+        ptrs = _image_ptrs(images)
         ws = (C.c_int * max(n, 1))(*[im.shape[1] for im in images])
         hs = (C.c_int * max(n, 1))(*[im.shape[0] for im in images])
         res = (jdaResult * max(n, 1))()
@@ -403,7 +417,7 @@ class Cascador:
         """Submit for frames in host memory (numpy uint8 [n,h,w]; kept alive until wait_batch)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, h, w = frames.shape
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         o, _ = self._opts(nms, False)
         t = lib.jdaDetectBatchSubmitHost(self.h, ptrs, n, w, h, scale, 0.1, min_size, max_size, th, C.byref(o))
         if t < 0:
@@ -455,7 +469,7 @@ class Cascador:
         score = np.zeros(tot, np.float32)
         hsh = np.zeros(tot, np.uint32)
         shapes = np.zeros((tot, self.dim), np.float32)
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         rc = lib.jdaTraceBatch(self.h, ptrs, n, w, h, scale, min_size, max_size,
                                carts.ctypes.data_as(C.POINTER(C.c_int)), score.ctypes.data_as(C.POINTER(C.c_float)),
                                hsh.ctypes.data_as(C.POINTER(C.c_uint)), shapes.ctypes.data_as(C.POINTER(C.c_float)))
@@ -484,7 +498,7 @@ class Cascador:
         if frames.ndim == 2:
             frames = frames[None]
         n, h, w = frames.shape
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         res = (jdaResultD * max(n, 1))()
         st = jdaStats()
         rc = lib.jdaDetectBatchCpp(self.h, ptrs, n, w, h, minimum_size, step, factor, overlap, 1 if nms else 0,
@@ -500,7 +514,7 @@ class Cascador:
         if frames.ndim == 2:
             frames = frames[None]
         n, h, w = frames.shape
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         res = (jdaResultD * max(n, 1))()
         st = jdaStats()
         rc = lib.jdaDetectBatchCppPyramid(self.h, ptrs, n, w, h, origin_size, step, factor, overlap, 1 if nms else 0,
@@ -530,7 +544,7 @@ class Cascador:
         score = np.zeros(tot, np.float64)
         hsh = np.zeros(tot, np.uint32)
         shapes = np.zeros((tot, self.dim), np.float64)
-        ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[_u8(frames[i]) for i in range(n)])
+        ptrs = _frame_ptrs(frames)
         rc = lib.jdaTraceBatchCpp(self.h, ptrs, n, w, h, minimum_size, step, factor,
                                   carts.ctypes.data_as(C.POINTER(C.c_int)), score.ctypes.data_as(C.POINTER(C.c_double)),
                                   hsh.ctypes.data_as(C.POINTER(C.c_uint)), shapes.ctypes.data_as(C.POINTER(C.c_double)))

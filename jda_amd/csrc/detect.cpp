@@ -88,6 +88,9 @@ static long long env_ll(const char* name, long long dflt) {
   X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
   X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
   X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
+  X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
+  X(kernel_d2h, "JDA_KERNEL_D2H", 1)        /* counters and detections -> pinned host memory by a kernel, not the copy engine */ \
+  X(filter0, "JDA_FILTER0", 1)              /* large hand-off queues: k_filter0 + k_finish(survivors) instead of two k_finish passes */ \
   X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
   X(fin_g1, "JDA_FIN_G1", 1)                                                                           \
   X(fin_g2, "JDA_FIN_G2", 0)                                                                           \
@@ -208,7 +211,8 @@ constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before
 // tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms,
 // the copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight); also the chunks of a
 // ragged job that are in flight at once
-constexpr int kTickets = 3;
+constexpr int kTickets = 6;
+constexpr int kRaggedLanes = 3;      // chunks of a ragged job in flight
 
 struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
 
@@ -243,6 +247,7 @@ struct Lane {
   hipEvent_t ev[5] = {};
   hipEvent_t ev_side[2] = {};
   hipEvent_t ev_user = nullptr;
+  hipEvent_t ev_h2d[2] = {};                 // staging buffer free / frames uploaded (Cascador::h2d)
   unsigned long long* h_cnt = nullptr;       // pinned copy of the work counters
   HostPinned h_gid, h_score, h_shape;        // detections of the lane's pass
   DevBuf ws;                                 // per-window arrays, carved for one dialect at a time
@@ -258,6 +263,7 @@ struct Lane {
     JDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& e : ev) JDA_HIP(hipEventCreate(&e));
     JDA_HIP(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
+    for (auto& e : ev_h2d) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     JDA_HIP(hipHostMalloc((void**)&h_cnt, sizeof(unsigned long long) * kCntShards * kCntStride, hipHostMallocDefault));
     return true;
   }
@@ -276,6 +282,7 @@ struct Lane {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
     if (ev_user) (void)hipEventDestroy(ev_user);
+    for (auto& e : ev_h2d) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
     if (side) (void)hipStreamDestroy(side);
   }
@@ -296,6 +303,11 @@ struct Cascador {
   int n_cus = 256;             // compute units of the device
   bool dev_init = false;
   hipStream_t aux = nullptr;   // stage-0 table builds (under mu)
+  // Frame uploads of every lane, in the order they are issued (under h2d_mu).  Uploads issued lane by lane run
+  // CONCURRENTLY on the copy engines, each at a fraction of the link: two batches then both arrive late, and their
+  // kernels collide afterwards.  One after the other, batch i+1 goes up while batch i computes.
+  hipStream_t h2d = nullptr;
+  std::mutex h2d_mu;
   std::vector<std::unique_ptr<Lane>> lanes;
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
@@ -342,6 +354,12 @@ static bool ensure_device(Cascador* c) {
   JDA_HIP(hipSetDevice(c->device));
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
   JDA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  if (getenv("JDA_H2D_PRIO")) {
+    int lo = 0, hi = 0;
+    JDA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    JDA_HIP(hipStreamCreateWithPriority(&c->h2d, hipStreamNonBlocking, atoi(getenv("JDA_H2D_PRIO")) ? hi : lo));
+  } else
+  JDA_HIP(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
   c->dev_init = true;
   return true;
 }
@@ -943,14 +961,32 @@ struct Pass {
     return true;
   }
 
+  // Host frames -> staging buffer, ahead of this pass on its stream.
+  bool upload_frames(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes) {
+    if (!kn().h2d_stream || !c->h2d) return copy_frames_h2d(dst, stride, frames, n, fbytes, st);
+    {
+      std::lock_guard<std::mutex> lk(c->h2d_mu);
+      JDA_HIP(hipEventRecord(ln->ev_h2d[0], st));                // (whatever read the staging buffer before is done)
+      JDA_HIP(hipStreamWaitEvent(c->h2d, ln->ev_h2d[0], 0));
+      if (!copy_frames_h2d(dst, stride, frames, n, fbytes, c->h2d)) return false;
+      if (kn().h2d_stream != 1) JDA_HIP(hipEventRecord(ln->ev_h2d[1], c->h2d));
+      else JDA_HIP(hipStreamSynchronize(c->h2d));
+    }
+    // The pass is enqueued once its frames are up, not behind a device-side wait: HIP multiplexes its streams onto
+    // four hardware queues, and a barrier packet that sits out a 1.4-ms upload also stalls whichever other lane shares
+    // that queue (seen in the copy/kernel timeline: a lane's second scan launch waiting for the NEXT batch's upload).
+    if (kn().h2d_stream == 2) { JDA_HIP(hipStreamWaitEvent(st, ln->ev_h2d[1], 0)); }
+    else if (kn().h2d_stream == 3) JDA_HIP(hipEventSynchronize(ln->ev_h2d[1]));
+    return true;
+  }
+
   // step 1: pyramids (multi-scale models), stage-0 scan (or everything, in dense mode)
   bool issue_scan(uint8_t* hbuf, size_t hs, uint8_t* qbuf, size_t qs, hipEvent_t scan_after) {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
     JDA_HIP(hipEventRecord(ev[0], st));
     if (rag) return issue_scan_ragged();
-    if (host_frames && !copy_frames_h2d(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes, st))
-      return false;
+    if (host_frames && !upload_frames(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes)) return false;
     if (multi) {
       const int W = pe->sp.width, H = pe->sp.height;
       const size_t stride = w.frame_stride;
@@ -1123,13 +1159,21 @@ struct Pass {
       finished = true;
       return true;
     }
+    const long long wg2 = std::min<long long>(n_grid, std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)));
+    if (kn().filter0 && s0_tbl() != nullptr && pe->fast_scan && !pe->any_untiled && !multi) {
+      // the dying majority is filtered by a lean kernel (four windows per workgroup, stage 0 only); the survivors --
+      // a few per cent -- go through k_finish for the regression of stage 0 and every later stage
+      JDA_HIP(launch_filter0<Real>(want_trace(), pe->dp, model(), w, n_grid, s0_tbl(), st));
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, g2, wg2, s0_tbl(), (int)kn().fin_tile, st, true));
+      finished = true;
+      return true;
+    }
     // Two launches so that the few windows that pass stage 0 (and then cost whole stages each) are spread over
     // the machine again.  The second is queued right behind the first, without a host round trip for the length
     // of the mid queue (the kernel reads it from the device counter): its grid is a quarter of the hand-off count
     // -- one workgroup per window as long as fewer than 25 % pass stage 0 (6.7 % in the cascade regime), a grid-stride
     // loop beyond that; the surplus workgroups exit at once (an empty workgroup costs ~1.3 ns of dispatcher time).
     JDA_HIP(launch_finish<Real>(want_trace(), 0, 1, apply_th, th, pe->dp, model(), w, (int)kn().fin_g1, n_grid, s0_tbl(), (int)kn().fin_tile1, st));
-    const long long wg2 = std::min<long long>(n_grid, std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)));
     JDA_HIP(launch_finish<Real>(want_trace(), 1, T, apply_th, th, pe->dp, model(), w, g2, wg2, nullptr, (int)kn().fin_tile, st));
     finished = true;
     return true;
@@ -1163,6 +1207,12 @@ struct Pass {
     if (counters_issued) return true;
     counters_issued = true;
     JDA_HIP(hipEventRecord(ev[3], st));
+    if (kn().kernel_d2h) {
+      const void* src[1] = {w.counters}; void* dst[1] = {h_cnt};
+      const size_t nb[1] = {sizeof(unsigned long long) * kCntShards * kCntStride};
+      JDA_HIP(launch_copy_out(src, dst, nb, 1, st));
+      return true;
+    }
     JDA_HIP(hipMemcpyAsync(h_cnt, w.counters, sizeof(unsigned long long) * kCntShards * kCntStride, hipMemcpyDeviceToHost, st));
     return true;
   }
@@ -1175,6 +1225,15 @@ struct Pass {
     if (!hg.reserve(to * 4, from * 4) || !hs.reserve(to * sizeof(Real), from * sizeof(Real)) ||
         !hh.reserve(to * dim * sizeof(Real), from * dim * sizeof(Real))) return false;
     const size_t n = to - from;
+    if (kn().kernel_d2h && from == 0) {          // (a 16-byte aligned start: the predicted prefix; a later rest goes by the copy engine)
+      const void* src[3] = {w.out_gid, w.out_score, w.out_shape};
+      void* dst[3] = {hg.p, hs.p, hh.p};
+      const size_t nb[3] = {n * 4, n * sizeof(Real), n * dim * sizeof(Real)};
+      JDA_HIP(launch_copy_out(src, dst, nb, 3, st));
+      out_copied = to;
+      results_pending = true;
+      return true;
+    }
     JDA_HIP(hipMemcpyAsync((uint32_t*)hg.p + from, w.out_gid + from, n * 4, hipMemcpyDeviceToHost, st));
     JDA_HIP(hipMemcpyAsync((Real*)hs.p + from, w.out_score + from, n * sizeof(Real), hipMemcpyDeviceToHost, st));
     JDA_HIP(hipMemcpyAsync((Real*)hh.p + from * dim, w.out_shape + from * dim, n * dim * sizeof(Real), hipMemcpyDeviceToHost, st));
@@ -2268,7 +2327,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     starts.push_back(n);
   }
   const int n_chunks = (int)starts.size() - 1;
-  const int lanes = std::min(kTickets, n_chunks);
+  const int lanes = std::min(kRaggedLanes, n_chunks);
   struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
   LaneSet held(c);
@@ -2372,6 +2431,7 @@ void jdaCascadorRelease(void* cascador) {
     (void)hipSetDevice(c->device);
     for (auto& l : c->lanes) l->destroy();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->h2d) { (void)hipStreamSynchronize(c->h2d); (void)hipStreamDestroy(c->h2d); }
     for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
     for (auto& b : c->plan_pool) { if (b.dp) (void)hipFree(b.dp); if (b.table) (void)hipFree(b.table); }
     c->mf.buf.release(); c->md.buf.release();

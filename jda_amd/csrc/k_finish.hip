@@ -21,7 +21,7 @@ template <typename DL, bool TRACE, int kG, bool MULTI, bool ST>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
                                                int t_begin, int t_end, int apply_th, typename DL::Real final_th,
-                                               const S0Node* __restrict__ s0_table, int tile_win) {
+                                               const S0Node* __restrict__ s0_table, int tile_win, int survivors) {
   using Real = typename DL::Real;
   constexpr bool kCpp = sizeof(Real) == 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -40,7 +40,10 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   constexpr bool multi = MULTI;   // split nodes read the half/quarter images too
   (void)multi_i;
   if (lane < kMaxStages) stage_cnt[lane] = 0;
-  const bool from_scan = t_begin == 0;
+  // the input queue: the hand-off queue of k_scan (t_begin == 0), the mid queue of an earlier k_finish launch
+  // (t_begin > 0), or -- survivors -- the mid queue as k_filter0 leaves it: windows that passed every cart of stage 0,
+  // still holding the mean shape (their stage-0 leaves are walked again here, no score is applied)
+  const bool from_scan = t_begin == 0 && !survivors;
   const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)w.cap);
   unsigned long long carts_acc = 0;
 
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     JDA_FSTAMP();
     const uint32_t gid = from_scan ? w.q_gid[i] : w.m_gid[i];
     Real score = from_scan ? w.q_score[i] : w.m_score[i];
-    const int kstart = from_scan ? (int)w.q_kstart[i] : 0;
+    const int kstart = from_scan ? (int)w.q_kstart[i] : (survivors ? K : 0);
     unsigned hash = kFnvSeed;
     if (TRACE) hash = from_scan ? w.q_hash[i] : w.m_hash[i];
     int win;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     __syncthreads();                       // previous window's readers are done with sh (and the tile)
     if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane);
     {
-      const Real* src = from_scan ? m.mean_shape : w.m_shape + (size_t)i * dim;
+      const Real* src = t_begin == 0 ? m.mean_shape : w.m_shape + (size_t)i * dim;
       for (int d = lane; d < dim; d += 64) sh[d] = src[d];
     }
     __syncthreads();
@@ -240,12 +243,169 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   if (lane == 0 && carts_acc) atomicAdd(shard_counter(w.counters, kCntCarts), carts_acc);
 }
 
+// =============================================================================
+// k_filter0: the rest of stage 0 for the hand-off queue, and nothing else
+// =============================================================================
+// 0.7 % of a batch's windows leave k_scan alive at cart `handoff`, and 93 % of those die before stage 0 ends, most of
+// them within a round of 64 carts.  k_finish spends a one-wave workgroup with a stage's worth of state on each: the
+// hardware holds 16 such workgroups per CU, and with ~8 us of dependent memory round trips per window (queue entry,
+// three tree levels of table + pixel loads, leaf scores, replay) the launch is bound by latency x 16 windows per CU,
+// not by any pipe (pass 1: 224 us for 70 k windows).  This kernel does only that filtering: wave = window, four
+// independent waves per workgroup (no LDS, no barrier), stage-0 walks from the resolved tables with the pixels read
+// from the frame, the systolic replay; few registers, so a CU holds several times as many windows.  A window that is
+// rejected is final here (counters, trace); one that passes every cart of stage 0 goes to the mid queue with its
+// score, and k_finish(survivors) takes it through the regression of stage 0 (re-walking its trees for the leaves) and
+// the later stages.  Same walks, same replay: c/jda.c:366-400.
+namespace {
+// One depth-4 cart of stage 0 from the level-major table with ALL seven node records fetched up front: the root, the
+// pair of its children (16 contiguous bytes) and the four grandchildren (32 contiguous bytes) of cart k sit at
+// lm_index(K, k, d, .), so the four loads are independent of the walk and -- lanes = consecutive carts -- coalesced.
+// Only the three pixel-pair reads stay dependent: 4 memory round trips per cart instead of 6.
+__device__ __forceinline__ int walk_cart_s0_d4(const S0Node* __restrict__ tbl, unsigned K, unsigned k,
+                                               const uint8_t* __restrict__ pix, int pitch) {
+  const S0Node r0 = tbl[k];
+  const uint4 c1 = *(const uint4*)(tbl + K + 2u * k);                 // children of the root
+  const uint4 c2a = *(const uint4*)(tbl + 3u * K + 4u * k);           // grandchildren 0, 1
+  const uint4 c2b = *(const uint4*)(tbl + 3u * K + 4u * k + 2u);      // grandchildren 2, 3
+  auto left = [&](uint32_t lo, uint32_t hi) {
+    const unsigned p1 = lo & 0x3fffffu, p2 = __builtin_amdgcn_alignbit(hi, lo, 22) & 0x3fffffu;
+    const int a = pix[__umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu)];
+    const int b = pix[__umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu)];
+    return a - b <= (int)((hi >> 12) & 0x3ffu) - 256;                 // c/jda.c:391-393
+  };
+  const bool l0 = left(r0.lo, r0.hi);                                 // left -> child 1 (index 0 of the pair), right -> child 2
+  const uint32_t lo1 = l0 ? c1.x : c1.z, hi1 = l0 ? c1.y : c1.w;
+  const bool l1 = left(lo1, hi1);
+  // node after level 1: 2*node + (left ? 1 : 2); its record among the four grandchildren: index 2*(l0 ? 0 : 1) + (l1 ? 0 : 1)
+  const uint32_t lo2 = l0 ? (l1 ? c2a.x : c2a.z) : (l1 ? c2b.x : c2b.z);
+  const uint32_t hi2 = l0 ? (l1 ? c2a.y : c2a.w) : (l1 ? c2b.y : c2b.w);
+  const bool l2 = left(lo2, hi2);
+  const int n1 = l0 ? 1 : 2, n2 = 2 * n1 + (l1 ? 1 : 2), n3 = 2 * n2 + (l2 ? 1 : 2);
+  return n3 - 7;
+}
+}  // namespace
+
+template <typename DL, bool TRACE>
+__global__ __launch_bounds__(256) void k_filter0(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
+                                                 WorkT<typename DL::Real> w, const S0Node* __restrict__ s0_table) {
+  using Real = typename DL::Real;
+  constexpr int NW = 2;                    // windows a wave walks side by side: their memory round trips overlap
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int K = m.K, node_n = m.node_n, leaf_n = m.leaf_n;
+  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  const Real* leaf_tab = m.leaf;
+  const int W = plan->width;
+  unsigned long long carts_acc = 0;
+  const unsigned waves = gridDim.x * 4u;
+  for (unsigned i0 = blockIdx.x * 4u + (unsigned)wv; i0 < n; i0 += NW * waves) {
+    unsigned idx[NW]; bool has[NW];
+    uint32_t gid[NW], xy[NW], wf[NW];
+    Real score[NW];
+    int kbeg[NW], rej[NW];
+    unsigned hash[NW];
+    const uint8_t* wbase[NW];
+    const S0Node* tbl[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      idx[u] = i0 + (unsigned)u * waves; has[u] = idx[u] < n;
+      const unsigned i = has[u] ? idx[u] : i0;
+      gid[u] = w.q_gid[i]; score[u] = w.q_score[i]; kbeg[u] = min((int)w.q_kstart[i], K);
+      hash[u] = TRACE ? w.q_hash[i] : kFnvSeed;
+      xy[u] = w.q_xy[i]; wf[u] = w.q_wf[i];
+      rej[u] = has[u] ? -1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      const int win = (int)(wf[u] & 0xffffu), frame = (int)(wf[u] >> 16);
+      const uint8_t* img = w.img_off != nullptr ? w.frames + w.img_off[frame] : w.frames + (size_t)frame * w.frame_stride;
+      wbase[u] = img + (size_t)(xy[u] >> 16) * W + (xy[u] & 0xffffu);
+      tbl[u] = s0_table;
+      const bool hit = lane < plan->n_levels && plan->lv[lane].win == win;
+      const unsigned long long mh = __ballot(hit);
+      if (mh) tbl[u] = s0_table + plan->lv[__ffsll((long long)mh) - 1].s0_table;   // (the host only runs this kernel when every level has a table)
+    }
+    // rounds of 64 carts, both windows in step while both are alive (a window's own cart range starts at its kbeg)
+    int k0[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++) k0[u] = kbeg[u] & ~63;
+    for (;;) {
+      bool go[NW], any = false;
+#pragma unroll
+      for (int u = 0; u < NW; u++) { go[u] = rej[u] < 0 && k0[u] < K; any = any || go[u]; }
+      if (!any) break;
+      int lf[NW], nrm[NW];
+      Real ls[NW], thk[NW], mk[NW], sk[NW];
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        const int k = k0[u] + lane;
+        thk[u] = 0; nrm[u] = 0; ls[u] = 0; mk[u] = 0; sk[u] = 1; lf[u] = 0;
+        if (go[u] && k < K) { thk[u] = m.cth[k]; nrm[u] = m.cnorm[k]; }   // independent of the walk: in flight with it
+      }
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        if (!go[u]) continue;
+        int kk[1], l1[1];
+        kk[0] = min(k0[u] + lane, K - 1);
+        if (m.D == 4) l1[0] = walk_cart_s0_d4(tbl[u], (unsigned)K, (unsigned)kk[0], wbase[u], W);
+        else walk_carts_s0<1, false>(tbl[u], K, kk, m.D, node_n, wbase[u], W, l1);
+        lf[u] = l1[0];
+      }
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        const int k = k0[u] + lane;
+        if (go[u] && k < K) {
+          ls[u] = leaf_tab[(unsigned)(k * leaf_n + lf[u])];
+          if (nrm[u]) { mk[u] = m.cmean[k]; sk[u] = m.cstd[k]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        if (!go[u]) continue;
+        const unsigned long long normmask = __ballot(nrm[u] != 0);
+        const int jr = replay_scores<Real, TRACE>(score[u], hash[u], ls[u], thk[u], mk[u], sk[u], normmask, lf[u],
+                                                  max(0, kbeg[u] - k0[u]), min(64, K - k0[u]));
+        if (jr >= 0) rej[u] = k0[u] + jr;
+        k0[u] += 64;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+      if (!has[u]) continue;
+      if (rej[u] >= 0) {
+        carts_acc += (unsigned long long)(rej[u] + 1);
+        if (TRACE && lane == 0) { w.tr_carts[gid[u]] = rej[u] + 1; w.tr_score[gid[u]] = score[u]; w.tr_hash[gid[u]] = hash[u]; }
+      } else {
+        unsigned o = 0;
+        if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
+        o = (unsigned)__shfl((int)o, 0);
+        if (o < w.cap && lane == 0) {
+          w.m_gid[o] = gid[u]; w.m_score[o] = score[u]; w.m_xy[o] = xy[u]; w.m_wf[o] = wf[u];
+          if (TRACE) w.m_hash[o] = hash[u];
+        }
+      }
+    }
+  }
+  if (lane == 0 && carts_acc) atomicAdd(shard_counter(w.counters, kCntCarts), carts_acc);
+}
+
+template <typename Real>
+hipError_t launch_filter0(bool trace, const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w, long long n_hint,
+                          const S0Node* s0_table, hipStream_t stream) {
+  using DL = typename std::conditional<sizeof(Real) == 4, DialectC, DialectCPP>::type;
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((n_hint + 7) / 8, 1 << 20));   // 4 waves x 2 windows
+  if (trace) hipLaunchKernelGGL((k_filter0<DL, true>), dim3(blocks), dim3(256), 0, stream, d_plan, m, w, s0_table);
+  else hipLaunchKernelGGL((k_filter0<DL, false>), dim3(blocks), dim3(256), 0, stream, d_plan, m, w, s0_table);
+  return hipGetLastError();
+}
+template hipError_t launch_filter0<float>(bool, const DevPlan*, const DevModelT<float>&, const WorkT<float>&, long long, const S0Node*, hipStream_t);
+template hipError_t launch_filter0<double>(bool, const DevPlan*, const DevModelT<double>&, const WorkT<double>&, long long, const S0Node*, hipStream_t);
+
 namespace {
 template <typename DL>
 hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th, typename DL::Real th,
                               const DevPlan* d_plan, const DevModelT<typename DL::Real>& m,
                               const WorkT<typename DL::Real>& w, int groups, long long n_hint, const S0Node* s0_table,
-                              int tile_win, hipStream_t stream) {
+                              int tile_win, bool survivors, hipStream_t stream) {
   using Real = typename DL::Real;
   const int dim_pad = (m.dim + 1) & ~1;
   const bool st = sizeof(Real) == 8 && m.similarity != 0;
@@ -275,7 +435,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, d_plan, m, w, multi, r, t_begin, t_end,
-                       apply_th ? 1 : 0, th, s0_table, tile_win);
+                       apply_th ? 1 : 0, th, s0_table, tile_win, survivors ? 1 : 0);
   };
   // groups = 64-cart groups walked speculatively per round: 1 where most windows are
   // rejected within a few carts (throughput), 4 where most pass (latency)
@@ -299,14 +459,16 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
 template <>
 hipError_t launch_finish<float>(bool trace, int t_begin, int t_end, bool apply_final_th, float final_th,
                                 const DevPlan* d_plan, const DevModelT<float>& m, const WorkT<float>& w,
-                                int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream) {
-  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, stream);
+                                int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream,
+                                bool survivors) {
+  return launch_finish_impl<DialectC>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, survivors, stream);
 }
 template <>
 hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_final_th, double final_th,
                                  const DevPlan* d_plan, const DevModelT<double>& m, const WorkT<double>& w,
-                                 int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream) {
-  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, stream);
+                                 int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream,
+                                 bool survivors) {
+  return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, survivors, stream);
 }
 
 

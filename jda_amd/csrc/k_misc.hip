@@ -246,6 +246,38 @@ template hipError_t launch_enqueue<float>(const DevPlan*, const DevPlan&, bool, 
 template hipError_t launch_enqueue<double>(const DevPlan*, const DevPlan&, bool, const WorkT<double>&, hipStream_t);
 
 // =============================================================================
+// results -> pinned host memory by a kernel
+// =============================================================================
+// The counters and the detections of a pass are a few hundred KB.  As hipMemcpyAsync they go to the copy engine, where
+// they queue behind the 78-MB frame uploads of the NEXT tickets of a host-frame stream (measured: a ticket's Wait then
+// sits out another batch's upload, 2.46 ms per batch on a link that moves a batch in 1.41 ms).  Written by a kernel
+// into mapped pinned memory they travel on the lane's own compute queue.
+struct CopySeg { const void* src; void* dst; unsigned long long bytes; };
+struct CopySegs { CopySeg s[4]; };
+
+__global__ __launch_bounds__(256) void k_copy_out(CopySegs segs) {
+  const CopySeg sg = segs.s[blockIdx.y];
+  const unsigned long long n16 = sg.bytes >> 4;
+  const uint4* s4 = (const uint4*)sg.src;
+  uint4* d4 = (uint4*)sg.dst;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (sg.bytes & 15)) ((unsigned char*)sg.dst)[(n16 << 4) + threadIdx.x] = ((const unsigned char*)sg.src)[(n16 << 4) + threadIdx.x];
+}
+
+// up to 4 segments (src device / dst mapped host, both 16-byte aligned) in one launch
+hipError_t launch_copy_out(const void* const* src, void* const* dst, const size_t* bytes, int n, hipStream_t stream) {
+  CopySegs segs{};
+  size_t most = 0;
+  int m = 0;
+  for (int i = 0; i < n && m < 4; i++)
+    if (bytes[i]) { segs.s[m].src = src[i]; segs.s[m].dst = dst[i]; segs.s[m].bytes = bytes[i]; most = std::max(most, bytes[i]); m++; }
+  if (m == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(256, (most / 16 + 255) / 256));
+  hipLaunchKernelGGL(k_copy_out, dim3(blocks, (unsigned)m), dim3(256), 0, stream, segs);
+  return hipGetLastError();
+}
+
+// =============================================================================
 // trace defaults: every window starts as "0 carts, mean shape"
 // =============================================================================
 

@@ -225,7 +225,17 @@ hipError_t launch_repack(const uint8_t* raw, uint8_t* dst, const RagImg* imgs, i
 template <typename Real>
 hipError_t launch_finish(bool trace, int t_begin, int t_end, bool apply_final_th, Real final_th,
                          const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w,
-                         int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream);
+                         int groups, long long n_hint, const S0Node* s0_table, int tile_win, hipStream_t stream,
+                         bool survivors = false);
+// survivors: the input is the mid queue as launch_filter0 leaves it (windows that passed every cart of stage 0, still
+// holding the mean shape); t_begin must be 0.
+
+// The rest of stage 0 for every window of the hand-off queue, four windows per workgroup and nothing but the filtering
+// (k_finish.hip: k_filter0): rejected windows are final, survivors go to the mid queue.  Needs the resolved stage-0
+// table of every level.
+template <typename Real>
+hipError_t launch_filter0(bool trace, const DevPlan* d_plan, const DevModelT<Real>& m, const WorkT<Real>& w, long long n_hint,
+                          const S0Node* s0_table, hipStream_t stream);
 // s0_table: the plan's resolved stage-0 tables (or null): stage 0 of windows from levels that have one walks from it
 // tile_win: windows up to this side copy their pixels to LDS first (0: every pixel is read from the frame,
 // < 0: the largest side that leaves the workgroup within kFinishLdsPerGroup)
@@ -247,6 +257,10 @@ hipError_t launch_stage(bool trace, int level, int t, bool apply_final_th, Real 
                         const DevPlan& h_plan, const DevModelT<Real>& m, const WorkT<Real>& w, int pix_cap,
                         int lds_max, hipStream_t stream);
 size_t stage_lds_bytes(int dim, int node_n, int leaf_n, int real_bytes);
+
+// Device -> mapped pinned host memory by a kernel on `stream` (instead of the copy engine): up to 4 segments, 16-byte
+// aligned.
+hipError_t launch_copy_out(const void* const* src, void* const* dst, const size_t* bytes, int n, hipStream_t stream);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

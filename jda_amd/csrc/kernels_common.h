@@ -279,6 +279,8 @@ __device__ __forceinline__ double lane_below(double old, double v) {
 template <typename Real, bool TRACE>
 __device__ __forceinline__ int replay_scores(Real& score, unsigned& hash, Real ls, Real th_k, Real mean_k, Real std_k,
                                              unsigned long long normmask, int lf, int jbeg, int jend) {
+  jbeg = __builtin_amdgcn_readfirstlane(jbeg);                        // (wave-uniform by contract; values that come out of vector
+  jend = __builtin_amdgcn_readfirstlane(jend);                        // loads are not known to be: the lane mask below lives in SGPRs)
   if (jbeg >= jend) return -1;                                        // no cart of this group is still to be scored
   const int lane = wave_lane();
   const bool norm = (normmask >> lane) & 1ull;

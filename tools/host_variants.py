@@ -17,6 +17,8 @@ for spec in (sys.argv[1:] or [""]):
         k, v = kv.split("=", 1); os.environ[k] = v
     out = []
     for name, frames in (("pageable", src), ("pinned", [p.numpy() for p in pin])):
+        if os.environ.get("HOST_ONLY", name) != name:
+            continue
         c = api.Cascador(mp)
         ahead = int(os.environ.get("AHEAD", "2"))
         def run(steps):
@@ -26,7 +28,7 @@ for spec in (sys.argv[1:] or [""]):
                     q.append(c.submit_batch_host(frames[(i + ahead) % 2]))
                 c.wait_batch(q.pop(0), keep_results="packed")
         run(4)
-        torch.cuda.synchronize(); t0 = time.perf_counter(); steps = 30
+        torch.cuda.synchronize(); t0 = time.perf_counter(); steps = int(os.environ.get('HOST_STEPS', '30'))
         run(steps)
         el = (time.perf_counter() - t0) / steps
         out.append("%s %.3f ms %.2e win/s" % (name, el * 1e3, wpf * 256 / el))
