@@ -211,7 +211,7 @@ constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before
 // tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms,
 // the copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight); also the chunks of a
 // ragged job that are in flight at once
-constexpr int kTickets = 6;
+constexpr int kTickets = 3;
 constexpr int kRaggedLanes = 3;      // chunks of a ragged job in flight
 
 struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
@@ -354,12 +354,6 @@ static bool ensure_device(Cascador* c) {
   JDA_HIP(hipSetDevice(c->device));
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
   JDA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-  if (getenv("JDA_H2D_PRIO")) {
-    int lo = 0, hi = 0;
-    JDA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    JDA_HIP(hipStreamCreateWithPriority(&c->h2d, hipStreamNonBlocking, atoi(getenv("JDA_H2D_PRIO")) ? hi : lo));
-  } else
-  JDA_HIP(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
   c->dev_init = true;
   return true;
 }
@@ -963,9 +957,12 @@ struct Pass {
 
   // Host frames -> staging buffer, ahead of this pass on its stream.
   bool upload_frames(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes) {
-    if (!kn().h2d_stream || !c->h2d) return copy_frames_h2d(dst, stride, frames, n, fbytes, st);
+    if (!kn().h2d_stream) return copy_frames_h2d(dst, stride, frames, n, fbytes, st);
     {
       std::lock_guard<std::mutex> lk(c->h2d_mu);
+      // (created by the first upload: HIP spreads its streams over four hardware queues in creation order, and a stream
+      // that callers with resident frames never use would still shift which lanes share a queue)
+      if (!c->h2d) JDA_HIP(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
       JDA_HIP(hipEventRecord(ln->ev_h2d[0], st));                // (whatever read the staging buffer before is done)
       JDA_HIP(hipStreamWaitEvent(c->h2d, ln->ev_h2d[0], 0));
       if (!copy_frames_h2d(dst, stride, frames, n, fbytes, c->h2d)) return false;
