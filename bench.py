@@ -276,6 +276,7 @@ def main():
         gather, gather_kind[0] = make_gather()
 
         counter = [0]
+        timed_passes = os.environ.get("JDA_BENCH_TIMED_PASSES", "0") == "1"
 
         def next_batch():
             counter[0] += 1
@@ -292,7 +293,9 @@ def main():
             return len(rows), st
 
         def submit():
-            return casc.submit_batch_device(next_batch(), call["scale"], call["min_size"], call["max_size"], th, nms=True)
+            # (no timing events in the passes of the headline leg: the kernel spans come from the one-lane leg)
+            return casc.submit_batch_device(next_batch(), call["scale"], call["min_size"], call["max_size"], th, nms=True,
+                                            stats=timed_passes)
 
         if depth == 1:
             for _ in range(warmup):

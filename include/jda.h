@@ -156,7 +156,8 @@ typedef struct {
                               /* the reference (cascador.cpp:359-364)         */
   long long stage_done_n[16]; /* windows that completed stage t (shape update) */
   double average_cart_n;      /* cart_gothrough_n / nonface_patch_n           */
-  double gpu_ms;              /* device time of the call (HIP events)         */
+  double gpu_ms;              /* device time of the call (HIP events; the events -- five marker packets per */
+                              /* pass -- are only recorded when statistics are asked for)                   */
   double scan_ms;             /* device time of the stage-0 scan launches (first start to last end; */
                               /* two sub-batches scan side by side on big batches)                  */
   double host_ms;             /* host post-processing (sort, NMS, relocation) */
@@ -228,8 +229,9 @@ JDA_API int jdaDetectBatchRaggedDevice(void *cascador, const unsigned char *d_ba
  * while the host parts of batch i (D2H, sort, NMS, result assembly) run (one batch ahead is enough for frames that
  * are already on the device; frames coming from the host want two ahead, see jdaDetectBatchSubmitHost).
  * The frames must stay valid until Wait returns.  The other entry points keep working while tickets are pending
- * (they run on other lanes).  opt->stats is ignored by Submit; Wait takes the stats pointer (gpu_ms = that batch's
- * own device span, call_ms = submit to the end of wait). */
+ * (they run on other lanes).  Wait takes the stats pointer (gpu_ms = that batch's own device span, call_ms = submit
+ * to the end of wait); nothing is written through opt->stats by Submit, but a non-NULL opt->stats tells it to bracket
+ * the pass with timing events -- without it Wait reports the counters and gpu_ms = scan_ms = 0. */
 JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, size_t frame_stride, int n,
                                  int width, int height, float scale, float step, int min_size, int max_size,
                                  float th, const jdaDetectOptions *opt);

@@ -398,12 +398,14 @@ class Cascador:
         return (out, st.asdict()) if stats else out
 
     # -- two batches in flight from one thread -----------------------------------
-    def submit_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True):
+    def submit_batch_device(self, d_frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True, stats=False):
         """Queues the scan of a batch and returns a ticket; collect it with wait_batch (the frames are kept
-        alive until then).  Submit batch i+1 before waiting for batch i to overlap host and device work."""
+        alive until then).  Submit batch i+1 before waiting for batch i to overlap host and device work.
+        stats=True: the pass is bracketed with timing events, so wait_batch(stats=True) reports gpu_ms / scan_ms
+        (the counters are reported either way)."""
         assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
         n, h, w = d_frames.shape
-        o, _ = self._opts(nms, False)
+        o, _ = self._opts(nms, stats)
         t = lib.jdaDetectBatchSubmit(self.h, C.c_void_p(d_frames.data_ptr()), h * w, n, w, h, scale, 0.1,
                                      min_size, max_size, th, C.byref(o))
         if t < 0:
@@ -413,12 +415,12 @@ class Cascador:
         self._pending[t] = (d_frames, n)
         return t
 
-    def submit_batch_host(self, frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True):
+    def submit_batch_host(self, frames, scale=1.25, min_size=40, max_size=-1, th=-0.5, nms=True, stats=False):
         """Submit for frames in host memory (numpy uint8 [n,h,w]; kept alive until wait_batch)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, h, w = frames.shape
         ptrs = _frame_ptrs(frames)
-        o, _ = self._opts(nms, False)
+        o, _ = self._opts(nms, stats)
         t = lib.jdaDetectBatchSubmitHost(self.h, ptrs, n, w, h, scale, 0.1, min_size, max_size, th, C.byref(o))
         if t < 0:
             raise JdaError(last_error())

@@ -89,6 +89,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
   X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
   X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
+  X(h2d_min_bytes, "JDA_H2D_MIN_BYTES", 8 << 20) /* ... for uploads of at least this many bytes */ \
   X(kernel_d2h, "JDA_KERNEL_D2H", 1)        /* counters and detections -> pinned host memory by a kernel, not the copy engine */ \
   X(filter0, "JDA_FILTER0", 1)              /* large hand-off queues: k_filter0 + k_finish(survivors) instead of two k_finish passes */ \
   X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
@@ -823,6 +824,10 @@ struct TraceOut {              // host arrays, may be null
 };
 
 struct RunStats {
+  // Device-side spans (gpu_ms, scan_ms, scan_lds_ms) are wanted: the pass brackets its steps with events.  Off for
+  // callers that did not ask for statistics -- each record is a marker packet the command processor works off
+  // between the kernels, a few microseconds apiece, five per pass.
+  bool timed = true;
   long long carts = 0, out = 0, carts_scan = 0, carts_scan_glb = 0, win_scan = 0, tail = 0;
   long long stage_done[kMaxStages] = {0};
   double gpu_ms = 0, scan_ms = 0, scan_lds_ms = 0;
@@ -887,6 +892,7 @@ struct Pass {
   int busy_lanes = 1;               // lanes of the cascador in use when the pass was set up (concurrent callers)
   void bind(Lane* l, int index, hipStream_t stream) {
     ln = l; lane = index; st = stream ? stream : l->stream; ev = l->ev; h_cnt = l->h_cnt;
+    timed = !rs || rs->timed || c->kn.debug_times;
     w = Sel<Real>::work(l); cap = l->cap;
     std::lock_guard<std::mutex> lk(c->mu);
     hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out;
@@ -899,6 +905,7 @@ struct Pass {
   const RaggedChunk* rag = nullptr;   // ragged pass: images of different sizes (w.segs / w.blk / w.img_off set by stage_ragged)
   // state between the steps
   bool dense = false, finished = false, lds_span = false;
+  bool timed = true;               // RunStats::timed
   bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
   bool counters_issued = false, results_pending = false;
   long long n_tail = -1;
@@ -957,7 +964,9 @@ struct Pass {
 
   // Host frames -> staging buffer, ahead of this pass on its stream.
   bool upload_frames(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes) {
-    if (!kn().h2d_stream) return copy_frames_h2d(dst, stride, frames, n, fbytes, st);
+    // (small uploads -- single frames of concurrent jdaDetect callers -- stay on the lane: they do not fill the link,
+    // and a host wait per call under one mutex would serialise the callers)
+    if (!kn().h2d_stream || (long long)n * (long long)fbytes < kn().h2d_min_bytes) return copy_frames_h2d(dst, stride, frames, n, fbytes, st);
     {
       std::lock_guard<std::mutex> lk(c->h2d_mu);
       // (created by the first upload: HIP spreads its streams over four hardware queues in creation order, and a stream
@@ -981,7 +990,7 @@ struct Pass {
   bool issue_scan(uint8_t* hbuf, size_t hs, uint8_t* qbuf, size_t qs, hipEvent_t scan_after) {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
-    JDA_HIP(hipEventRecord(ev[0], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[0], st));
     if (rag) return issue_scan_ragged();
     if (host_frames && !upload_frames(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes)) return false;
     if (multi) {
@@ -1005,8 +1014,8 @@ struct Pass {
     const bool ok = dense_ok(&pix_cap, &lds_max);
     dense = ok && (kn().dense == 2 || hint_dense);
     if (dense) {
-      JDA_HIP(hipEventRecord(ev[1], st));
-      JDA_HIP(hipEventRecord(ev[2], st));
+      if (timed) JDA_HIP(hipEventRecord(ev[1], st));
+      if (timed) JDA_HIP(hipEventRecord(ev[2], st));
       finished = true;
       return run_dense();
     }
@@ -1017,7 +1026,7 @@ struct Pass {
     // machine: 2.65 ms vs 2.39 ms per 256-frame step -- half-size scans are less efficient and k_finish is
     // throughput bound itself)
     (void)scan_after;
-    JDA_HIP(hipEventRecord(ev[1], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[1], st));
     if (pe->fast_scan) {
       const int handoff = (int)kn().handoff;
       const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
@@ -1073,11 +1082,11 @@ struct Pass {
         }
       }
       lds_span = !side_pending && !(((lane & 1) && kn().lanes_reverse) && !small);   // LDS launches first, back to back
-      if (lds_span) JDA_HIP(hipEventRecord(ev[4], st));
+      if (lds_span && timed) JDA_HIP(hipEventRecord(ev[4], st));
       if (any_glb && !scan(2, -1, st)) return false;
       if (side_pending) JDA_HIP(hipStreamWaitEvent(st, ln->ev_side[1], 0));
     }
-    JDA_HIP(hipEventRecord(ev[2], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();
   }
 
@@ -1092,9 +1101,10 @@ struct Pass {
       const long long guess = std::min<long long>((long long)cap, (long long)(pred_tail * (double)nw * 1.1) + 64);
       if (!launch_finishers(guess)) return false;
       predicted = true;
-      if (!issue_counters()) return false;
       const double po = pred_out >= 0 ? pred_out : 0.0;
-      return issue_results(0, std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64));
+      const size_t to = std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64);
+      if (kn().kernel_d2h && dets && to > 0) return issue_results(0, to, true);      // counters + prefix in one launch
+      return issue_counters() && issue_results(0, to);
     }
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
     return read_counter(kCntTail);
@@ -1120,7 +1130,7 @@ struct Pass {
     w.segs = (const RagSeg*)(tab + ch.off_segs); w.blk = (const RagBlk*)(tab + ch.off_blk);
     w.img_off = (const unsigned long long*)(tab + ch.off_imgoff);
     if (!clear_counters()) return false;
-    JDA_HIP(hipEventRecord(ev[1], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[1], st));
     const int handoff = (int)kn().handoff;
     const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
     const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
@@ -1129,7 +1139,7 @@ struct Pass {
                                        l.blk_base, l.blk_n, st));
       rs->scan_launches++;
     }
-    JDA_HIP(hipEventRecord(ev[2], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();
   }
 
@@ -1203,7 +1213,7 @@ struct Pass {
   bool issue_counters() {
     if (counters_issued) return true;
     counters_issued = true;
-    JDA_HIP(hipEventRecord(ev[3], st));
+    if (timed) JDA_HIP(hipEventRecord(ev[3], st));
     if (kn().kernel_d2h) {
       const void* src[1] = {w.counters}; void* dst[1] = {h_cnt};
       const size_t nb[1] = {sizeof(unsigned long long) * kCntShards * kCntStride};
@@ -1215,7 +1225,7 @@ struct Pass {
   }
 
   // detections [from, to) of the device list -> the lane's pinned host arrays (asynchronous)
-  bool issue_results(size_t from, size_t to) {
+  bool issue_results(size_t from, size_t to, bool with_counters = false) {
     const int dim = hm().dim();
     if (!dets || to <= from) return true;
     HostPinned &hg = ln->h_gid, &hs = ln->h_score, &hh = ln->h_shape;
@@ -1223,10 +1233,11 @@ struct Pass {
         !hh.reserve(to * dim * sizeof(Real), from * dim * sizeof(Real))) return false;
     const size_t n = to - from;
     if (kn().kernel_d2h && from == 0) {          // (a 16-byte aligned start: the predicted prefix; a later rest goes by the copy engine)
-      const void* src[3] = {w.out_gid, w.out_score, w.out_shape};
-      void* dst[3] = {hg.p, hs.p, hh.p};
-      const size_t nb[3] = {n * 4, n * sizeof(Real), n * dim * sizeof(Real)};
-      JDA_HIP(launch_copy_out(src, dst, nb, 3, st));
+      const void* src[4] = {w.out_gid, w.out_score, w.out_shape, w.counters};
+      void* dst[4] = {hg.p, hs.p, hh.p, h_cnt};
+      const size_t nb[4] = {n * 4, n * sizeof(Real), n * dim * sizeof(Real), sizeof(unsigned long long) * kCntShards * kCntStride};
+      if (with_counters) { counters_issued = true; if (timed) JDA_HIP(hipEventRecord(ev[3], st)); }
+      JDA_HIP(launch_copy_out(src, dst, nb, with_counters ? 4 : 3, st));
       out_copied = to;
       results_pending = true;
       return true;
@@ -1470,6 +1481,7 @@ static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const ui
     for (auto& p : ps) if (!p.after_counters() || !p.collect()) return false;
     // scan time of the round: the lanes' scans run side by side, so their union (first scan
     // start to last scan end) is what one step spends scanning, not the sum of the spans
+    if (!ps[0].timed) continue;
     float ms_scan = 0;
     for (auto& p : ps) {
       float ms = 0;
@@ -1780,6 +1792,7 @@ static int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   }
   RawDets<float> dets;
   RunStats rs;
+  rs.timed = opt && opt->stats;
   if (!run_device<float>(c, lanes, pe, d_frames, stride, n, true, th, opt ? (hipStream_t)opt->hip_stream : nullptr, &dets, nullptr, &rs, host))
     return -1;
   const double post_ms = post_c(c, sp, dets, n, opt, out);
@@ -1829,6 +1842,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   pb.reset();
   pb.sp = sp; pb.pe = pe;
   pb.n = n; pb.opt_set = opt != nullptr; if (opt) pb.opt = *opt;
+  pb.rs.timed = opt && opt->stats;        // (a flag here: the statistics themselves are handed to Wait)
   pb.opt.stats = nullptr;
   pb.t_submit = now_ms();
   Pass<float>& p = pb.pass;
@@ -1896,10 +1910,12 @@ static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out)
   double post_ms = 0;
   if (ok) {
     float ms_scan = 0, ms_all = 0;
-    (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
-    (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    if (p.timed) {
+      (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+      (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    }
     pb.rs.scan_ms += ms_scan; pb.rs.gpu_ms += ms_all;
-    if (p.lds_span) { float ms = 0; if (hipEventElapsedTime(&ms, p.ev[1], p.ev[4]) == hipSuccess) pb.rs.scan_lds_ms += ms; }
+    if (p.lds_span && p.timed) { float ms = 0; if (hipEventElapsedTime(&ms, p.ev[1], p.ev[4]) == hipSuccess) pb.rs.scan_lds_ms += ms; }
     post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
     fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
     if (stats) stats->call_ms = now_ms() - pb.t_submit;
@@ -2335,8 +2351,10 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     sl.busy = false;
     if (!p.after_tail() || !p.issue_counters() || !p.after_counters() || !p.collect()) return false;
     float ms_scan = 0, ms_all = 0;
-    (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
-    (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    if (p.timed) {
+      (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+      (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    }
     sl.rs.scan_ms += ms_scan; sl.rs.gpu_ms += ms_all;
     post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
     add_stats(&total, sl.rs);
@@ -2347,7 +2365,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     const int lane = ci % lanes;
     Slot& sl = slots[lane];
     if (sl.busy && !collect(sl)) { ok = false; break; }
-    sl.dets = RawDets<float>(); sl.rs = RunStats();
+    sl.dets = RawDets<float>(); sl.rs = RunStats(); sl.rs.timed = opt && opt->stats;
     Lane* ln = held.v[lane];
     if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
     if (sl.ch.windows == 0) {                        // images too small for any window
