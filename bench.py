@@ -571,7 +571,9 @@ def main():
                        "single_caller_ms_per_step": single_info["ms_per_step"],
                        "single_caller_windows_per_s": single_info["windows_per_s"],
                        "host_frames_windows_per_s": host_info["pageable_windows_per_s"] if host_info else None,
-                       "host_frames_pinned_windows_per_s": host_info["pinned_windows_per_s"] if host_info else None},
+                       "host_frames_pinned_windows_per_s": host_info["pinned_windows_per_s"] if host_info else None,
+                       "host_frames_pinned_over_value": (host_info["pinned_windows_per_s"] / casc_info["windows_per_s"])
+                                                        if host_info else None},
             "roofline": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
