@@ -8,7 +8,6 @@ mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --no-cpu --no-allpass > $O/bench_run2.json 2>> $O/bench.err
-timeout 600 python bench.py --no-cpu --no-allpass > $O/bench_run3.json 2>> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
 V="python $R/tools/variants.py"
 export VAR_STEPS=10
@@ -41,3 +40,4 @@ timeout 600 python tools/fddb_bench.py --threads 8 --dialect c > $O/fddb_loop.js
 timeout 600 python -m pytest tests/test_reentrant.py tests/test_gpu_parity.py -q -s -k "concurrent or config2_at_its_stated" 2>&1 | grep -E "calls/s|config2 full|passed|failed" > $O/concurrency_config2.txt
 bash tools/single_trace.sh $TAG/single > /dev/null 2>&1
 du -sh $O; head -12 $O/kernel_trace_one_lane_stats.txt | cut -c1-170; cat $O/concurrency_config2.txt; cat $O/ragged.jsonl | cut -c1-200
+bash tools/host_trace.sh > $O/host_trace.txt 2>&1; cp gpurun_out/host_timeline_pinned.txt gpurun_out/host_timeline_pageable.txt $O/ 2>/dev/null
