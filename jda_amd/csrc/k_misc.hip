@@ -115,14 +115,22 @@ __global__ __launch_bounds__(256) void k_repack(const uint8_t* __restrict__ raw,
   if (y >= im.h) return;
   const uint8_t* s = raw + im.src_off + (size_t)y * im.w;
   uint32_t* d = (uint32_t*)(dst + im.dst_off + (size_t)y * pitch);
-  const int nd = (im.w + 3) >> 2;
-  for (int j = threadIdx.x & 63; j < nd; j += 64) {
-    const int x = 4 * j;
-    uint32_t v = s[x];
-    if (x + 1 < im.w) v |= (uint32_t)s[x + 1] << 8;
-    if (x + 2 < im.w) v |= (uint32_t)s[x + 2] << 16;
-    if (x + 3 < im.w) v |= (uint32_t)s[x + 3] << 24;
-    d[j] = v;
+  // 8 output bytes per thread and step: two dword loads at the row's own (arbitrary) alignment -- global memory takes
+  // unaligned dwords on this target -- and one aligned 8-byte store; the row's last bytes one by one
+  const int nq = im.w >> 3;
+  uint2* d2 = (uint2*)d;
+  for (int j = threadIdx.x & 63; j < nq; j += 64) {
+    uint2 v;
+    __builtin_memcpy(&v, s + 8 * j, 8);
+    d2[j] = v;
+  }
+  const int x0 = nq << 3;
+  if ((threadIdx.x & 63) == 0 && x0 < im.w) {
+    uint32_t v0 = 0, v1 = 0;
+    for (int k = 0; k < 4; k++) if (x0 + k < im.w) v0 |= (uint32_t)s[x0 + k] << (8 * k);
+    for (int k = 0; k < 4; k++) if (x0 + 4 + k < im.w) v1 |= (uint32_t)s[x0 + 4 + k] << (8 * k);
+    d[x0 >> 2] = v0;
+    if (x0 + 4 < im.w) d[(x0 >> 2) + 1] = v1;
   }
 }
 
