@@ -1049,6 +1049,43 @@ def test_submit_host_frames_pageable_and_pinned(built, gpu, model_file):
         _compare_detect(x, y)
 
 
+@pytest.mark.parametrize("h2d_stream,kernel_d2h", [(1, 1), (0, 0), (2, 1), (3, 0)])
+def test_host_frame_stream_upload_and_copy_out_modes(built, gpu, model_file, h2d_stream, kernel_d2h):
+    """The host-frame stream under every upload mode (own stream + host wait / lane stream / own stream + device wait /
+    + event wait) and both result paths (copy-out kernel, copy engine): three tickets in flight over batches large
+    enough to take the upload stream (>= h2d_min_bytes), pinned and pageable, always the synchronous call's results."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 70, 9, 5), 8, seed=121, cart_th=-0.9, norm_every=9)
+    frames = [synth.make_frames(24, 320, 240, seed=122 + j) for j in range(3)]          # 1.8 MB per batch
+    c = api.Cascador(p)
+    c.set_option("h2d_stream", h2d_stream); c.set_option("kernel_d2h", kernel_d2h)
+    c.set_option("h2d_min_bytes", 1 << 20)
+    assert c.get_option("h2d_stream") == h2d_stream
+    want = [c.detect_batch(f, stats=True) for f in frames]
+    pins = [torch.from_numpy(f).pin_memory() for f in frames]
+    for src in (frames, [t.numpy() for t in pins]):
+        order = [0, 1, 2, 1, 0, 2, 2]
+        q = [c.submit_batch_host(src[order[0]]), c.submit_batch_host(src[order[1]], stats=True)]
+        for i, j in enumerate(order):
+            if i + 2 < len(order):
+                q.append(c.submit_batch_host(src[order[i + 2]], stats=(i % 2 == 1)))
+            got, st = c.wait_batch(q.pop(0), stats=True)
+            for x, y in zip(got, want[j][0]):
+                _compare_detect(x, y)
+            for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n", "handoff_n"):
+                assert st[k] == want[j][1][k], (i, k)
+            # the device spans are only measured when Submit was told so (opt->stats as a flag)
+            timed = i % 2 == 1
+            assert (st["gpu_ms"] > 0) == timed, (i, st["gpu_ms"])
+    # single frames (below h2d_min_bytes: the caller's lane) next to a pending ticket
+    t = c.submit_batch_host(frames[0])
+    one = c.detect(frames[1][0])
+    _compare_detect(one, want[1][0][0])
+    for x, y in zip(c.wait_batch(t), want[0][0]):
+        _compare_detect(x, y)
+
+
 def test_batch_too_large_for_32bit_window_ids_is_refused(built, gpu, model_file, monkeypatch):
     """Detections carry a 32-bit window id over the whole batch; a batch whose frames x windows exceeds 2^32
     must fail loudly instead of wrapping (the test_wpf_scale option inflates the count the guard sees)."""
