@@ -90,6 +90,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
   X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
   X(h2d_min_bytes, "JDA_H2D_MIN_BYTES", 8 << 20) /* ... for uploads of at least this many bytes */ \
+  X(ragged_uploader, "JDA_RAGGED_UPLOADER", 1) /* ragged job from one packed host buffer: a helper thread uploads chunk after chunk */ \
   X(kernel_d2h, "JDA_KERNEL_D2H", 1)        /* counters and detections -> pinned host memory by a kernel, not the copy engine */ \
   X(filter0, "JDA_FILTER0", 1)              /* large hand-off queues: k_filter0 + k_finish(survivors) instead of two k_finish passes */ \
   X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
@@ -873,6 +874,7 @@ struct RaggedChunk {
   const uint8_t* d_raw = nullptr;                    // the base their RagImg::src_off refer to on the device
   const int* widths = nullptr; const int* heights = nullptr;      // of the chunk's images
   bool host_contiguous = false;         // the host images lie back to back in memory in RagImg::src_off order
+  const uint8_t* d_uploaded = nullptr;  // the chunk's tight images are (being) uploaded here by the job's helper thread
 };
 
 // One sub-batch of frames going through the device pipeline on one lane (stream + workspace).
@@ -1118,7 +1120,9 @@ struct Pass {
     uint8_t* tab = (uint8_t*)ln->rag_tab.p;
     JDA_HIP(hipMemcpyAsync(tab, ln->h_tab.p, ch.table_bytes, hipMemcpyHostToDevice, st));
     const uint8_t* raw = ch.d_raw;
-    if (ch.host_imgs) {
+    if (ch.d_uploaded) {
+      raw = ch.d_uploaded;              // (detect_ragged waited for the upload on the host before it called this)
+    } else if (ch.host_imgs) {
       // tight images -> device: one copy when they lie back to back in the caller's memory, else through the lane's
       // pinned staging buffer (filled by build_chunk)
       const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : ln->h_raw.p;
@@ -1948,6 +1952,8 @@ struct RaggedJob {
   ScanPlan levels;                  // global level list; nx, ny = nominal (mean) grids, width = pitch
   std::vector<int> n_lv;            // levels image i has (a prefix of the global list)
   PlanEntry* pe = nullptr;
+  uint8_t* d_job_raw = nullptr;     // host job with a helper thread: every chunk's tight images go here ...
+  std::vector<size_t> raw_off;      // ... chunk k at d_job_raw + raw_off[k]
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -2128,7 +2134,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   ch->raw_bytes = job.host_imgs ? src : 0;
   ch->host_contiguous = contiguous;
   if (!ln->rag_frames.reserve(ch->frame_bytes)) return false;
-  if (job.host_imgs) {
+  if (job.host_imgs && !job.d_job_raw) {
     if (!ln->rag_raw.reserve(src + 16)) return false;
     if (!contiguous) {
       if (!ln->h_raw.reserve(src + 16)) return false;
@@ -2346,6 +2352,54 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   LaneSet held(c);
   if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0)) return -1;
   bool ok = true;
+
+  // ---- host images in ONE packed buffer, several chunks: a helper thread uploads chunk after chunk into a buffer of
+  //      the job (the first lane's) on the cascador's upload stream and waits for each on the host; this thread builds
+  //      tables, enqueues passes and post-processes meanwhile, and only waits for a chunk's pixels right before it
+  //      enqueues that chunk.  (Uploads issued here would block this thread for the length of every pageable copy.) ----
+  struct Uploader {
+    std::thread th;
+    std::mutex mu; std::condition_variable cv;
+    int ready = 0;                 // chunks [0, ready) are on the device
+    bool failed = false, stop = false;
+    std::string err;
+    ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
+  } up;
+  if (host_imgs && n_chunks > 1 && c->kn.ragged_uploader) {
+    bool packed = true;
+    size_t total = 0;
+    for (int i = 0; i < n && packed; i++) {
+      if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { packed = false; break; }
+      if (i > 0 && host_imgs[i] != host_imgs[i - 1] + (size_t)widths[i - 1] * heights[i - 1]) packed = false;
+      total += (size_t)widths[i] * heights[i];
+    }
+    if (packed && held.v[0]->rag_raw.reserve(total + 16)) {
+      job.d_job_raw = (uint8_t*)held.v[0]->rag_raw.p;
+      job.raw_off.assign(n_chunks + 1, 0);
+      for (int k = 0; k < n_chunks; k++) job.raw_off[k + 1] = (size_t)(host_imgs[starts[k + 1] - 1] - host_imgs[0]) +
+                                                              (size_t)widths[starts[k + 1] - 1] * heights[starts[k + 1] - 1];
+      const int dev = c->device;
+      up.th = std::thread([&, dev]() {
+        bool good = hipSetDevice(dev) == hipSuccess;
+        for (int k = 0; k < n_chunks && good; k++) {
+          { std::lock_guard<std::mutex> lk(up.mu); if (up.stop) return; }
+          const double t_up = now_ms();
+          {
+            std::lock_guard<std::mutex> lk(c->h2d_mu);
+            if (!c->h2d) good = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking) == hipSuccess;
+            good = good && hipMemcpyAsync(job.d_job_raw + job.raw_off[k], host_imgs[0] + job.raw_off[k], job.raw_off[k + 1] - job.raw_off[k],
+                                          hipMemcpyHostToDevice, c->h2d) == hipSuccess;
+            good = good && hipStreamSynchronize(c->h2d) == hipSuccess;
+          }
+          if (c->kn.debug_times) fprintf(stderr, "[jda] ragged upload %d: %.3f MB at %.3f..%.3f ms\n", k, (job.raw_off[k + 1] - job.raw_off[k]) / 1e6, t_up - t_call, now_ms() - t_call);
+          std::lock_guard<std::mutex> lk(up.mu);
+          if (good) up.ready = k + 1;
+          else { up.failed = true; up.err = std::string("upload of a ragged chunk failed: ") + hipGetErrorString(hipGetLastError()); }
+          up.cv.notify_all();
+        }
+      });
+    }
+  }
   auto collect = [&](Slot& sl) -> bool {
     Pass<float>& p = sl.pass;
     sl.busy = false;
@@ -2386,9 +2440,18 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
     p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
     p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+    if (job.d_job_raw) {
+      const double t_w = now_ms();
+      std::unique_lock<std::mutex> lk(up.mu);
+      up.cv.wait(lk, [&] { return up.ready > ci || up.failed; });
+      if (c->kn.debug_times) fprintf(stderr, "[jda] ragged chunk %d: waited for its pixels %.3f..%.3f ms\n", ci, t_w - t_call, now_ms() - t_call);
+      if (up.failed) { fail(up.err); ok = false; break; }
+      sl.ch.d_uploaded = job.d_job_raw + job.raw_off[ci];
+    }
     if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { ok = false; break; }
     sl.busy = true;
   }
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: all chunks issued at %.3f ms\n", now_ms() - t_call);
   // drain in chunk order
   for (int k = 0; k < lanes && ok; k++) {
     Slot& sl = slots[(n_chunks + k) % lanes];
