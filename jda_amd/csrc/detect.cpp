@@ -2330,16 +2330,28 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   //      in 16 bits), walked through up to three lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
   //      the host builds and issues chunk i and post-processes chunk i-3 ----
   const DevPlan& hp = job.pe->hp;
+  // host images in one packed buffer (every image right behind the one before): uploaded by a helper thread, below
+  bool packed = host_imgs != nullptr && c->kn.ragged_uploader != 0;
+  size_t packed_bytes = 0;
+  for (int i = 0; i < n && packed; i++) {
+    if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { packed = false; break; }
+    if (i > 0 && host_imgs[i] != host_imgs[i - 1] + (size_t)widths[i - 1] * heights[i - 1]) packed = false;
+    packed_bytes += (size_t)widths[i] * heights[i];
+  }
   std::vector<int> starts;
   {
     long long wsum = 0; int cnt = 0;
-    const long long target = std::max<long long>(1, c->kn.ragged_chunk_windows);
+    const long long full = std::max<long long>(1, c->kn.ragged_chunk_windows);
+    long long target = full;
     starts.push_back(0);
     for (int i = 0; i < n; i++) {
       long long wi = 0;
       for (int l = 0; l < job.n_lv[i]; l++)
         wi += (long long)((widths[i] - hp.lv[l].win) / hp.lv[l].step + 1) * ((heights[i] - hp.lv[l].win) / hp.lv[l].step + 1);
       if (wi > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
+      // (a job whose pixels still have to come over the link starts with a quarter and a half chunk: the GPU has work
+      // after a quarter of a chunk's upload time instead of a whole one)
+      if (packed) target = starts.size() == 1 ? full / 4 : (starts.size() == 2 ? full / 2 : full);
       if (cnt > 0 && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
       wsum += wi; cnt++;
     }
@@ -2365,15 +2377,8 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     std::string err;
     ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
   } up;
-  if (host_imgs && n_chunks > 1 && c->kn.ragged_uploader) {
-    bool packed = true;
-    size_t total = 0;
-    for (int i = 0; i < n && packed; i++) {
-      if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { packed = false; break; }
-      if (i > 0 && host_imgs[i] != host_imgs[i - 1] + (size_t)widths[i - 1] * heights[i - 1]) packed = false;
-      total += (size_t)widths[i] * heights[i];
-    }
-    if (packed && held.v[0]->rag_raw.reserve(total + 16)) {
+  if (packed && n_chunks > 1) {
+    if (held.v[0]->rag_raw.reserve(packed_bytes + 16)) {
       job.d_job_raw = (uint8_t*)held.v[0]->rag_raw.p;
       job.raw_off.assign(n_chunks + 1, 0);
       for (int k = 0; k < n_chunks; k++) job.raw_off[k + 1] = (size_t)(host_imgs[starts[k + 1] - 1] - host_imgs[0]) +
