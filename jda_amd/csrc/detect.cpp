@@ -91,6 +91,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
   X(h2d_min_bytes, "JDA_H2D_MIN_BYTES", 8 << 20) /* ... for uploads of at least this many bytes */ \
   X(ragged_uploader, "JDA_RAGGED_UPLOADER", 1) /* ragged job from one packed host buffer: a helper thread uploads chunk after chunk */ \
+  X(ragged_stage_threads, "JDA_RAGGED_STAGE_THREADS", 4) /* ... and this many threads gather separate host arrays into its pinned buffers */ \
   X(kernel_d2h, "JDA_KERNEL_D2H", 1)        /* counters and detections -> pinned host memory by a kernel, not the copy engine */ \
   X(filter0, "JDA_FILTER0", 1)              /* large hand-off queues: k_filter0 + k_finish(survivors) instead of two k_finish passes */ \
   X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
@@ -2330,13 +2331,13 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   //      in 16 bits), walked through up to three lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
   //      the host builds and issues chunk i and post-processes chunk i-3 ----
   const DevPlan& hp = job.pe->hp;
-  // host images in one packed buffer (every image right behind the one before): uploaded by a helper thread, below
-  bool packed = host_imgs != nullptr && c->kn.ragged_uploader != 0;
-  size_t packed_bytes = 0;
-  for (int i = 0; i < n && packed; i++) {
-    if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { packed = false; break; }
+  // host images: uploaded by a helper thread, below (packed = every image right behind the one before in memory)
+  bool helper = host_imgs != nullptr && c->kn.ragged_uploader != 0, packed = helper;
+  std::vector<size_t> tight(helper ? (size_t)n + 1 : 0, 0);       // image i at tight[i] of the job's tight image buffer
+  for (int i = 0; i < n && helper; i++) {
+    if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { helper = false; break; }
     if (i > 0 && host_imgs[i] != host_imgs[i - 1] + (size_t)widths[i - 1] * heights[i - 1]) packed = false;
-    packed_bytes += (size_t)widths[i] * heights[i];
+    tight[i + 1] = tight[i] + (size_t)widths[i] * heights[i];
   }
   std::vector<int> starts;
   {
@@ -2351,7 +2352,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
       if (wi > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
       // (a job whose pixels still have to come over the link starts with a quarter and a half chunk: the GPU has work
       // after a quarter of a chunk's upload time instead of a whole one)
-      if (packed) target = starts.size() == 1 ? full / 4 : (starts.size() == 2 ? full / 2 : full);
+      if (helper) target = starts.size() == 1 ? full / 4 : (starts.size() == 2 ? full / 2 : full);
       if (cnt > 0 && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
       wsum += wi; cnt++;
     }
@@ -2365,10 +2366,13 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
   if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0)) return -1;
   bool ok = true;
 
-  // ---- host images in ONE packed buffer, several chunks: a helper thread uploads chunk after chunk into a buffer of
-  //      the job (the first lane's) on the cascador's upload stream and waits for each on the host; this thread builds
-  //      tables, enqueues passes and post-processes meanwhile, and only waits for a chunk's pixels right before it
-  //      enqueues that chunk.  (Uploads issued here would block this thread for the length of every pageable copy.) ----
+  // ---- host images, several chunks: a helper thread brings chunk after chunk into a buffer of the job (the first
+  //      lane's) on the cascador's upload stream and waits for each upload on the host; this thread builds tables,
+  //      enqueues passes and post-processes meanwhile, and only waits for a chunk's pixels right before it enqueues that
+  //      chunk.  (Issued here, every pageable upload blocked this thread for a millisecond, and staging 2,845 separate
+  //      arrays with one memcpy loop took longer than the GPU needs for the job.)  Images that lie back to back go up
+  //      straight from the caller's memory; separate arrays are gathered into two pinned buffers (the first two lanes')
+  //      by `ragged_stage_threads` copy threads, chunk k+1 while chunk k is on the link. ----
   struct Uploader {
     std::thread th;
     std::mutex mu; std::condition_variable cv;
@@ -2377,31 +2381,63 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     std::string err;
     ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
   } up;
-  if (packed && n_chunks > 1) {
-    if (held.v[0]->rag_raw.reserve(packed_bytes + 16)) {
+  if (helper && n_chunks > 1 && held.v[0]->rag_raw.reserve(tight[n] + 16)) {
+    size_t most = 0;
+    job.raw_off.assign(n_chunks + 1, 0);
+    for (int k = 0; k < n_chunks; k++) { job.raw_off[k + 1] = tight[starts[k + 1]]; most = std::max(most, job.raw_off[k + 1] - job.raw_off[k]); }
+    if (packed || (held.v[0]->h_raw.reserve(most + 16) && held.v[1]->h_raw.reserve(most + 16))) {
       job.d_job_raw = (uint8_t*)held.v[0]->rag_raw.p;
-      job.raw_off.assign(n_chunks + 1, 0);
-      for (int k = 0; k < n_chunks; k++) job.raw_off[k + 1] = (size_t)(host_imgs[starts[k + 1] - 1] - host_imgs[0]) +
-                                                              (size_t)widths[starts[k + 1] - 1] * heights[starts[k + 1] - 1];
       const int dev = c->device;
-      up.th = std::thread([&, dev]() {
+      const int copy_threads = (int)std::max<long long>(1, std::min<long long>(16, c->kn.ragged_stage_threads));
+      uint8_t* stage[2] = {(uint8_t*)held.v[0]->h_raw.p, (uint8_t*)held.v[1]->h_raw.p};
+      up.th = std::thread([&, dev, copy_threads, stage]() {
         bool good = hipSetDevice(dev) == hipSuccess;
+        auto publish = [&](int k_done) {
+          std::lock_guard<std::mutex> lk(up.mu);
+          if (good) up.ready = k_done;
+          else { up.failed = true; up.err = std::string("upload of a ragged chunk failed: ") + hipGetErrorString(hipGetLastError()); }
+          up.cv.notify_all();
+        };
+        auto drain = [&]() {          // the uploads queued so far are on the device
+          std::lock_guard<std::mutex> lk(c->h2d_mu);
+          good = good && hipStreamSynchronize(c->h2d) == hipSuccess;
+        };
         for (int k = 0; k < n_chunks && good; k++) {
           { std::lock_guard<std::mutex> lk(up.mu); if (up.stop) return; }
           const double t_up = now_ms();
+          const size_t bytes = job.raw_off[k + 1] - job.raw_off[k];
+          const uint8_t* src = host_imgs[0] + job.raw_off[k];
+          if (!packed) {
+            // gather the chunk's images into pinned buffer k & 1 (its last upload, chunk k-2, was drained one round ago)
+            uint8_t* dst = stage[k & 1];
+            const int a = starts[k], b = starts[k + 1];
+            auto copy_range = [&](int i0, int i1) {
+              for (int i = i0; i < i1; i++) std::memcpy(dst + (tight[i] - tight[a]), host_imgs[i], tight[i + 1] - tight[i]);
+            };
+            std::vector<std::thread> ts;
+            int i0 = a;
+            for (int t = 0; t < copy_threads && i0 < b; t++) {
+              const size_t upto = tight[a] + bytes * (size_t)(t + 1) / (size_t)copy_threads;
+              int i1 = i0;
+              while (i1 < b && (tight[i1 + 1] <= upto || t == copy_threads - 1)) i1++;
+              if (i1 == i0) continue;
+              if (t == copy_threads - 1 || i1 == b) { copy_range(i0, b); i0 = b; }
+              else { ts.emplace_back(copy_range, i0, i1); i0 = i1; }
+            }
+            if (i0 < b) copy_range(i0, b);
+            for (auto& t : ts) t.join();
+            src = dst;
+          }
+          if (k > 0 && !packed) { drain(); publish(k); }           // chunk k-1 has arrived while this one was gathered
           {
             std::lock_guard<std::mutex> lk(c->h2d_mu);
             if (!c->h2d) good = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking) == hipSuccess;
-            good = good && hipMemcpyAsync(job.d_job_raw + job.raw_off[k], host_imgs[0] + job.raw_off[k], job.raw_off[k + 1] - job.raw_off[k],
-                                          hipMemcpyHostToDevice, c->h2d) == hipSuccess;
-            good = good && hipStreamSynchronize(c->h2d) == hipSuccess;
+            good = good && hipMemcpyAsync(job.d_job_raw + job.raw_off[k], src, bytes, hipMemcpyHostToDevice, c->h2d) == hipSuccess;
           }
-          if (c->kn.debug_times) fprintf(stderr, "[jda] ragged upload %d: %.3f MB at %.3f..%.3f ms\n", k, (job.raw_off[k + 1] - job.raw_off[k]) / 1e6, t_up - t_call, now_ms() - t_call);
-          std::lock_guard<std::mutex> lk(up.mu);
-          if (good) up.ready = k + 1;
-          else { up.failed = true; up.err = std::string("upload of a ragged chunk failed: ") + hipGetErrorString(hipGetLastError()); }
-          up.cv.notify_all();
+          if (packed || k == n_chunks - 1) { drain(); publish(k + 1); }
+          if (c->kn.debug_times) fprintf(stderr, "[jda] ragged upload %d: %.3f MB at %.3f..%.3f ms\n", k, bytes / 1e6, t_up - t_call, now_ms() - t_call);
         }
+        if (!good) publish(0);
       });
     }
   }
