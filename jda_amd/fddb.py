@@ -105,31 +105,69 @@ def list_job(fddb_dir, folds=range(1, 11)):
     return job
 
 
-def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, world=1, device=None, log=None):
+def detect_fold_ragged(casc, grays, c_call=None):
+    """Dialect C, one fold's (or shard's) images as ONE jdaDetectBatchRagged job instead of one jdaDetect per image
+    (test.cpp:100-170 calls Detect image by image; the results are the same, image by image).
+    -> ([(rects, scores, shapes)] per image, stats of the job)"""
+    call = dict(scale=1.25, min_size=40, max_size=-1, th=-0.5)
+    call.update(c_call or {})
+    res, st = casc.detect_ragged(grays, call["scale"], call["min_size"], call["max_size"], call["th"], stats=True)
+    out = []
+    for r in res:
+        bb = r["bboxes"]
+        rects = np.concatenate([bb, bb[:, 2:3]], 1) if len(bb) else np.zeros((0, 4), np.int32)
+        out.append((rects, r["scores"].astype(np.float64), r["shapes"].astype(np.float64)))
+    return out, st
+
+
+def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, world=1, device=None, log=None,
+        ragged=None):
     """The whole `jda fddb` run.  With world > 1 the images are split in contiguous blocks over the
     ranks, every rank detects its block, and the (image, rect, score, landmarks) rows
-    are gathered on rank 0, which writes the ten fold-XX-out.txt files.  Returns per-fold stats on rank 0."""
+    are gathered on rank 0, which writes the ten fold-XX-out.txt files.  Returns per-fold stats on rank 0.
+    ragged (default: on for dialect "c"): the images of a fold that fall into this rank's block are decoded first and
+    go through the ragged entry as one job; off: one call per image, like the reference's loop."""
     from . import dist as jdist
     job = list_job(fddb_dir, folds)
     lo, hi = jdist.shard_range(len(job), rank, world)
     L = casc.L
     rows, local_stats, skipped = [], {}, []
-    for idx in range(lo, hi):
-        fold, image_id = job[idx]
-        gray = load_gray(os.path.join(fddb_dir, "images", image_id + ".jpg"))
-        if gray is None:
-            skipped.append(idx)
-            continue
-        rects, scores, shapes, st = detect_image(casc, gray, dialect, params)
+    if ragged is None:
+        ragged = dialect == "c" and hasattr(casc, "detect_ragged")
+    pending = []                                              # (idx, gray) of the fold being collected
+
+    def flush(fold):
+        if not pending:
+            return []
+        per_image, st = detect_fold_ragged(casc, [g for _, g in pending])
         local_stats.setdefault(fold, FoldStats()).add(st)
+        done = [(i, r) for (i, _), r in zip(pending, per_image)]
+        del pending[:]
+        return done
+
+    def emit(idx, rects, scores, shapes):
         n = len(scores)
         m = np.empty((n, 6 + 2 * L), np.float64)
         m[:, 0] = idx; m[:, 1:5] = rects; m[:, 5] = scores; m[:, 6:] = shapes
         rows.append(m)
-        # images with no detection still need their "id\n0\n" block: a marker row with rect w = -1
-        if n == 0:
+        if n == 0:          # images with no detection still need their "id\n0\n" block: a marker row with rect w = -1
             z = np.zeros((1, 6 + 2 * L)); z[0, 0] = idx; z[0, 3] = -1
             rows.append(z)
+
+    for idx in range(lo, hi):
+        fold, image_id = job[idx]
+        gray = load_gray(os.path.join(fddb_dir, "images", image_id + ".jpg"))
+        if gray is None:
+            skipped.append(idx)                             # unreadable image: skipped like the reference
+        elif ragged:
+            pending.append((idx, gray))
+        else:
+            rects, scores, shapes, st = detect_image(casc, gray, dialect, params)
+            local_stats.setdefault(fold, FoldStats()).add(st)
+            emit(idx, rects, scores, shapes)
+        if ragged and (idx + 1 == hi or job[idx + 1][0] != fold):
+            for i, (rects, scores, shapes) in flush(fold):
+                emit(i, rects, scores, shapes)
     mat = np.concatenate(rows) if rows else np.zeros((0, 6 + 2 * L))
     stat_rows = np.array([[f, s.patch_n, s.face_patch_n, s.nonface_patch_n, s.cart_gothrough_n]
                           for f, s in sorted(local_stats.items())], np.float64).reshape(-1, 5)

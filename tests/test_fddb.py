@@ -111,16 +111,17 @@ def test_run_sharded_over_gloo_matches_single(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dialect", ["cpp", "c"])
-def test_fddb_end_to_end_gpu(built, model_file, tmp_path, dialect):
-    """Real detector: every fold file equals what the oracle produces for the same decoded images."""
+@pytest.mark.parametrize("dialect,ragged", [("cpp", None), ("c", None), ("c", False)])
+def test_fddb_end_to_end_gpu(built, model_file, tmp_path, dialect, ragged):
+    """Real detector: every fold file equals what the oracle produces for the same decoded images (dialect C: a fold as
+    one ragged job -- the default -- and image by image like the reference's loop)."""
     from jda_amd import api, fddb
     from oracle.pyoracle import Oracle
     d = str(tmp_path / "fddb")
     fddb.make_synthetic_fddb(d, n_images=12, seed=4, max_side=160, fmt="PNG")
     p, _ = model_file((3, 20, 5, 4), 8, seed=9, cart_th=-0.7, norm_every=6)
     c, o = api.Cascador(p), Oracle(p)
-    stats = fddb.run(c, d, dialect=dialect)
+    stats = fddb.run(c, d, dialect=dialect, ragged=ragged)
     total = 0
     for i in range(1, 11):
         want = ""
