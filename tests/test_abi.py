@@ -120,3 +120,32 @@ def test_dist_library_exports_its_header(built):
         assert hasattr(L, n), n
     deps = subprocess.run(["readelf", "-d", os.path.join(ROOT, "jda_amd", "libjda.so")], capture_output=True, text=True).stdout
     assert "rccl" not in deps and "torch" not in deps
+
+
+def test_options_round_trip_and_start_from_the_environment(built, model_file, monkeypatch):
+    """jdaSetOption / jdaGetOption (include/jda.h): per cascador, seeded ONCE from JDA_<KEY> when the cascador is created,
+    unknown keys refused.  No GPU needed: the options live in the host object."""
+    from jda_amd import api
+    p, _ = model_file((2, 8, 5, 3), 8, seed=1)
+    documented = {"handoff": 128, "lanes": 2, "dense": 1, "plan_cache": 64, "predict": 1, "wide_max": 1024,
+                  "wide_busy_max": 2, "ragged_chunk_windows": 6000000, "ragged_tile_grow_pct": 150, "filter0": 1,
+                  "kernel_d2h": 1, "h2d_stream": 1, "h2d_min_bytes": 8 << 20, "ragged_uploader": 1,
+                  "ragged_stage_threads": 4}
+    for k in list(os.environ):
+        if k.startswith("JDA_") and k not in ("JDA_LIB_PATH",):
+            monkeypatch.delenv(k)
+    c = api.Cascador(p)
+    for k, v in documented.items():
+        assert c.get_option(k) == v, k
+    monkeypatch.setenv("JDA_HANDOFF", "96"); monkeypatch.setenv("JDA_H2D_STREAM", "2")
+    c2 = api.Cascador(p)                                   # the environment is read when the cascador is created ...
+    assert c2.get_option("handoff") == 96 and c2.get_option("h2d_stream") == 2
+    assert c.get_option("handoff") == 128                  # ... and only then
+    monkeypatch.setenv("JDA_HANDOFF", "64")
+    assert c2.get_option("handoff") == 96
+    c2.set_option("handoff", 112)
+    assert c2.get_option("handoff") == 112 and c.get_option("handoff") == 128
+    with pytest.raises(api.JdaError):
+        c.set_option("no_such_option", 1)
+    assert api.lib.jdaGetOption(c.h, b"no_such_option") == -1
+    c.close(); c2.close()

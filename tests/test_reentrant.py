@@ -62,7 +62,7 @@ def test_concurrent_callers_share_one_cascador(built, gpu, tmp_path):
         for r in range(reps):
             _eq(got[t][r], want[(t + r) % 16], (t, r))
     print("jdaDetect calls/s: 1 thread %.0f, %d threads on one cascador %.0f (%.1fx)" % (one, n_thr, many, many / one))
-    assert many >= 2.5 * one, (one, many)        # (3.2x measured; 8 lanes share four hardware queues)
+    assert many >= 2.2 * one, (one, many)        # (2.6-3.3x measured over six boxes; 8 lanes share four hardware queues)
 
 
 def test_mixed_entries_run_side_by_side_on_one_cascador(built, gpu, model_file):
