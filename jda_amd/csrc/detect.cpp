@@ -2390,7 +2390,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
       const int dev = c->device;
       const int copy_threads = (int)std::max<long long>(1, std::min<long long>(16, c->kn.ragged_stage_threads));
       uint8_t* stage[2] = {(uint8_t*)held.v[0]->h_raw.p, (uint8_t*)held.v[1]->h_raw.p};
-      up.th = std::thread([&, dev, copy_threads, stage]() {
+      auto uploader = [&, dev, copy_threads, stage]() {
         bool good = hipSetDevice(dev) == hipSuccess;
         auto publish = [&](int k_done) {
           std::lock_guard<std::mutex> lk(up.mu);
@@ -2422,7 +2422,10 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
               while (i1 < b && (tight[i1 + 1] <= upto || t == copy_threads - 1)) i1++;
               if (i1 == i0) continue;
               if (t == copy_threads - 1 || i1 == b) { copy_range(i0, b); i0 = b; }
-              else { ts.emplace_back(copy_range, i0, i1); i0 = i1; }
+              else {
+                try { ts.emplace_back(copy_range, i0, i1); } catch (...) { copy_range(i0, i1); }   // (no thread to be had: copy here)
+                i0 = i1;
+              }
             }
             if (i0 < b) copy_range(i0, b);
             for (auto& t : ts) t.join();
@@ -2438,7 +2441,9 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
           if (c->kn.debug_times) fprintf(stderr, "[jda] ragged upload %d: %.3f MB at %.3f..%.3f ms\n", k, bytes / 1e6, t_up - t_call, now_ms() - t_call);
         }
         if (!good) publish(0);
-      });
+      };
+      try { up.th = std::thread(uploader); }
+      catch (...) { job.d_job_raw = nullptr; }          // (no thread to be had: the chunks upload themselves, as without a helper)
     }
   }
   auto collect = [&](Slot& sl) -> bool {
