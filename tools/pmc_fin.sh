@@ -11,6 +11,6 @@ for set in "TA_BUSY_avr TA_BUSY_max MemUnitBusy MemUnitStalled" "TCP_TOTAL_CACHE
   i=$((i+1)); rm -rf /tmp/pf
   timeout 90 rocprofv3 --kernel-trace --pmc $set -d /tmp/pf -- python $R/tools/variants.py "" > /dev/null 2> $O/err_$i.txt
   db=$(find /tmp/pf -name "*.db" | head -1)
-  [ -n "$db" ] && python $R/tools/rocpd_pmc.py $db | grep -E "k_finish|k_scan<float, 4, false, 2" | cut -c1-150 > $O/set_$i.txt || echo "no db for: $set" > $O/set_$i.txt
+  [ -n "$db" ] && python $R/tools/rocpd_pmc.py $db | grep -E "k_filter0|k_finish|k_scan<float, 4, false, 2" | cut -c1-150 > $O/set_$i.txt || echo "no db for: $set" > $O/set_$i.txt
 done
 cat $O/set_*.txt
