@@ -538,7 +538,7 @@ def main():
         lds_s = roof_info["scan_lds_ms_per_step"] * 1e-3
         lane_reads = roof_info["scan_lds_carts_per_step"] * lane_reads_per_cart
         achieved = lane_reads * 4 / lds_s / 1e9 if lds_s > 0 else 0.0
-        traffic, traffic_src, hbm_frac = None, None, None
+        traffic, traffic_src, hbm_frac, traffic_fresh = None, None, None, None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
@@ -548,6 +548,10 @@ def main():
                                "this command, NOT measured in this run" % tj.get("source", "r01"))
                 if traffic and lds_s > 0:
                     hbm_frac = traffic / lds_s / 1e9 / HBM_PEAK_GBPS
+                # the counters were taken on a particular build: say whether it is the device code this run uses
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_traffic
+                traffic_fresh = tj.get("kernel_sources_sha256") == pmc_traffic.kernel_sources_sha256()
             except Exception:
                 traffic = None
         scan_bytes_alg = roof_info["scan_lds_carts_per_step"] * ((D - 1) * 34 + 16)
@@ -577,6 +581,7 @@ def main():
             "roofline": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_from_this_device_code": traffic_fresh,
                          "kernel": "k_scan, the LDS-tiled launches of one step (one per tiled pyramid level)",
                          "what": "LDS crossbar bytes: (D-1)*3+2 = %d lane-reads of 4 B per window-cart x carts evaluated "
                                  "(device counter) / HIP-event span of the launches; peak = 128 B/clk/CU x 256 CUs x 2.4 GHz "

@@ -35,13 +35,24 @@ def group(name):
     return None
 
 
+def kernel_sources_sha256():
+    """Hash of the device code (csrc/*.hip, *.h) the counters were taken on: bench.py compares it with the sources it
+    runs on, so a traffic figure echoed from a stale file is flagged in the line."""
+    import glob, hashlib, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jda_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main(cf, cw, bf, bw, passes, tag, calib_bytes=1 << 30):
     passes = int(passes)
     f, wv = sums(cf, "FETCH_SIZE"), sums(cw, "WRITE_SIZE")
     pick = lambda d, sub: [sum(x) for x in zip(*[(c, v) for k, (c, v) in d.items() if sub in k])] or [0, 0.0]
     n4, r4 = pick(f, "calib_read4"); n16, r16 = pick(f, "calib_read16"); nw, w4 = pick(wv, "calib_write4")
     f4 = calib_bytes / (r4 / n4 * 1024.0); f16 = calib_bytes / (r16 / n16 * 1024.0); wf = calib_bytes / (w4 / nw * 1024.0)
-    out = {"source": tag, "unit": "bytes per step (one pass over the 256-frame batch)", "passes_profiled": passes,
+    out = {"source": tag, "kernel_sources_sha256": kernel_sources_sha256(), "unit": "bytes per step (one pass over the 256-frame batch)", "passes_profiled": passes,
            "calibration": {"buffer_bytes": calib_bytes, "fetch_factor_4B_per_lane": f4, "fetch_factor_16B_per_lane": f16,
                            "write_factor": wf}, "kernels": {}}
     bfetch, bwrite = sums(bf, "FETCH_SIZE"), sums(bw, "WRITE_SIZE")
