@@ -238,7 +238,8 @@ JDA_API int jdaDetectBatchSubmit(void *cascador, const unsigned char *d_frames, 
 JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaResult *out);
 
 /* Submit for frames in HOST memory (frames[i] is width*height bytes): the batch is copied to a staging buffer
- * of its ticket on that ticket's stream, then scanned like jdaDetectBatchSubmit.  The copy and the scan launches
+ * of its ticket (uploads of at least `h2d_min_bytes` go batch after batch through one upload stream of the cascador,
+ * smaller ones on the ticket's own stream), then scanned like jdaDetectBatchSubmit.  The copy and the scan launches
  * are issued by a helper thread AFTER this call has returned, so in EVERY case -- pageable or pinned frames --
  * both the frame bytes and the frames[] pointer array itself must stay valid and unchanged until
  * jdaDetectBatchWait for this ticket has returned (do not reuse a capture buffer or a stack array before that).

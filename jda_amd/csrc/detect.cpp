@@ -211,9 +211,8 @@ constexpr int kFinishTileWin = -1;
 // the copy is one more dependent step in front of them (measured: 1.816 ms of GPU time per step with tiles of 46, 57
 // or 72 pixels against 1.806 without)
 constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before k_finish takes over (JDA_HANDOFF)
-// tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for copy + kernels + host work = 3.8 ms,
-// the copy alone is 1.8 ms per batch, so the link is only kept busy with three in flight); also the chunks of a
-// ragged job that are in flight at once
+// tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for upload 1.4 ms + kernels 1.7 ms + host
+// work, so the link and the GPU are only both kept busy with three in flight)
 constexpr int kTickets = 3;
 constexpr int kRaggedLanes = 3;      // chunks of a ragged job in flight
 
@@ -839,7 +838,7 @@ struct RunStats {
 
 // Copies a run of host frames to the staging buffer (frame i at dst + i*stride) on a stream.
 // Frames that lie back to back in host memory (one array) go as ONE strided copy: 256 separate
-// 300-KB copies from pageable memory reach ~15 GB/s, one copy of the batch ~40 GB/s.
+// 300-KB copies from pageable memory reach ~15 GB/s, one copy of the batch 57 GB/s (tools/pcie_bw.py).
 static bool copy_frames_h2d(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes,
                             hipStream_t st) {
   for (int i = 0; i < n;) {
@@ -1875,7 +1874,7 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   };
   if (host_frames && c->kn.host_submit_thread) {
     // the copy + scan launches of this ticket on their own thread (joined by Wait): a pageable H2D copy blocks
-    // its caller for the whole transfer (1.8 ms per 256 frames 640x480), time in which the submitting thread can
+    // its caller for the whole transfer (1.4 ms per 256 frames 640x480), time in which the submitting thread can
     // already collect and post-process the other ticket
     commit();
     pb.issue_ok = true; pb.issue_err.clear();
