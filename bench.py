@@ -240,8 +240,17 @@ def main():
             flag = torch.tensor([ok if int(head[0].item()) == 1 else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                g = jdist.CGather(rank, world, head[1:].cpu().numpy().tobytes(), local_rank, width, 4096)
-                return g, "libjda_dist.so: jdaDistGatherStart/Collect (ncclAllGather of fixed blocks on the library's communicator)"
+                g = None
+                try:
+                    g = jdist.CGather(rank, world, head[1:].cpu().numpy().tobytes(), local_rank, width, 4096)
+                except Exception as e:                      # noqa: BLE001 -- (a rank that cannot join: every rank falls back)
+                    sys.stderr.write("bench.py rank %d: libjda_dist communicator not set up (%r), falling back to torch.distributed\n" % (rank, e))
+                made = torch.tensor([1 if g is not None else 0], device=dev)
+                dist.all_reduce(made, op=dist.ReduceOp.MIN)
+                if int(made.item()) == 1:
+                    return g, "libjda_dist.so: jdaDistGatherStart/Collect (ncclAllGather of fixed blocks on the library's communicator)"
+                if g is not None and hasattr(g, "close"):
+                    g.close()
         kind = "torch.distributed all_gather (%s)" % backend if world > 1 else "none (one rank)"
         return jdist.PipelinedGather(4096, width, device=gather_dev), kind
 
