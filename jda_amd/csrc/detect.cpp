@@ -109,7 +109,18 @@ static long long env_ll(const char* name, long long dflt) {
   X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */ \
-  X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */
+  X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
+  X(scan_p, "JDA_SCAN_P", 0)                /* persistent scan kernel (k_scan_p): 0 off, 1 for large uniform batches, 2 whenever it fits */ \
+  X(scan_p_block, "JDA_SCAN_P_BLOCK", 1024) /* ... threads per workgroup */                             \
+  X(scan_p_wgs, "JDA_SCAN_P_WGS", 1)        /* ... workgroups per CU */                                 \
+  X(scan_p_slots, "JDA_SCAN_P_SLOTS", 0)    /* ... pixel-tile slots per workgroup (0: as many as fit, at most 8) */ \
+  X(scan_p_b0, "JDA_SCAN_P_B0", 16)         /* ... cart counts at which windows are re-bucketed */       \
+  X(scan_p_b1, "JDA_SCAN_P_B1", 32)                                                                    \
+  X(scan_p_b2, "JDA_SCAN_P_B2", 64)                                                                    \
+  X(scan_p_b3, "JDA_SCAN_P_B3", 96)                                                                    \
+  X(scan_p_b4, "JDA_SCAN_P_B4", 0)                                                                     \
+  X(scan_p_lg, "JDA_SCAN_P_LG", 64444)      /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 pair tasks of 32 / 16 windows */ \
+  X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */
 
 struct Knobs {
 #define X(name, env, dflt) long long name = (dflt);
@@ -988,6 +999,52 @@ struct Pass {
     return true;
   }
 
+  // The persistent form of an LDS-tiled level's scan (k_scan_p.hip): dialect C, no trace.  false = not applicable
+  // (the caller launches k_scan).
+  bool scan_persistent(int level, hipStream_t s) {
+    if constexpr (sizeof(Real) != 4) { (void)level; (void)s; return false; }
+    else {
+      if (!kn().scan_p || want_trace()) return false;
+      const DevModelT<Real>& m = model();
+      const DevLevel& lv = pe->hp.lv[level];
+      const int K = std::min(m.K, (int)kn().handoff);
+      PScanCfg cfg{};
+      const long long bs[5] = {kn().scan_p_b0, kn().scan_p_b1, kn().scan_p_b2, kn().scan_p_b3, kn().scan_p_b4};
+      int digits[kPScanMaxBuckets] = {6, 6, 6, 6, 6, 6}, nd = 0;
+      { long long v = std::max<long long>(0, kn().scan_p_lg); int tmp[16]; int n = 0; while (v > 0 && n < 16) { tmp[n++] = (int)(v % 10); v /= 10; }
+        for (int i = n - 1; i >= 0 && nd < kPScanMaxBuckets; i--) digits[nd++] = tmp[i]; }
+      int last = 0;
+      for (int i = 0; i < 5 && cfg.nb < kPScanMaxBuckets; i++) {
+        const int b = (int)bs[i];
+        if (b <= last || b >= K) continue;
+        cfg.bound[cfg.nb] = b;
+        const int d = digits[cfg.nb];
+        cfg.lg[cfg.nb] = (d == 4 || d == 5) && m.leaf_n <= 256 ? d : 6;
+        cfg.nb++;
+        last = b;
+      }
+      cfg.bound[cfg.nb] = K;
+      const int block = (int)std::max<long long>(64, std::min<long long>(1024, kn().scan_p_block)) & ~63;
+      const int wgs = (int)std::max<long long>(1, std::min<long long>(8, kn().scan_p_wgs));
+      cfg.ring_cap = 64 * (block / 64 + 2);
+      cfg.opts = (int)kn().scan_p_opts;
+      cfg.slot_bytes = (lv.pitch * (lv.win + (lv.th - 1) * lv.step) + 15) & ~15;
+      cfg.slots = 0;
+      const long long fixed = (long long)scan_p_lds_bytes(cfg, K, m.node_n, m.leaf_n, block / 64);
+      const long long budget = (160 * 1024) / wgs;
+      long long slots = (budget - fixed) / std::max(1, cfg.slot_bytes);
+      if (kn().scan_p_slots > 0) slots = std::min<long long>(slots, kn().scan_p_slots);
+      slots = std::min<long long>(slots, 8);
+      if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
+      cfg.slots = (int)slots;
+      if (kn().scan_p == 1 && (long long)lv.tiles_x * lv.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
+      const hipError_t e = launch_scan_persistent(level, cfg, block, c->n_cus * wgs, pe->dp, pe->hp, m, pe->table, w, s);
+      if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return false; }
+      if (e != hipSuccess) { fail(std::string("launch_scan_persistent failed: ") + hipGetErrorString(e)); return false; }
+      return true;
+    }
+  }
+
   // step 1: pyramids (multi-scale models), stage-0 scan (or everything, in dense mode)
   bool issue_scan(uint8_t* hbuf, size_t hs, uint8_t* qbuf, size_t qs, hipEvent_t scan_after) {
     constexpr int dialect = Sel<Real>::dialect;
@@ -1042,6 +1099,7 @@ struct Pass {
       auto scan = [&](int mode, int level, hipStream_t s) -> bool {
         // (opts bit 0, 8 trees in flight per lane in the LDS-tiled modes, was measured neutral to slower: off)
         const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
+        if (mode == 1 && level >= 0 && scan_persistent(level, s)) { rs->scan_launches++; return true; }
         JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, s));
         rs->scan_launches++;
         return true;

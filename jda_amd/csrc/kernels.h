@@ -216,6 +216,22 @@ hipError_t launch_scan_ragged(int mode, int block, bool trace, int handoff, int 
                               const DevModelT<Real>& m, const S0Node* table, const WorkT<Real>& w, int pix_bytes,
                               int blk_base, int blk_n, hipStream_t stream);
 
+// The persistent form of the LDS-tiled scan (k_scan_p.hip; dialect C, pixel mode 1, uniform batches): one workgroup per
+// CU walks its share of the level's tiles through `slots` pixel-tile slots; items that have completed bound[b] carts
+// wait in ring b; lg[b] = 6: a bucket task is lane = window over 64 items, 4 / 5: pair task over 16 / 32 items.
+// bound[nb] = carts done by this kernel (the hand-off).  opts bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks.
+constexpr int kPScanMaxBuckets = 6;
+struct PScanCfg {
+  int nb;
+  int bound[kPScanMaxBuckets + 1];
+  int lg[kPScanMaxBuckets];
+  int slots, slot_bytes, ring_cap, opts;
+};
+size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves);
+hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int grid_max, const DevPlan* d_plan,
+                                  const DevPlan& h_plan, const DevModelT<float>& m, const S0Node* table,
+                                  const WorkT<float>& w, hipStream_t stream);
+
 // Tight images (row stride = width) at raw + src_off -> rows of `pitch` bytes at dst + dst_off, n images of at most
 // max_h rows.
 hipError_t launch_repack(const uint8_t* raw, uint8_t* dst, const RagImg* imgs, int n, int max_h, int pitch, hipStream_t stream);
