@@ -1024,9 +1024,10 @@ struct Pass {
         last = b;
       }
       cfg.bound[cfg.nb] = K;
+      cfg.bound_last = K;
       const int block = (int)std::max<long long>(64, std::min<long long>(1024, kn().scan_p_block)) & ~63;
       const int wgs = (int)std::max<long long>(1, std::min<long long>(8, kn().scan_p_wgs));
-      cfg.ring_cap = 64 * (block / 64 + 2);
+      scan_p_ring_caps(&cfg, block / 64);
       cfg.opts = (int)kn().scan_p_opts;
       cfg.slot_bytes = (lv.pitch * (lv.win + (lv.th - 1) * lv.step) + 15) & ~15;
       cfg.slots = 0;

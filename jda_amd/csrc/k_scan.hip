@@ -545,7 +545,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   }
 #ifdef JDA_SCAN_TIMING
   JDA_STAMP(-1);
-  if (tid == 0 && w.dbg && blockIdx.x < 65536) {
+  if (tid == 0 && w.dbg && blockIdx.x < 49152) {      // (rows from 49152: k_scan_p's)
     unsigned long long* o = w.dbg + (size_t)blockIdx.x * 32;
     o[0] = (unsigned long long)n_stamp | ((unsigned long long)level << 32);
     for (int i = 0; i < n_stamp; i++) { o[1 + i] = stamps[i]; o[16 + i] = (unsigned long long)(long long)items_at[i]; }

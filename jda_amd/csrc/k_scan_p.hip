@@ -35,28 +35,37 @@ constexpr int kPSpinMax = 1 << 20;     // watchdog of every wait loop (a wait is
 
 struct ThNormF { float th, norm; };
 
-struct PCtl {                          // control block in LDS (ints; every access is an LDS atomic or a relaxed load)
-  int next_j;                          // next tile (sequence number inside this workgroup's share) to bring in
-  int err;
-  int pad0[2];
-  int r_rsv[kPScanMaxBuckets], r_cmt[kPScanMaxBuckets], r_pop[kPScanMaxBuckets];
-  int s_state[kPSlotsMax];             // 0 free, 1 being loaded, 2 published
-  int s_pending[kPSlotsMax];           // fresh batches not finished + items alive
-  int s_fresh[kPSlotsMax];             // next fresh batch
-  int s_nbatch[kPSlotsMax];
-  int s_frame[kPSlotsMax], s_wx0[kPSlotsMax], s_wy0[kPSlotsMax], s_twe[kPSlotsMax], s_the[kPSlotsMax], s_xshift[kPSlotsMax];
-  unsigned long long dbg[16];
+// Control block in LDS: 16-byte records, so that a wave picks its next task from ONE ds_read_b128 -- lane i reads
+// record i, evaluates "its" slot or ring, and ballots turn the candidates into masks.  (The first version walked rings
+// and slots with dependent reads and scalar branches: ~400 instructions per pick.  A wave issues an instruction every
+// 5-10 clocks at best, so a pick cost 4 k clocks and -- with lost compare-and-swaps repeating it -- 75 % of all wave
+// clocks, although the LDS round trip itself is ~60 clocks: stamps in profiles/r04_scan_p_stamps.txt.)
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct PCtl {
+  v4i rec[24];
+  //   rec[s], s < 8        slot:  x state (0 free, 1 being loaded, 2 published), y generation << 12 | next fresh batch,
+  //                               z batches, w references (fresh batches not finished + items alive)
+  //   rec[8 + b], b < 6    ring:  x committed, y popped, z reserved
+  //   rec[14]              x next tile (sequence number inside this workgroup's share) to bring in
+  //   rec[16 + s]          slot geometry: x twe | the << 16, y xshift, z frame, w wx0 | wy0 << 16
+  int cfgw[64];                        // PScanCfg as words (see kCf*): a wave keeps word i in lane i and reads it with v_readlane
+  unsigned long long dbg[20];
 };
+constexpr int kRecRing = 8, kRecMisc = 14, kRecGeo = 16;
+// (dynamic indexing of the by-value kernel argument is a scalar memory load per access, ~200 clocks each and serialised)
+constexpr int kCfNb = 0, kCfBound = 1, kCfLg = kCfBound + kPScanMaxBuckets + 1, kCfCap = kCfLg + kPScanMaxBuckets,
+              kCfOff = kCfCap + kPScanMaxBuckets, kCfEnd = kCfOff + kPScanMaxBuckets;
+static_assert(kCfEnd <= 64, "cfg words fit a wave");
 
 struct PLds {
   int nodes, leaf, par, ctl, rings, lfbuf, slots, total;
-  __host__ __device__ PLds(int carts, int node_n, int leaf_n, int nb, int ring_cap, int waves, int n_slots, int slot_bytes) {
+  __host__ __device__ PLds(int carts, int node_n, int leaf_n, int ring_items, int waves, int n_slots, int slot_bytes) {
     int o = 0;
     nodes = o; o += carts * node_n * (int)sizeof(S0Node); o = (o + 15) & ~15;
     leaf = o; o += carts * leaf_n * 4; o = (o + 15) & ~15;
     par = o; o += carts * (int)sizeof(CartPar<float>); o = (o + 15) & ~15;
     ctl = o; o += (int)sizeof(PCtl); o = (o + 15) & ~15;
-    rings = o; o += nb * ring_cap * 8; o = (o + 15) & ~15;
+    rings = o; o += ring_items * 8; o = (o + 15) & ~15;
     lfbuf = o; o += waves * 512;
     slots = o; o += n_slots * slot_bytes;
     total = o;
@@ -233,8 +242,22 @@ __device__ __forceinline__ void p_pair(const PCtx& c, uint8_t* lf, int lg, int c
 
 }  // namespace
 
+// Ring capacities (PScanCfg::ring_cap / ring_off): a wave takes the deepest ring that holds a full task before anything
+// else, so ring b never holds more than a task minus one item plus what the `waves` tasks in flight can add -- 64
+// survivors from a fresh or lane = window task, 16 / 32 from a pair task.
+void scan_p_ring_caps(PScanCfg* cfg, int waves) {
+  int off = 0;
+  for (int b = 0; b < cfg->nb; b++) {
+    const int need = 1 << cfg->lg[b];
+    const int prod = b == 0 || cfg->lg[b - 1] == 6 ? 64 : (1 << cfg->lg[b - 1]);
+    cfg->ring_cap[b] = (need - 1 + waves * prod + 64 + 15) & ~15;
+    cfg->ring_off[b] = off;
+    off += cfg->ring_cap[b];
+  }
+  cfg->ring_items = off;
+}
 size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves) {
-  return (size_t)PLds(carts, node_n, leaf_n, cfg.nb, cfg.ring_cap, waves, cfg.slots, cfg.slot_bytes).total;
+  return (size_t)PLds(carts, node_n, leaf_n, cfg.ring_items, waves, cfg.slots, cfg.slot_bytes).total;
 }
 
 template <int DEPTH>
@@ -247,8 +270,8 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   const int wv = tid >> 6;
   const int NW = blockDim.x >> 6;
   const int node_n = m.node_n, leaf_n = m.leaf_n;
-  const int K = cfg.bound[cfg.nb];                     // this kernel stops here and hands survivors to k_finish
-  const PLds L(K, node_n, leaf_n, cfg.nb, cfg.ring_cap, NW, cfg.slots, cfg.slot_bytes);
+  const int K = cfg.bound_last;                        // this kernel stops here and hands survivors to k_finish
+  const PLds L(K, node_n, leaf_n, cfg.ring_items, NW, cfg.slots, cfg.slot_bytes);
   PCtl* ctl = (PCtl*)(lds + L.ctl);
   uint2* rings = (uint2*)(lds + L.rings);
   uint8_t* lfw = lds + L.lfbuf + wv * 512;
@@ -257,17 +280,20 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   const int tiles_per_frame = lv.tiles_x * lv.tiles_y;
   const int G = gridDim.x;
   const int n_my = (total_blocks - (int)blockIdx.x + G - 1) / G;
-  const int C = cfg.ring_cap;
   const int S = cfg.slots;
 
 #ifdef JDA_SCAN_TIMING
-  unsigned long long t_cat[6] = {0, 0, 0, 0, 0, 0};    // fresh, lane = window bucket, pair bucket, tile load, idle, push/pop
-  unsigned n_cat[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_cat[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // fresh, lane = window bucket, pair bucket, tile load, idle, scheduling (won / lost), snapshot wait, push, item read
+  unsigned n_cat[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
   const unsigned long long t_begin = t_last;
 #define JDA_PCAT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_cat[i] += t_now - t_last; n_cat[i]++; t_last = t_now; } while (0)
+#define JDA_PSUB_BEGIN() const unsigned long long t_sub0 = __builtin_amdgcn_s_memtime()
+#define JDA_PSUB_END(i) do { lds_drain(); t_cat[i] += __builtin_amdgcn_s_memtime() - t_sub0; n_cat[i]++; } while (0)
 #else
 #define JDA_PCAT(i) do { } while (0)
+#define JDA_PSUB_BEGIN() do { } while (0)
+#define JDA_PSUB_END(i) do { } while (0)
 #endif
 
   // ---- prologue: the cart tables of [0, K) once per workgroup, control block cleared ----
@@ -275,8 +301,24 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   dma_to_lds_rt(lds + L.leaf, m.leaf, K * leaf_n * 4, tid, (int)blockDim.x);
   dma_to_lds_rt(lds + L.par, (const CartPar<float>*)m.par0, K * (int)sizeof(CartPar<float>), tid, (int)blockDim.x);
   for (int i = tid; i < (int)(sizeof(PCtl) / 4); i += blockDim.x) ((int*)ctl)[i] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    ctl->cfgw[kCfNb] = cfg.nb;
+#pragma unroll
+    for (int i = 0; i <= kPScanMaxBuckets; i++) ctl->cfgw[kCfBound + i] = cfg.bound[i];
+#pragma unroll
+    for (int i = 0; i < kPScanMaxBuckets; i++) { ctl->cfgw[kCfLg + i] = cfg.lg[i]; ctl->cfgw[kCfCap + i] = cfg.ring_cap[i]; ctl->cfgw[kCfOff + i] = cfg.ring_off[i]; }
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  const int cfgv = ctl->cfgw[lane];
+  auto CF = [&](int i) { return __builtin_amdgcn_readlane(cfgv, i); };
+  const int NB = CF(kCfNb);
+  // lane 8 + b: items a full task of ring b takes
+  const int need_v = 1 << __shfl(cfgv, kCfLg + ((lane - kRecRing) & 7));
+  typedef volatile __attribute__((address_space(3))) v4i* lds_rec_t;
+  lds_rec_t rec_l = (lds_rec_t)(ctl->rec);
+  int* const recw = (int*)ctl->rec;          // word view for the atomics: record r, field f = recw[4 r + f]
 
   PCtx c;
   c.lds = lds;
@@ -289,26 +331,30 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   unsigned my_carts = 0, handed = 0, win_cov = 0;
   int idle_spins = 0;
 
-  // survivors of a task -> ring `b` (b < nb) or the hand-off queue (b == nb); returns the number pushed
-  auto push = [&](int b, bool alive, uint32_t packed, float score) -> int {
+  // survivors of a task -> ring `b` (b < nb) or the hand-off queue (b == nb)
+  auto push = [&](int b, bool alive, uint32_t packed, float score) {
     const unsigned long long mask = __ballot(alive);
     const int n = __popcll(mask);
-    if (n == 0) return 0;
+    if (n == 0) return;
     const int rank = __popcll(mask & lanes_below(lane));
-    if (b < cfg.nb) {
+    if (b < NB) {
+      JDA_PSUB_BEGIN();
+      const int C = CF(kCfCap + b);
+      int* rw = recw + 4 * (kRecRing + b);
       int start = 0;
-      if (lane == 0) start = atomicAdd(&ctl->r_rsv[b], n);
+      if (lane == 0) start = atomicAdd(rw + 2, n);
       start = uni(start);
       // (never taken while the scheduling bound holds; guards the unread tail of the ring)
-      for (int spin = 0; start + n - ld_relaxed(&ctl->r_pop[b]) > C && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(2);
+      for (int spin = 0; start + n - ld_relaxed(rw + 1) > C && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(2);
       if (alive) {
-        unsigned pos = (unsigned)(start + rank) % (unsigned)C;
-        rings[b * C + pos] = make_uint2(packed, __float_as_uint(score));
+        const unsigned pos = (unsigned)(start + rank) % (unsigned)C;
+        rings[CF(kCfOff + b) + pos] = make_uint2(packed, __float_as_uint(score));
       }
       lds_drain();
-      for (int spin = 0; ld_relaxed(&ctl->r_cmt[b]) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
+      for (int spin = 0; ld_relaxed(rw) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
       compiler_fence();
-      if (lane == 0) st_relaxed(&ctl->r_cmt[b], start + n);
+      if (lane == 0) st_relaxed(rw, start + n);
+      JDA_PSUB_END(8);
     } else {
       unsigned gbase = 0;
       if (lane == 0) gbase = (unsigned)atomicAdd(&w.counters[kCntTail], (unsigned long long)n);
@@ -317,7 +363,8 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
         const int s = (int)(packed >> (kPBaseBits + kPWidxBits));
         const int widx = (int)((packed >> kPBaseBits) & ((1u << kPWidxBits) - 1u));
         const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
-        const int frame = ctl->s_frame[s], wx0 = ctl->s_wx0[s], wy0 = ctl->s_wy0[s];
+        const v4i g = rec_l[kRecGeo + s];
+        const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
         const unsigned slot = gbase + (unsigned)rank;
         if (slot < w.cap) {
           w.q_gid[slot] = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
@@ -328,122 +375,78 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
         }
         handed += K;
       }
+      lds_drain();                                       // (the slot records have been read before the references go)
     }
-    return n;
   };
-  // an item has ended (died or was handed off): drop its reference; the last one frees the slot
+  // an item has ended (died or was handed off): its reference on the slot goes.  Fire and forget -- a slot whose
+  // count has reached zero is found by the next wave that looks for a slot to load into.
   auto release = [&](bool ended, uint32_t packed) {
     if (ended) {
       const int s = (int)(packed >> (kPBaseBits + kPWidxBits));
-      const int old = atomicSub(&ctl->s_pending[s], 1);
-      if (old == 1) st_relaxed(&ctl->s_state[s], 0);
-    }
-  };
-  // takes n items off ring b if it holds at least `need`; returns the first position or -1
-  auto try_pop = [&](int b, int need, int want, int* n_out) -> int {
-    for (;;) {
-      const int pop = ld_relaxed(&ctl->r_pop[b]);
-      const int cmt = ld_relaxed(&ctl->r_cmt[b]);
-      const int avail = uni(cmt - pop);
-      if (avail < need || avail <= 0) return -1;
-      const int n = min(avail, want);
-      int got = 0;
-      if (lane == 0) got = (atomicCAS(&ctl->r_pop[b], pop, pop + n) == pop) ? 1 : 0;
-      if (uni(got)) { *n_out = n; return uni(pop); }
+      (void)__hip_atomic_fetch_add(recw + 4 * s + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   };
 
+  const unsigned slot_bits = (1u << S) - 1u;
   for (;;) {
-    int task = -1;                       // 0 fresh, 1 bucket
-    int t_b = 0, t_n = 0, t_start = 0, t_s = 0, t_j = 0;
+    // ---- pick: one record per lane, candidates as ballots ----
+    const v4i r = rec_l[lane & 15];
+    compiler_fence();
+    const bool is_slot = lane < S, is_ring = (unsigned)(lane - kRecRing) < (unsigned)NB;
+    const int bidx = r.y & 0xfff;
+    const int avail_v = r.x - r.y;
+    const unsigned m_dr = (unsigned)__ballot(is_slot && (r.x == 0 || (r.x == 2 && bidx >= r.z && r.w == 0)));
+    const unsigned m_fr = (unsigned)__ballot(is_slot && r.x == 2 && bidx < r.z);
+    const unsigned m_full = (unsigned)__ballot(is_ring && avail_v >= need_v);
+    const unsigned m_part = (unsigned)__ballot(is_ring && avail_v > 0);
+    const int next_j = __builtin_amdgcn_readlane(r.x, kRecMisc);
+    int task = -1;                       // 0 fresh, 1 bucket, 2 tile load
+    int t_b = 0, t_n = 0, t_start = 0, t_s = 0, t_j = 0, t_gen = 0;
+    bool lost = false;                   // a compare-and-swap went to another wave: look again
 
-    // ---- 1. a free slot and tiles left: bring the next tile in ----
-    if (ld_relaxed(&ctl->next_j) < n_my) {
-      int claimed = -1;
-      for (int s = 0; s < S && claimed < 0; s++) {
-        if (ld_relaxed(&ctl->s_state[s]) == 0) {
-          int got = 0;
-          if (lane == 0) got = (atomicCAS(&ctl->s_state[s], 0, 1) == 0) ? 1 : 0;
-          if (uni(got)) claimed = s;
-        }
+    if (next_j < n_my && m_dr != 0u) {
+      // ---- 1. tiles left and a slot that is free or has drained: bring the next tile in ----
+      const int s = __builtin_ctz(m_dr);
+      const int stt = __builtin_amdgcn_readlane(r.x, s);
+      int got = 0;
+      if (lane == 0) got = (atomicCAS(recw + 4 * s, stt, 1) == stt) ? 1 : 0;
+      if (uni(got)) { task = 2; t_s = s; t_gen = (__builtin_amdgcn_readlane(r.y, s) >> 12) + 1; }
+      else lost = true;
+    } else if (m_full != 0u || (m_fr == 0u && m_part != 0u)) {
+      // ---- 2. the deepest ring that holds a full task; 4. nothing fresh either (a tile is late, or the launch is
+      //         ending): whatever the deepest non-empty ring holds ----
+      const int rl_ = 31 - __builtin_clz(m_full != 0u ? m_full : m_part);
+      const int b = rl_ - kRecRing;
+      const int need = m_full != 0u ? (1 << CF(kCfLg + b)) : 1;
+      const int cmt = __builtin_amdgcn_readlane(r.x, rl_);
+      int expv = __builtin_amdgcn_readlane(r.y, rl_);
+      // a lost compare-and-swap returns the ring's new state: try again from it while the task is still there
+      for (;;) {
+        const int n = m_full != 0u ? need : min(cmt - expv, 1 << CF(kCfLg + b));
+        int old = 0;
+        if (lane == 0) old = atomicCAS(recw + 4 * rl_ + 1, expv, expv + n);
+        old = uni(old);
+        if (old == expv) { task = 1; t_b = b; t_start = expv; t_n = n; break; }
+        expv = old;
+        if (cmt - expv < need) { lost = true; break; }
       }
-      if (claimed >= 0) {
-        const int s = claimed;
-        // skip blocks of the padded frame group that have no frame
-        int j = 0, frame = 0, trel = 0;
-        bool have = false;
-        for (;;) {
-          if (lane == 0) j = atomicAdd(&ctl->next_j, 1);
-          j = uni(j);
-          if (j >= n_my) break;
-          const int v = (int)blockIdx.x + j * G;
-          const int group = v / (8 * tiles_per_frame);
-          const int r = v - group * (8 * tiles_per_frame);
-          frame = group * 8 + (r & 7);
-          trel = r >> 3;
-          if (frame < w.n_frames) { have = true; break; }
-        }
-        if (!have) {
-          st_relaxed(&ctl->s_state[s], 0);
-        } else {
-          const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
-          const int wx0 = tx * lv.tw, wy0 = ty * lv.th;
-          const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
-          const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
-          const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
-          const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
-          const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
-                                           lv.pitch, lane);
-          const int nbatch = (lv.tw * the + 63) >> 6;
-          const int gen = (ld_relaxed(&ctl->s_fresh[s]) >> 12) + 1;
-          if (lane == 0) {
-            ctl->s_frame[s] = frame; ctl->s_wx0[s] = wx0; ctl->s_wy0[s] = wy0; ctl->s_twe[s] = twe; ctl->s_the[s] = the;
-            ctl->s_xshift[s] = xshift; ctl->s_nbatch[s] = nbatch; ctl->s_pending[s] = nbatch;
-          }
-          win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile has landed, the slot record too
-          st_relaxed(&ctl->s_fresh[s], (gen & 0x7ffff) << 12);
-          st_relaxed(&ctl->s_state[s], 2);
-        }
-        JDA_PCAT(3);
-        continue;
-      }
-    }
-
-    // ---- 2. the deepest ring that holds a full task ----
-    for (int b = cfg.nb - 1; b >= 0 && task < 0; b--) {
-      const int need = 1 << cfg.lg[b];
-      const int st = try_pop(b, need, need, &t_n);
-      if (st >= 0) { task = 1; t_b = b; t_start = st; }
-    }
-    // ---- 3. fresh windows ----
-    // (s_fresh = generation << 12 | next batch, taken by compare-and-swap: a wave that looked at the slot's previous
-    // tile cannot take a batch of the next one -- the loader publishes a new generation)
-    if (task < 0) {
-      for (int s = 0; s < S && task < 0; s++) {
-        for (;;) {
-          const int f = ld_relaxed(&ctl->s_fresh[s]);
-          const int nb_s = ld_relaxed(&ctl->s_nbatch[s]);
-          const int stt = ld_relaxed(&ctl->s_state[s]);
-          if (uni(stt) != 2 || uni(f & 0xfff) >= uni(nb_s)) break;
-          int got = 0;
-          if (lane == 0) got = (atomicCAS(&ctl->s_fresh[s], f, f + 1) == f) ? 1 : 0;
-          if (uni(got)) { task = 0; t_s = s; t_j = uni(f & 0xfff); break; }
-        }
-      }
-    }
-    // ---- 4. whatever is left (a tile is late, or the launch is ending) ----
-    if (task < 0) {
-      for (int b = cfg.nb - 1; b >= 0 && task < 0; b--) {
-        const int st = try_pop(b, 1, 1 << cfg.lg[b], &t_n);
-        if (st >= 0) { task = 1; t_b = b; t_start = st; }
-      }
+    } else if (m_fr != 0u) {
+      // ---- 3. fresh windows: y = generation << 12 | next batch, taken with an atomic add (never lost to another
+      //         wave).  A wave that looked at the slot's previous tile may get a batch of the NEXT one -- the loader
+      //         publishes a new generation only when the tile has landed, so the batch is good ----
+      const int s = __builtin_ctz(m_fr);
+      int old = 0;
+      if (lane == 0) old = atomicAdd(recw + 4 * s + 1, 1);
+      old = uni(old);
+      int nbt = __builtin_amdgcn_readlane(r.z, s);
+      if ((old >> 12) != (__builtin_amdgcn_readlane(r.y, s) >> 12)) nbt = uni(ld_relaxed(recw + 4 * s + 2));
+      if ((old & 0xfff) < nbt) { task = 0; t_s = s; t_j = old & 0xfff; }
+      else lost = true;
     }
     if (task < 0) {
-      // ---- 5. nothing to do: finished when every tile has been brought in and every slot is free again ----
-      bool done = ld_relaxed(&ctl->next_j) >= n_my;
-      for (int s = 0; s < S; s++) done = done && ld_relaxed(&ctl->s_state[s]) == 0;
-      if (uni(done ? 1 : 0)) break;
+      if (lost) { JDA_PCAT(6); continue; }
+      // ---- 5. nothing to do: finished when every tile has been brought in and every slot has drained ----
+      if (next_j >= n_my && (m_dr & slot_bits) == slot_bits) break;
       if (++idle_spins > kPSpinMax) break;             // (watchdog: a scheduling bug must not hang the device)
       __builtin_amdgcn_s_sleep(8);
       JDA_PCAT(4);
@@ -452,44 +455,83 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
     JDA_PCAT(5);
     idle_spins = 0;
 
-    if (task == 0) {
+    if (task == 2) {
+      const int s = t_s;
+      // skip blocks of the padded frame group that have no frame
+      int j = 0, frame = 0, trel = 0;
+      bool have = false;
+      for (;;) {
+        if (lane == 0) j = atomicAdd(recw + 4 * kRecMisc, 1);
+        j = uni(j);
+        if (j >= n_my) break;
+        const int v = (int)blockIdx.x + j * G;
+        const int group = v / (8 * tiles_per_frame);
+        const int rr = v - group * (8 * tiles_per_frame);
+        frame = group * 8 + (rr & 7);
+        trel = rr >> 3;
+        if (frame < w.n_frames) { have = true; break; }
+      }
+      if (!have) {
+        if (lane == 0) { recw[4 * s + 2] = 0; recw[4 * s + 3] = 0; }
+        lds_drain();
+        st_relaxed(recw + 4 * s, 0);
+      } else {
+        const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
+        const int wx0 = tx * lv.tw, wy0 = ty * lv.th;
+        const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
+        const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
+        const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
+        const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
+        const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
+                                         lv.pitch, lane);
+        const int nbatch = (lv.tw * the + 63) >> 6;
+        if (lane == 0) {
+          int* g = recw + 4 * (kRecGeo + s);
+          g[0] = twe | (the << 16); g[1] = xshift; g[2] = frame; g[3] = wx0 | (wy0 << 16);
+          recw[4 * s + 2] = nbatch; recw[4 * s + 3] = nbatch;
+        }
+        win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile has landed, the slot record too
+        st_relaxed(recw + 4 * s + 1, (t_gen & 0x7ffff) << 12);
+        st_relaxed(recw + 4 * s, 2);
+      }
+      JDA_PCAT(3);
+    } else if (task == 0) {
       // ---- fresh: windows [64 j, 64 j + 64) of slot t_s, carts [0, bound[0]) ----
       const int s = t_s;
-      const int twe = uni(ctl->s_twe[s]), the = uni(ctl->s_the[s]), xshift = uni(ctl->s_xshift[s]);
+      const v4i g = rec_l[kRecGeo + s];
+      const int twe = g.x & 0xffff, the = g.x >> 16, xshift = g.y;
       const int i = 64 * t_j + lane;
       const int wy = i / lv.tw, wx = i - wy * lv.tw;
       bool alive = wx < twe && wy < the;
-      const bool valid = alive;
       const int base = L.slots + s * cfg.slot_bytes + (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
       const uint32_t packed = (uint32_t)base | ((uint32_t)i << kPBaseBits) | ((uint32_t)s << (kPBaseBits + kPWidxBits));
       float score = 0.f;
-      p_uni<DEPTH>(c, 0, cfg.bound[0], base, alive, score, my_carts, ilp8_fresh);
-      (void)valid;
-      // the survivors' references are taken BEFORE they become visible in the ring (a consumer may end them at once);
-      // then the batch's own reference goes (hand-off: the survivors have ended already)
-      const int ns = __popcll(__ballot(alive));
-      if (cfg.nb > 0 && ns > 0 && lane == 0) atomicAdd(&ctl->s_pending[s], ns);
+      p_uni<DEPTH>(c, 0, CF(kCfBound), base, alive, score, my_carts, ilp8_fresh);
+      // the batch's own reference becomes its survivors' references BEFORE they are visible in the ring (a consumer
+      // may end them at once); hand-off: the survivors have ended, the slot records are read first
+      const int ns = NB > 0 ? __popcll(__ballot(alive)) : 0;
+      if (ns > 0 && lane == 0) (void)__hip_atomic_fetch_add(recw + 4 * s + 3, ns - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       push(0, alive, packed, score);
-      if (lane == 0) {
-        const int old = atomicSub(&ctl->s_pending[s], 1);
-        if (old == 1) st_relaxed(&ctl->s_state[s], 0);
-      }
+      if (ns == 0 && lane == 0) (void)__hip_atomic_fetch_add(recw + 4 * s + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       JDA_PCAT(0);
     } else {
       const int b = t_b;
-      const int c0 = cfg.bound[b], c1 = cfg.bound[b + 1];
-      const int lg = cfg.lg[b];
+      const int c0 = CF(kCfBound + b), c1 = CF(kCfBound + b + 1);
+      const int lg = CF(kCfLg + b);
+      const uint2* ring = rings + CF(kCfOff + b);
+      const unsigned C = (unsigned)CF(kCfCap + b);
       if (lg == 6) {
         // ---- lane = window ----
         bool alive = lane < t_n;
         uint2 it = make_uint2(0u, 0u);
-        if (alive) it = rings[b * C + (unsigned)(t_start + lane) % (unsigned)C];
+        if (alive) it = ring[(unsigned)(t_start + lane) % C];
         const bool valid = alive;
         const int base = (int)(it.x & ((1u << kPBaseBits) - 1u));
         float score = __uint_as_float(it.y);
         p_uni<DEPTH>(c, c0, c1, base, alive, score, my_carts, ilp8_bucket);
         push(b + 1, alive, it.x, score);
-        release(valid && (!alive || b + 1 == cfg.nb), it.x);
+        release(valid && (!alive || b + 1 == NB), it.x);
         JDA_PCAT(1);
       } else {
         // ---- pair form ----
@@ -497,14 +539,14 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
         const int item = lane & (np - 1);
         const bool has_item = item < t_n;
         uint2 it = make_uint2(0u, 0u);
-        if (has_item) it = rings[b * C + (unsigned)(t_start + item) % (unsigned)C];
+        if (has_item) it = ring[(unsigned)(t_start + item) % C];
         bool alive = has_item && lane < np;
         const bool valid = alive;
         const int base = (int)(it.x & ((1u << kPBaseBits) - 1u));
         float score = __uint_as_float(it.y);
         p_pair<DEPTH>(c, lfw, lg, c0, c1, lane, has_item, base, alive, score, my_carts);
         push(b + 1, alive, it.x, score);
-        release(valid && (!alive || b + 1 == cfg.nb), it.x);
+        release(valid && (!alive || b + 1 == NB), it.x);
         JDA_PCAT(2);
       }
     }
@@ -520,7 +562,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   if (lane == 0) { red[wv] = (int)v; red[16 + wv] = (int)hv; red[32 + wv] = (int)cv; }
 #ifdef JDA_SCAN_TIMING
   if (lane == 0) {
-    for (int i = 0; i < 6; i++) { atomicAdd(&ctl->dbg[i], t_cat[i]); atomicAdd(&ctl->dbg[6 + i], (unsigned long long)n_cat[i]); }
+    for (int i = 0; i < 10; i++) { atomicAdd(&ctl->dbg[i], t_cat[i]); atomicAdd(&ctl->dbg[10 + i], (unsigned long long)n_cat[i]); }
   }
 #endif
   __syncthreads();
@@ -531,12 +573,12 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
     atomicAdd(shard_counter(w.counters, kCntCartsScan), sv + sh);
     atomicAdd(shard_counter(w.counters, kCntWinScan), sc);
 #ifdef JDA_SCAN_TIMING
-    if (w.dbg && blockIdx.x < 65536) {
-      unsigned long long* o = w.dbg + (size_t)blockIdx.x * 32;
+    if (w.dbg && blockIdx.x < 2048) {
+      unsigned long long* o = w.dbg + (49152 + (size_t)(level & 7) * 2048 + blockIdx.x) * 32;      // (a row per level: later launches do not overwrite it)
       o[0] = 0x5000ull | ((unsigned long long)level << 32);
       o[1] = __builtin_amdgcn_s_memtime() - t_begin;
-      for (int i = 0; i < 12; i++) o[2 + i] = ctl->dbg[i];
-      o[14] = (unsigned long long)n_my;
+      for (int i = 0; i < 20; i++) o[2 + i] = ctl->dbg[i];
+      o[22] = (unsigned long long)n_my;
     }
 #endif
   }
@@ -549,8 +591,8 @@ hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int
   const DevLevel& lv = h_plan.lv[level];
   if (lv.tiled != 1 || cfg.nb < 0 || cfg.nb > kPScanMaxBuckets || cfg.slots < 1 || cfg.slots > kPSlotsMax) return hipErrorInvalidValue;
   if (lv.tw * lv.th > (1 << kPWidxBits) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
-  const int K = cfg.bound[cfg.nb];
-  const PLds L(K, m.node_n, m.leaf_n, cfg.nb, cfg.ring_cap, block / 64, cfg.slots, cfg.slot_bytes);
+  const int K = cfg.bound_last;
+  const PLds L(K, m.node_n, m.leaf_n, cfg.ring_items, block / 64, cfg.slots, cfg.slot_bytes);
   if (L.total > 160 * 1024 || L.total > (1 << kPBaseBits)) return hipErrorInvalidValue;
   const int groups = (w.n_frames + 7) / 8;
   const int total_blocks = groups * 8 * lv.tiles_x * lv.tiles_y;

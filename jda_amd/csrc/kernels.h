@@ -225,8 +225,11 @@ struct PScanCfg {
   int nb;
   int bound[kPScanMaxBuckets + 1];
   int lg[kPScanMaxBuckets];
-  int slots, slot_bytes, ring_cap, opts;
+  int slots, slot_bytes, opts;
+  int bound_last;                      // = bound[nb]
+  int ring_cap[kPScanMaxBuckets], ring_off[kPScanMaxBuckets], ring_items;     // items per ring / first item / all rings (scan_p_ring_caps)
 };
+void scan_p_ring_caps(PScanCfg* cfg, int waves);
 size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves);
 hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int grid_max, const DevPlan* d_plan,
                                   const DevPlan& h_plan, const DevModelT<float>& m, const S0Node* table,

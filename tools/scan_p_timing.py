@@ -16,13 +16,13 @@ assert api.lib.jdaDebugScanTiming(C.c_void_p(c.h), buf.ctypes.data_as(C.POINTER(
 tag = (buf[:, 0] & 0xffffffff).astype(np.int64); lvl = (buf[:, 0] >> 32).astype(np.int64)
 sel = tag == 0x5000
 print("persistent workgroups with stamps:", int(sel.sum()), "(the last launch to write a slot wins: the last LDS-tiled level)")
-names = ["fresh", "bucket lane=window", "bucket pair", "tile load", "idle", "schedule"]
+names = ["fresh", "bucket lane=window", "bucket pair", "tile load", "idle", "pick won", "pick lost", "(snapshot read)", "(push to ring)", "(unused)"]
 for L in sorted(set(lvl[sel].tolist())):
     s = sel & (lvl == L)
     tot = buf[s, 1].astype(np.float64)
-    t = buf[s, 2:8].astype(np.float64); n = buf[s, 8:14].astype(np.float64)
-    print("level %d: %d workgroups, %.0f tiles each, median workgroup clocks %.0f" % (L, s.sum(), np.median(buf[s, 14].astype(np.float64)), np.median(tot)))
-    wsum = t.sum(1)
+    t = buf[s, 2:12].astype(np.float64); n = buf[s, 12:22].astype(np.float64)
+    print("level %d: %d workgroups, %.0f tiles each, median workgroup clocks %.0f" % (L, s.sum(), np.median(buf[s, 22].astype(np.float64)), np.median(tot)))
+    wsum = t[:, :7].sum(1)
     for i, nm in enumerate(names):
         print("   %-20s %5.1f %% of wave clocks   %8.0f tasks per workgroup   %8.0f clocks per task" % (
             nm, 100 * np.median(t[:, i] / wsum), np.median(n[:, i]), np.median(t[:, i] / np.maximum(n[:, i], 1))))
