@@ -110,16 +110,19 @@ static long long env_ll(const char* name, long long dflt) {
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
-  X(scan_p, "JDA_SCAN_P", 0)                /* persistent scan kernel (k_scan_p): 0 off, 1 for large uniform batches, 2 whenever it fits */ \
-  X(scan_p_block, "JDA_SCAN_P_BLOCK", 1024) /* ... threads per workgroup */                             \
+  X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
+  X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
+  X(scan_p_min_slots, "JDA_SCAN_P_MIN_SLOTS", 4) /* ... pixel-tile slots a level's workgroup must have room for (scan_p = 1) */ \
   X(scan_p_wgs, "JDA_SCAN_P_WGS", 1)        /* ... workgroups per CU */                                 \
   X(scan_p_slots, "JDA_SCAN_P_SLOTS", 0)    /* ... pixel-tile slots per workgroup (0: as many as fit, at most 8) */ \
-  X(scan_p_b0, "JDA_SCAN_P_B0", 16)         /* ... cart counts at which windows are re-bucketed */       \
-  X(scan_p_b1, "JDA_SCAN_P_B1", 32)                                                                    \
-  X(scan_p_b2, "JDA_SCAN_P_B2", 64)                                                                    \
-  X(scan_p_b3, "JDA_SCAN_P_B3", 96)                                                                    \
+  X(scan_p_b0, "JDA_SCAN_P_B0", 32)         /* ... cart counts at which windows are re-bucketed */       \
+  X(scan_p_b1, "JDA_SCAN_P_B1", 64)                                                                    \
+  X(scan_p_b2, "JDA_SCAN_P_B2", 0)                                                                     \
+  X(scan_p_b3, "JDA_SCAN_P_B3", 0)                                                                     \
   X(scan_p_b4, "JDA_SCAN_P_B4", 0)                                                                     \
-  X(scan_p_lg, "JDA_SCAN_P_LG", 64444)      /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 pair tasks of 32 / 16 windows */ \
+  X(scan_p_handoff, "JDA_SCAN_P_HANDOFF", 0) /* ... carts of stage 0 it evaluates (0: `handoff`).  Its cart tables are loaded once per workgroup and its deep windows pooled over all tiles, so a later hand-off costs it little */ \
+  X(scan_p_ring, "JDA_SCAN_P_RING", 256)    /* ... items per ring (rounded up to a power of two) */     \
+  X(scan_p_lg, "JDA_SCAN_P_LG", 64)         /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 pair tasks of 32 / 16 windows */ \
   X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */
 
 struct Knobs {
@@ -144,6 +147,17 @@ struct Knobs {
     return false;
   }
 };
+
+// Does any of the first K carts of stage 0 normalise its score ((mean, std) != (0, 1), c/jda.c:397), in the precision
+// the dialect computes in?  The scan kernels drop the per-cart test of the flag from their loops when none does.
+static bool stage0_any_norm(const HostModel& hm, int K, bool fp32) {
+  K = std::min(K, hm.K);
+  for (int k = 0; k < K; k++) {
+    const bool plain = fp32 ? ((float)hm.cart_mean[k] == 0.f && (float)hm.cart_std[k] == 1.f) : (hm.cart_mean[k] == 0.0 && hm.cart_std[k] == 1.0);
+    if (!plain) return true;
+  }
+  return false;
+}
 
 // ---------------------------------------------------------------- device buffers
 
@@ -1007,7 +1021,7 @@ struct Pass {
       if (!kn().scan_p || want_trace()) return false;
       const DevModelT<Real>& m = model();
       const DevLevel& lv = pe->hp.lv[level];
-      const int K = std::min(m.K, (int)kn().handoff);
+      const int K = std::min(m.K, (int)(kn().scan_p_handoff > 0 ? kn().scan_p_handoff : kn().handoff));
       PScanCfg cfg{};
       const long long bs[5] = {kn().scan_p_b0, kn().scan_p_b1, kn().scan_p_b2, kn().scan_p_b3, kn().scan_p_b4};
       int digits[kPScanMaxBuckets] = {6, 6, 6, 6, 6, 6}, nd = 0;
@@ -1019,15 +1033,20 @@ struct Pass {
         if (b <= last || b >= K) continue;
         cfg.bound[cfg.nb] = b;
         const int d = digits[cfg.nb];
-        cfg.lg[cfg.nb] = (d == 4 || d == 5) && m.leaf_n <= 256 ? d : 6;
+        cfg.lg[cfg.nb] = ((d == 4 || d == 5) && m.leaf_n <= 256) || d == 2 || d == 3 ? d : 6;
         cfg.nb++;
         last = b;
       }
       cfg.bound[cfg.nb] = K;
       cfg.bound_last = K;
+      cfg.any_norm = stage0_any_norm(c->hm, K, true) ? 1 : 0;
       const int block = (int)std::max<long long>(64, std::min<long long>(1024, kn().scan_p_block)) & ~63;
       const int wgs = (int)std::max<long long>(1, std::min<long long>(8, kn().scan_p_wgs));
+      cfg.ring_cap[0] = (int)std::max<long long>(64, std::min<long long>(4096, kn().scan_p_ring));
       scan_p_ring_caps(&cfg, block / 64);
+      { const unsigned mg = ((1u << 20) + (unsigned)lv.tw - 1u) / (unsigned)lv.tw; bool ok = true;
+        for (unsigned i = 0; i < (unsigned)(lv.tw * lv.th + 64) && ok; i++) ok = ((i * mg) >> 20) == i / (unsigned)lv.tw;
+        cfg.tw_magic = ok ? (int)mg : 0; }
       cfg.opts = (int)kn().scan_p_opts;
       cfg.slot_bytes = (lv.pitch * (lv.win + (lv.th - 1) * lv.step) + 15) & ~15;
       cfg.slots = 0;
@@ -1037,6 +1056,7 @@ struct Pass {
       if (kn().scan_p_slots > 0) slots = std::min<long long>(slots, kn().scan_p_slots);
       slots = std::min<long long>(slots, 8);
       if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
+      if (kn().scan_p == 1 && slots < kn().scan_p_min_slots) return false;     // few resident windows per wave: k_scan's closed tiles do better there
       cfg.slots = (int)slots;
       if (kn().scan_p == 1 && (long long)lv.tiles_x * lv.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
       const hipError_t e = launch_scan_persistent(level, cfg, block, c->n_cus * wgs, pe->dp, pe->hp, m, pe->table, w, s);

@@ -105,7 +105,9 @@ struct PCtx {
 };
 
 // carts [k, k+CNT) applied to this lane's window, strictly in cart order with the per-cart reject (c/jda.c:395-399)
-template <int CNT>
+// NORM = false: no cart of this launch normalises its score (known on the host) -- the per-cart test of the flag and
+// its branch leave the loop.
+template <int CNT, bool NORM>
 __device__ __forceinline__ void p_apply(const PCtx& c, int k, const int* lf, bool& alive, float& score, unsigned& my_carts) {
   ThNormF p[CNT];
   float lsv[CNT];
@@ -118,7 +120,7 @@ __device__ __forceinline__ void p_apply(const PCtx& c, int k, const int* lf, boo
   for (int u = 0; u < CNT; u++) {
     if (!dead) {
       s = s + lsv[u];                                                                                  // c/jda.c:396
-      if (p[u].norm != 0.f) { const CartPar<float> q = c.t_par[k + u]; s = (s - q.mean) / q.std; }     // c/jda.c:397 (rare)
+      if (NORM && p[u].norm != 0.f) { const CartPar<float> q = c.t_par[k + u]; s = (s - q.mean) / q.std; }   // c/jda.c:397 (rare)
       kd = k + u;
       dead = s < p[u].th;                                                                              // c/jda.c:399
     }
@@ -128,7 +130,9 @@ __device__ __forceinline__ void p_apply(const PCtx& c, int k, const int* lf, boo
 }
 
 // lane = window: carts [c0, c1) for the window at `base`
-template <int DEPTH>
+// (a branch-free form of the reject -- the four partial sums, a ballot per cart, the carts of rejected windows counted
+// per wave in scalar registers -- was measured 9 % slower per walk than this one, whose dead lanes skip the rest)
+template <int DEPTH, bool NORM>
 __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, bool& alive, float& score, unsigned& my_carts,
                                       bool ilp8) {
   int k = c0;
@@ -138,7 +142,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
       if (alive) {
         int lf[8];
         scan_trees<DEPTH, false, 8>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf);
-        p_apply<8>(c, k, lf, alive, score, my_carts);
+        p_apply<8, NORM>(c, k, lf, alive, score, my_carts);
       }
     }
   }
@@ -147,7 +151,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
     if (alive) {
       int lf[4];
       scan_trees<DEPTH, false, 4>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf);
-      p_apply<4>(c, k, lf, alive, score, my_carts);
+      p_apply<4, NORM>(c, k, lf, alive, score, my_carts);
     }
   }
   for (; k < c1; k++) {
@@ -155,7 +159,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
     if (alive) {
       int lf[1];
       lf[0] = scan_tree<DEPTH, false>(c.t_nodes + k * c.node_n, c.lds, base, c.D) - c.node_n;
-      p_apply<1>(c, k, lf, alive, score, my_carts);
+      p_apply<1, NORM>(c, k, lf, alive, score, my_carts);
     }
   }
 }
@@ -232,7 +236,7 @@ __device__ __forceinline__ void p_pair(const PCtx& c, uint8_t* lf, int lg, int c
         if (alive) {
           int l1[1];
           l1[0] = (int)lf[item * rc + (k - r0)];
-          p_apply<1>(c, k, l1, alive, score, my_carts);
+          p_apply<1, true>(c, k, l1, alive, score, my_carts);
         }
       }
     }
@@ -242,19 +246,15 @@ __device__ __forceinline__ void p_pair(const PCtx& c, uint8_t* lf, int lg, int c
 
 }  // namespace
 
-// Ring capacities (PScanCfg::ring_cap / ring_off): a wave takes the deepest ring that holds a full task before anything
-// else, so ring b never holds more than a task minus one item plus what the `waves` tasks in flight can add -- 64
-// survivors from a fresh or lane = window task, 16 / 32 from a pair task.
+// Rings: `ring_cap` items each (a power of two).  A producer reserves with a compare-and-swap that checks the room; when
+// a ring is full its survivors are not queued -- the task walks them through the next cart range itself (lanes partly
+// empty, but no wave ever waits for room: no deadlock, no overflow, whatever the rings' size).
 void scan_p_ring_caps(PScanCfg* cfg, int waves) {
-  int off = 0;
-  for (int b = 0; b < cfg->nb; b++) {
-    const int need = 1 << cfg->lg[b];
-    const int prod = b == 0 || cfg->lg[b - 1] == 6 ? 64 : (1 << cfg->lg[b - 1]);
-    cfg->ring_cap[b] = (need - 1 + waves * prod + 64 + 15) & ~15;
-    cfg->ring_off[b] = off;
-    off += cfg->ring_cap[b];
-  }
-  cfg->ring_items = off;
+  (void)waves;
+  int cap = 64;
+  while (cap < cfg->ring_cap[0]) cap *= 2;
+  for (int b = 0; b < kPScanMaxBuckets; b++) { cfg->ring_cap[b] = cap; cfg->ring_off[b] = b * cap; }
+  cfg->ring_items = cfg->nb * cap;
 }
 size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves) {
   return (size_t)PLds(carts, node_n, leaf_n, cfg.ring_items, waves, cfg.slots, cfg.slot_bytes).total;
@@ -315,7 +315,9 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   auto CF = [&](int i) { return __builtin_amdgcn_readlane(cfgv, i); };
   const int NB = CF(kCfNb);
   // lane 8 + b: items a full task of ring b takes
-  const int need_v = 1 << __shfl(cfgv, kCfLg + ((lane - kRecRing) & 7));
+  // (task form digit: 6 lane = window, 64 items; 3 / 2 lane = window, a full task is 32 / 16 items; 5 / 4 pair task of 32 / 16)
+  auto need_of = [](int d) { return d == 6 ? 64 : (d == 5 || d == 3) ? 32 : 16; };
+  const int need_v = need_of(__shfl(cfgv, kCfLg + ((lane - kRecRing) & 7)));
   typedef volatile __attribute__((address_space(3))) v4i* lds_rec_t;
   lds_rec_t rec_l = (lds_rec_t)(ctl->rec);
   int* const recw = (int*)ctl->rec;          // word view for the atomics: record r, field f = recw[4 r + f]
@@ -327,228 +329,262 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   c.t_par = (const CartPar<float>*)(lds + L.par);
   c.node_n = node_n; c.leaf_n = leaf_n; c.D = m.D;
   const bool ilp8_fresh = (cfg.opts & 1) != 0, ilp8_bucket = (cfg.opts & 2) != 0;
+  const bool any_norm = cfg.any_norm != 0;
 
   unsigned my_carts = 0, handed = 0, win_cov = 0;
   int idle_spins = 0;
 
-  // survivors of a task -> ring `b` (b < nb) or the hand-off queue (b == nb)
-  auto push = [&](int b, bool alive, uint32_t packed, float score) {
+  const int C = CF(kCfCap);                            // items per ring (a power of two)
+  // survivors -> ring b, if it has room (reserved by compare-and-swap against the pop counter); false: no room
+  auto push_ring = [&](int b, bool alive, uint32_t packed, float score) -> bool {
+    const unsigned long long mask = __ballot(alive);
+    const int n = __popcll(mask);
+    if (n == 0) return true;
+    JDA_PSUB_BEGIN();
+    int* rw = recw + 4 * (kRecRing + b);
+    int start;
+    for (;;) {
+      const v4i q = rec_l[kRecRing + b];
+      const int rsv = uni(q.z), pop = uni(q.y);
+      if (rsv + n - pop > C) return false;
+      int old = 0;
+      if (lane == 0) old = atomicCAS(rw + 2, rsv, rsv + n);
+      if (uni(old) == rsv) { start = rsv; break; }
+    }
+    if (alive) {
+      const int rank = __popcll(mask & lanes_below(lane));
+      rings[b * C + ((start + rank) & (C - 1))] = make_uint2(packed, __float_as_uint(score));
+    }
+    lds_drain();
+    for (int spin = 0; ld_relaxed(rw) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
+    compiler_fence();
+    if (lane == 0) st_relaxed(rw, start + n);
+    JDA_PSUB_END(8);
+    return true;
+  };
+  // windows alive after cart K - 1 -> hand-off queue (k_finish continues at cart K)
+  auto hand_off = [&](bool alive, uint32_t packed, float score) {
     const unsigned long long mask = __ballot(alive);
     const int n = __popcll(mask);
     if (n == 0) return;
-    const int rank = __popcll(mask & lanes_below(lane));
-    if (b < NB) {
-      JDA_PSUB_BEGIN();
-      const int C = CF(kCfCap + b);
-      int* rw = recw + 4 * (kRecRing + b);
-      int start = 0;
-      if (lane == 0) start = atomicAdd(rw + 2, n);
-      start = uni(start);
-      // (never taken while the scheduling bound holds; guards the unread tail of the ring)
-      for (int spin = 0; start + n - ld_relaxed(rw + 1) > C && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(2);
-      if (alive) {
-        const unsigned pos = (unsigned)(start + rank) % (unsigned)C;
-        rings[CF(kCfOff + b) + pos] = make_uint2(packed, __float_as_uint(score));
-      }
-      lds_drain();
-      for (int spin = 0; ld_relaxed(rw) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
-      compiler_fence();
-      if (lane == 0) st_relaxed(rw, start + n);
-      JDA_PSUB_END(8);
-    } else {
-      unsigned gbase = 0;
-      if (lane == 0) gbase = (unsigned)atomicAdd(&w.counters[kCntTail], (unsigned long long)n);
-      gbase = (unsigned)uni((int)gbase);
-      if (alive) {
-        const int s = (int)(packed >> (kPBaseBits + kPWidxBits));
-        const int widx = (int)((packed >> kPBaseBits) & ((1u << kPWidxBits) - 1u));
-        const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
-        const v4i g = rec_l[kRecGeo + s];
-        const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
-        const unsigned slot = gbase + (unsigned)rank;
-        if (slot < w.cap) {
-          w.q_gid[slot] = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
-          w.q_score[slot] = score;
-          w.q_kstart[slot] = (uint32_t)K;
-          w.q_xy[slot] = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
-          w.q_wf[slot] = (uint32_t)lv.win | ((uint32_t)frame << 16);
-        }
-        handed += K;
-      }
-      lds_drain();                                       // (the slot records have been read before the references go)
-    }
-  };
-  // an item has ended (died or was handed off): its reference on the slot goes.  Fire and forget -- a slot whose
-  // count has reached zero is found by the next wave that looks for a slot to load into.
-  auto release = [&](bool ended, uint32_t packed) {
-    if (ended) {
+    unsigned gbase = 0;
+    if (lane == 0) gbase = (unsigned)atomicAdd(&w.counters[kCntTail], (unsigned long long)n);
+    gbase = (unsigned)uni((int)gbase);
+    if (alive) {
+      const int rank = __popcll(mask & lanes_below(lane));
       const int s = (int)(packed >> (kPBaseBits + kPWidxBits));
-      (void)__hip_atomic_fetch_add(recw + 4 * s + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int widx = (int)((packed >> kPBaseBits) & ((1u << kPWidxBits) - 1u));
+      const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
+      const v4i g = rec_l[kRecGeo + s];
+      const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
+      const unsigned slot = gbase + (unsigned)rank;
+      if (slot < w.cap) {
+        w.q_gid[slot] = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
+        w.q_score[slot] = score;
+        w.q_kstart[slot] = (uint32_t)K;
+        w.q_xy[slot] = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
+        w.q_wf[slot] = (uint32_t)lv.win | ((uint32_t)frame << 16);
+      }
+      handed += K;
     }
+    lds_drain();                                         // (the slot records have been read before the references go)
   };
+  // a set of windows to walk, one per lane where r_ok: level rv (-1 fresh, else they have completed bound[rv] carts)
+  int rv = -2;                                         // -2: nothing to walk
+  uint32_t r_pk = 0u;
+  float r_sc = 0.f;
+  bool r_ok = false;
 
   const unsigned slot_bits = (1u << S) - 1u;
   for (;;) {
-    // ---- pick: one record per lane, candidates as ballots ----
-    const v4i r = rec_l[lane & 15];
-    compiler_fence();
-    const bool is_slot = lane < S, is_ring = (unsigned)(lane - kRecRing) < (unsigned)NB;
-    const int bidx = r.y & 0xfff;
-    const int avail_v = r.x - r.y;
-    const unsigned m_dr = (unsigned)__ballot(is_slot && (r.x == 0 || (r.x == 2 && bidx >= r.z && r.w == 0)));
-    const unsigned m_fr = (unsigned)__ballot(is_slot && r.x == 2 && bidx < r.z);
-    const unsigned m_full = (unsigned)__ballot(is_ring && avail_v >= need_v);
-    const unsigned m_part = (unsigned)__ballot(is_ring && avail_v > 0);
-    const int next_j = __builtin_amdgcn_readlane(r.x, kRecMisc);
-    int task = -1;                       // 0 fresh, 1 bucket, 2 tile load
-    int t_b = 0, t_n = 0, t_start = 0, t_s = 0, t_j = 0, t_gen = 0;
-    bool lost = false;                   // a compare-and-swap went to another wave: look again
-
-    if (next_j < n_my && m_dr != 0u) {
-      // ---- 1. tiles left and a slot that is free or has drained: bring the next tile in ----
-      const int s = __builtin_ctz(m_dr);
-      const int stt = __builtin_amdgcn_readlane(r.x, s);
-      int got = 0;
-      if (lane == 0) got = (atomicCAS(recw + 4 * s, stt, 1) == stt) ? 1 : 0;
-      if (uni(got)) { task = 2; t_s = s; t_gen = (__builtin_amdgcn_readlane(r.y, s) >> 12) + 1; }
-      else lost = true;
-    } else if (m_full != 0u || (m_fr == 0u && m_part != 0u)) {
-      // ---- 2. the deepest ring that holds a full task; 4. nothing fresh either (a tile is late, or the launch is
-      //         ending): whatever the deepest non-empty ring holds ----
-      const int rl_ = 31 - __builtin_clz(m_full != 0u ? m_full : m_part);
-      const int b = rl_ - kRecRing;
-      const int need = m_full != 0u ? (1 << CF(kCfLg + b)) : 1;
-      const int cmt = __builtin_amdgcn_readlane(r.x, rl_);
-      int expv = __builtin_amdgcn_readlane(r.y, rl_);
-      // a lost compare-and-swap returns the ring's new state: try again from it while the task is still there
-      for (;;) {
-        const int n = m_full != 0u ? need : min(cmt - expv, 1 << CF(kCfLg + b));
-        int old = 0;
-        if (lane == 0) old = atomicCAS(recw + 4 * rl_ + 1, expv, expv + n);
-        old = uni(old);
-        if (old == expv) { task = 1; t_b = b; t_start = expv; t_n = n; break; }
-        expv = old;
-        if (cmt - expv < need) { lost = true; break; }
-      }
-    } else if (m_fr != 0u) {
-      // ---- 3. fresh windows: y = generation << 12 | next batch, taken with an atomic add (never lost to another
-      //         wave).  A wave that looked at the slot's previous tile may get a batch of the NEXT one -- the loader
-      //         publishes a new generation only when the tile has landed, so the batch is good ----
-      const int s = __builtin_ctz(m_fr);
-      int old = 0;
-      if (lane == 0) old = atomicAdd(recw + 4 * s + 1, 1);
-      old = uni(old);
-      int nbt = __builtin_amdgcn_readlane(r.z, s);
-      if ((old >> 12) != (__builtin_amdgcn_readlane(r.y, s) >> 12)) nbt = uni(ld_relaxed(recw + 4 * s + 2));
-      if ((old & 0xfff) < nbt) { task = 0; t_s = s; t_j = old & 0xfff; }
-      else lost = true;
-    }
-    if (task < 0) {
-      if (lost) { JDA_PCAT(6); continue; }
-      // ---- 5. nothing to do: finished when every tile has been brought in and every slot has drained ----
-      if (next_j >= n_my && (m_dr & slot_bits) == slot_bits) break;
-      if (++idle_spins > kPSpinMax) break;             // (watchdog: a scheduling bug must not hang the device)
-      __builtin_amdgcn_s_sleep(8);
-      JDA_PCAT(4);
-      continue;
-    }
-    JDA_PCAT(5);
-    idle_spins = 0;
-
-    if (task == 2) {
-      const int s = t_s;
-      // skip blocks of the padded frame group that have no frame
-      int j = 0, frame = 0, trel = 0;
-      bool have = false;
-      for (;;) {
-        if (lane == 0) j = atomicAdd(recw + 4 * kRecMisc, 1);
-        j = uni(j);
-        if (j >= n_my) break;
-        const int v = (int)blockIdx.x + j * G;
-        const int group = v / (8 * tiles_per_frame);
-        const int rr = v - group * (8 * tiles_per_frame);
-        frame = group * 8 + (rr & 7);
-        trel = rr >> 3;
-        if (frame < w.n_frames) { have = true; break; }
-      }
-      if (!have) {
-        if (lane == 0) { recw[4 * s + 2] = 0; recw[4 * s + 3] = 0; }
-        lds_drain();
-        st_relaxed(recw + 4 * s, 0);
-      } else {
-        const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
-        const int wx0 = tx * lv.tw, wy0 = ty * lv.th;
-        const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
-        const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
-        const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
-        const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
-        const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
-                                         lv.pitch, lane);
-        const int nbatch = (lv.tw * the + 63) >> 6;
-        if (lane == 0) {
-          int* g = recw + 4 * (kRecGeo + s);
-          g[0] = twe | (the << 16); g[1] = xshift; g[2] = frame; g[3] = wx0 | (wy0 << 16);
-          recw[4 * s + 2] = nbatch; recw[4 * s + 3] = nbatch;
+    if (rv == -2) {
+      // ================= choose what to do next =================
+      {
+        // ---- pick: one record per lane, candidates as ballots ----
+        const v4i r = rec_l[lane & 15];
+        compiler_fence();
+        const bool is_slot = lane < S, is_ring = (unsigned)(lane - kRecRing) < (unsigned)NB;
+        const int bidx = r.y & 0xfff;
+        const int avail_v = r.x - r.y;
+        const unsigned m_dr = (unsigned)__ballot(is_slot && (r.x == 0 || (r.x == 2 && bidx >= r.z && r.w == 0)));
+        const unsigned m_fr = (unsigned)__ballot(is_slot && r.x == 2 && bidx < r.z);
+        const unsigned m_full = (unsigned)__ballot(is_ring && avail_v >= need_v);
+        const int next_j = __builtin_amdgcn_readlane(r.x, kRecMisc);
+        int task = -1;                     // 0 fresh, 1 ring, 2 tile load
+        int t_b = 0, t_n = 0, t_s = 0, t_j = 0, t_gen = 0;
+        uint2 t_it = make_uint2(0u, 0u);
+        bool lost = false;                 // a compare-and-swap went to another wave: look again
+        unsigned m_ring = m_full;
+        if (!(next_j < n_my && m_dr != 0u) && m_full == 0u && m_fr == 0u) {
+          // nothing fresh, no full ring task.  While a tile is on its way: wait.  Else every slot waits for its last
+          // windows (or the launch is ending): whatever the deepest ring holds.
+          const unsigned m_ld = (unsigned)__ballot(is_slot && r.x == 1);
+          if (m_ld == 0u) m_ring = (unsigned)__ballot(is_ring && avail_v > 0);
         }
-        win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile has landed, the slot record too
-        st_relaxed(recw + 4 * s + 1, (t_gen & 0x7ffff) << 12);
-        st_relaxed(recw + 4 * s, 2);
+        if (next_j < n_my && m_dr != 0u) {
+          // ---- tiles left and a slot that is free or has drained: bring the next tile in ----
+          const int s = __builtin_ctz(m_dr);
+          const int stt = __builtin_amdgcn_readlane(r.x, s);
+          int got = 0;
+          if (lane == 0) got = (atomicCAS(recw + 4 * s, stt, 1) == stt) ? 1 : 0;
+          if (uni(got)) { task = 2; t_s = s; t_gen = (__builtin_amdgcn_readlane(r.y, s) >> 12) + 1; }
+          else lost = true;
+        } else if (m_ring != 0u) {
+          // ---- the deepest ring that holds a full task (or, draining, anything).  The items are read BEFORE the
+          //      compare-and-swap that takes them (a wave's LDS operations execute in order): while the pop counter
+          //      stands, no producer writes into that part of the ring, so a swap that succeeds proves the items read
+          //      are the ones taken -- and producers may reuse the room at once ----
+          const int rl_ = 31 - __builtin_clz(m_ring);
+          const int b = rl_ - kRecRing;
+          const int dg = CF(kCfLg + b);
+          const int full_n = need_of(dg);
+          const int need = m_full != 0u ? full_n : 1;
+          const int cmt = __builtin_amdgcn_readlane(r.x, rl_);
+          int expv = __builtin_amdgcn_readlane(r.y, rl_);
+          const int item = (dg == 4 || dg == 5) ? (lane & (full_n - 1)) : lane;
+          for (;;) {
+            const int n = min(cmt - expv, full_n);
+            t_it = make_uint2(0u, 0u);
+            if (item < n) t_it = rings[b * C + ((expv + item) & (C - 1))];
+            int old = 0;
+            if (lane == 0) old = atomicCAS(recw + 4 * rl_ + 1, expv, expv + n);
+            old = uni(old);
+            if (old == expv) { task = 1; t_b = b; t_n = n; break; }
+            expv = old;
+            if (cmt - expv < need) { lost = true; break; }
+          }
+        } else if (m_fr != 0u) {
+          // ---- fresh windows: y = generation << 12 | next batch, taken with an atomic add (never lost to another
+          //      wave).  A wave that looked at the slot's previous tile may get a batch of the NEXT one -- the loader
+          //      publishes a new generation only when the tile has landed, so the batch is good ----
+          const int s = __builtin_ctz(m_fr);
+          int old = 0;
+          if (lane == 0) old = atomicAdd(recw + 4 * s + 1, 1);
+          old = uni(old);
+          int nbt = __builtin_amdgcn_readlane(r.z, s);
+          if ((old >> 12) != (__builtin_amdgcn_readlane(r.y, s) >> 12)) nbt = uni(ld_relaxed(recw + 4 * s + 2));
+          if ((old & 0xfff) < nbt) { task = 0; t_s = s; t_j = old & 0xfff; }
+          else lost = true;
+        }
+        if (task < 0) {
+          if (lost) { __builtin_amdgcn_s_sleep(2); JDA_PCAT(6); continue; }
+          // ---- nothing to do: finished when every tile has been brought in and every slot has drained ----
+          if (next_j >= n_my && (m_dr & slot_bits) == slot_bits) break;
+          if (++idle_spins > kPSpinMax) break;           // (watchdog: a scheduling bug must not hang the device)
+          __builtin_amdgcn_s_sleep(16);
+          JDA_PCAT(4);
+          continue;
+        }
+        JDA_PCAT(5);
+        idle_spins = 0;
+
+        if (task == 2) {
+          const int s = t_s;
+          // skip blocks of the padded frame group that have no frame
+          int j = 0, frame = 0, trel = 0;
+          bool have = false;
+          for (;;) {
+            if (lane == 0) j = atomicAdd(recw + 4 * kRecMisc, 1);
+            j = uni(j);
+            if (j >= n_my) break;
+            const int v = (int)blockIdx.x + j * G;
+            const int group = v / (8 * tiles_per_frame);
+            const int rr = v - group * (8 * tiles_per_frame);
+            frame = group * 8 + (rr & 7);
+            trel = rr >> 3;
+            if (frame < w.n_frames) { have = true; break; }
+          }
+          if (!have) {
+            if (lane == 0) { recw[4 * s + 2] = 0; recw[4 * s + 3] = 0; }
+            lds_drain();
+            st_relaxed(recw + 4 * s, 0);
+          } else {
+            const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
+            const int wx0 = tx * lv.tw, wy0 = ty * lv.th;
+            const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
+            const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
+            const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
+            const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
+            const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
+                                             lv.pitch, lane);
+            const int nbatch = (lv.tw * the + 63) >> 6;
+            if (lane == 0) {
+              int* g = recw + 4 * (kRecGeo + s);
+              g[0] = twe | (the << 16); g[1] = xshift; g[2] = frame; g[3] = wx0 | (wy0 << 16);
+              recw[4 * s + 2] = nbatch; recw[4 * s + 3] = nbatch;
+            }
+            win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile has landed, the slot record too
+            st_relaxed(recw + 4 * s + 1, (t_gen & 0x7ffff) << 12);
+            st_relaxed(recw + 4 * s, 2);
+          }
+          JDA_PCAT(3);
+          continue;
+        } else if (task == 0) {
+          // ---- fresh: windows [64 j, 64 j + 64) of slot t_s from cart 0 ----
+          const int s = t_s;
+          const v4i g = rec_l[kRecGeo + s];
+          const int twe = g.x & 0xffff, the = g.x >> 16, xshift = g.y;
+          const int i = 64 * t_j + lane;
+          const int wy = cfg.tw_magic ? (int)(((unsigned)i * (unsigned)cfg.tw_magic) >> 20) : i / lv.tw;
+          const int wx = i - wy * lv.tw;
+          r_ok = wx < twe && wy < the;
+          const int base = L.slots + s * cfg.slot_bytes + (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
+          r_pk = (uint32_t)base | ((uint32_t)i << kPBaseBits) | ((uint32_t)s << (kPBaseBits + kPWidxBits));
+          r_sc = 0.f;
+          // the batch's reference on the slot becomes one reference per window (ended windows give theirs back below)
+          const int nv = __popcll(__ballot(r_ok));
+          if (nv != 1 && lane == 0) (void)__hip_atomic_fetch_add(recw + 4 * s + 3, nv - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (nv == 0) { JDA_PCAT(0); continue; }
+          rv = -1;
+        } else {
+          // ---- t_n items of shared ring t_b (already in t_it) ----
+          const int b = t_b;
+          const int dg = CF(kCfLg + b);
+          if (dg == 4 || dg == 5) {
+            // pair form: walked here, survivors straight on
+            const int np = 1 << dg;
+            const int item = lane & (np - 1);
+            const bool has_item = item < t_n;
+            const bool valid = has_item && lane < np;
+            bool alive = valid;
+            float score = __uint_as_float(t_it.y);
+            p_pair<DEPTH>(c, lfw, dg, CF(kCfBound + b), CF(kCfBound + b + 1), lane, has_item, (int)(t_it.x & ((1u << kPBaseBits) - 1u)),
+                          alive, score, my_carts);
+            if (valid && !alive) (void)__hip_atomic_fetch_add(recw + 4 * (int)(t_it.x >> (kPBaseBits + kPWidxBits)) + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            JDA_PCAT(2);
+            // survivors: next ring, or hand-off, or (ring full) walked on below as a lane = window set
+            if (b + 1 == NB) {
+              hand_off(alive, t_it.x, score);
+              if (alive) (void)__hip_atomic_fetch_add(recw + 4 * (int)(t_it.x >> (kPBaseBits + kPWidxBits)) + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              continue;
+            }
+            if (push_ring(b + 1, alive, t_it.x, score)) continue;
+            rv = b + 1; r_pk = t_it.x; r_sc = score; r_ok = alive;
+          } else {
+            rv = b; r_pk = t_it.x; r_sc = __uint_as_float(t_it.y); r_ok = lane < t_n;
+          }
+        }
       }
-      JDA_PCAT(3);
-    } else if (task == 0) {
-      // ---- fresh: windows [64 j, 64 j + 64) of slot t_s, carts [0, bound[0]) ----
-      const int s = t_s;
-      const v4i g = rec_l[kRecGeo + s];
-      const int twe = g.x & 0xffff, the = g.x >> 16, xshift = g.y;
-      const int i = 64 * t_j + lane;
-      const int wy = i / lv.tw, wx = i - wy * lv.tw;
-      bool alive = wx < twe && wy < the;
-      const int base = L.slots + s * cfg.slot_bytes + (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
-      const uint32_t packed = (uint32_t)base | ((uint32_t)i << kPBaseBits) | ((uint32_t)s << (kPBaseBits + kPWidxBits));
-      float score = 0.f;
-      p_uni<DEPTH>(c, 0, CF(kCfBound), base, alive, score, my_carts, ilp8_fresh);
-      // the batch's own reference becomes its survivors' references BEFORE they are visible in the ring (a consumer
-      // may end them at once); hand-off: the survivors have ended, the slot records are read first
-      const int ns = NB > 0 ? __popcll(__ballot(alive)) : 0;
-      if (ns > 0 && lane == 0) (void)__hip_atomic_fetch_add(recw + 4 * s + 3, ns - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      push(0, alive, packed, score);
-      if (ns == 0 && lane == 0) (void)__hip_atomic_fetch_add(recw + 4 * s + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      JDA_PCAT(0);
-    } else {
-      const int b = t_b;
-      const int c0 = CF(kCfBound + b), c1 = CF(kCfBound + b + 1);
-      const int lg = CF(kCfLg + b);
-      const uint2* ring = rings + CF(kCfOff + b);
-      const unsigned C = (unsigned)CF(kCfCap + b);
-      if (lg == 6) {
-        // ---- lane = window ----
-        bool alive = lane < t_n;
-        uint2 it = make_uint2(0u, 0u);
-        if (alive) it = ring[(unsigned)(t_start + lane) % C];
-        const bool valid = alive;
-        const int base = (int)(it.x & ((1u << kPBaseBits) - 1u));
-        float score = __uint_as_float(it.y);
-        p_uni<DEPTH>(c, c0, c1, base, alive, score, my_carts, ilp8_bucket);
-        push(b + 1, alive, it.x, score);
-        release(valid && (!alive || b + 1 == NB), it.x);
-        JDA_PCAT(1);
-      } else {
-        // ---- pair form ----
-        const int np = 1 << lg;
-        const int item = lane & (np - 1);
-        const bool has_item = item < t_n;
-        uint2 it = make_uint2(0u, 0u);
-        if (has_item) it = ring[(unsigned)(t_start + item) % C];
-        bool alive = has_item && lane < np;
-        const bool valid = alive;
-        const int base = (int)(it.x & ((1u << kPBaseBits) - 1u));
-        float score = __uint_as_float(it.y);
-        p_pair<DEPTH>(c, lfw, lg, c0, c1, lane, has_item, base, alive, score, my_carts);
-        push(b + 1, alive, it.x, score);
-        release(valid && (!alive || b + 1 == NB), it.x);
-        JDA_PCAT(2);
-      }
+    }
+
+    // ================= walk the set: carts [bound[rv], bound[rv + 1]), lane = window (the one hot call site) =================
+    {
+      const int c0 = rv < 0 ? 0 : CF(kCfBound + rv), c1 = CF(kCfBound + rv + 1);
+      bool alive = r_ok;
+      if (any_norm) p_uni<DEPTH, true>(c, c0, c1, (int)(r_pk & ((1u << kPBaseBits) - 1u)), alive, r_sc, my_carts, rv < 0 ? ilp8_fresh : ilp8_bucket);
+      else p_uni<DEPTH, false>(c, c0, c1, (int)(r_pk & ((1u << kPBaseBits) - 1u)), alive, r_sc, my_carts, rv < 0 ? ilp8_fresh : ilp8_bucket);
+      const int nx = rv + 1;               // the survivors have completed bound[nx] carts
+      if (nx == NB) { hand_off(alive, r_pk, r_sc); alive = false; }
+      // windows that have ended give their references back
+      if (r_ok && !alive) (void)__hip_atomic_fetch_add(recw + 4 * (int)(r_pk >> (kPBaseBits + kPWidxBits)) + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      JDA_PCAT(rv < 0 ? 0 : 1);
+      rv = -2;
+      const unsigned long long mask = __ballot(alive);
+      const int n = __popcll(mask);
+      if (n == 0) continue;
+      // the ring of their level; when it is full the same lanes walk on through the next range
+      if (!push_ring(nx, alive, r_pk, r_sc)) { rv = nx; r_ok = alive; }
     }
   }
 

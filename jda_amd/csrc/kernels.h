@@ -227,6 +227,8 @@ struct PScanCfg {
   int lg[kPScanMaxBuckets];
   int slots, slot_bytes, opts;
   int bound_last;                      // = bound[nb]
+  int any_norm;                        // a cart of [0, bound_last) normalises its score (mean, std != 0, 1)
+  int tw_magic;                        // ceil(2^20 / tile width in windows) where i / tw == (i * magic) >> 20 for every window index of a tile, else 0
   int ring_cap[kPScanMaxBuckets], ring_off[kPScanMaxBuckets], ring_items;     // items per ring / first item / all rings (scan_p_ring_caps)
 };
 void scan_p_ring_caps(PScanCfg* cfg, int waves);

@@ -29,11 +29,13 @@ def same(a, b):
 
 VARIANTS = [
     {"JDA_SCAN_P": "2"},
-    {"JDA_SCAN_P": "2", "JDA_SCAN_P_BLOCK": "512"},
-    {"JDA_SCAN_P": "2", "JDA_SCAN_P_LG": "66666"},
-    {"JDA_SCAN_P": "2", "JDA_SCAN_P_LG": "55555", "JDA_SCAN_P_BLOCK": "256", "JDA_SCAN_P_SLOTS": "2"},
-    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "8", "JDA_SCAN_P_B1": "24", "JDA_SCAN_P_B2": "40", "JDA_SCAN_P_B3": "100", "JDA_SCAN_P_B4": "120", "JDA_SCAN_P_LG": "65454", "JDA_SCAN_P_OPTS": "3"},
-    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "4", "JDA_SCAN_P_B1": "0", "JDA_SCAN_P_B2": "0", "JDA_SCAN_P_B3": "0", "JDA_SCAN_P_LG": "4", "JDA_SCAN_P_BLOCK": "128"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "16", "JDA_SCAN_P_B1": "32", "JDA_SCAN_P_B2": "48", "JDA_SCAN_P_B3": "64", "JDA_SCAN_P_B4": "96", "JDA_SCAN_P_LG": "66666", "JDA_SCAN_P_BLOCK": "1024"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_RING": "64", "JDA_SCAN_P_B2": "96"},                     # small rings: survivors walk on in their task
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_RING": "64", "JDA_SCAN_P_B0": "16", "JDA_SCAN_P_B1": "32", "JDA_SCAN_P_B2": "48", "JDA_SCAN_P_B3": "64", "JDA_SCAN_P_B4": "96", "JDA_SCAN_P_LG": "64545", "JDA_SCAN_P_BLOCK": "512"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B2": "96", "JDA_SCAN_P_LG": "632", "JDA_SCAN_P_BLOCK": "256", "JDA_SCAN_P_SLOTS": "2"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "8", "JDA_SCAN_P_B1": "24", "JDA_SCAN_P_B2": "40", "JDA_SCAN_P_B3": "100", "JDA_SCAN_P_B4": "120", "JDA_SCAN_P_LG": "65454", "JDA_SCAN_P_OPTS": "3", "JDA_SCAN_P_RING": "64"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "4", "JDA_SCAN_P_B1": "0", "JDA_SCAN_P_LG": "4", "JDA_SCAN_P_BLOCK": "128"},
+    {"JDA_SCAN_P": "2", "JDA_SCAN_P_B0": "0", "JDA_SCAN_P_B1": "0"},
 ]
 
 def case(dims, cart_th, size, n, th=-0.5, seed=3, norm_every=5, variants=VARIANTS):
@@ -69,7 +71,7 @@ if __name__ == "__main__":
         bad += case((3, 70, 9, 5), -1.0, (202, 150), 2)                     # depth 5, 4-byte aligned rows
         bad += case((2, 64, 68, 6), -1.0, (200, 150), 2)
         bad += case((1, 4, 3, 2), -0.3, (200, 150), 2)
-        bad += case((5, 540, 27, 4), -2.0, (640, 480), 16, variants=VARIANTS[:3])
+        bad += case((5, 540, 27, 4), -2.0, (640, 480), 16, variants=VARIANTS[:4])
         bad += case((5, 540, 27, 4), synth.NEG_BIG, (160, 120), 1, variants=VARIANTS[:2])
     print("TOTAL BAD", bad)
     sys.exit(1 if bad else 0)
