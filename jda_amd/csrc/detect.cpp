@@ -110,6 +110,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
+  X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
   X(scan_p_min_slots, "JDA_SCAN_P_MIN_SLOTS", 4) /* ... pixel-tile slots a level's workgroup must have room for (scan_p = 1) */ \
@@ -1119,7 +1120,8 @@ struct Pass {
       }
       auto scan = [&](int mode, int level, hipStream_t s) -> bool {
         // (opts bit 0, 8 trees in flight per lane in the LDS-tiled modes, was measured neutral to slower: off)
-        const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
+        const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
+                         (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
         if (mode == 1 && level >= 0 && scan_persistent(level, s)) { rs->scan_launches++; return true; }
         JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, s));
         rs->scan_launches++;
@@ -1216,7 +1218,8 @@ struct Pass {
     if (timed) JDA_HIP(hipEventRecord(ev[1], st));
     const int handoff = (int)kn().handoff;
     const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
-    const int opts = (int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8;
+    const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
+                     (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
     for (const RaggedChunk::Launch& l : ch.launches) {
       JDA_HIP(launch_scan_ragged<Real>(l.mode, l.block, false, handoff, cp_max, opts, pe->dp, m, pe->table, w, l.pix_bytes,
                                        l.blk_base, l.blk_n, st));

@@ -66,7 +66,9 @@ size_t scan_lds_bytes(int pix_bytes, int carts, int node_n, int leaf_n, int real
 // RAGGED: the block map of a ragged batch names the tile (kernels.h: RagSeg / RagBlk).  A template parameter, not a
 // run-time test: with the two ways of finding the tile in one kernel the uniform batch ran 13 % slower (r03, same
 // opcode counts -- the level record no longer stayed where the hot loop wants it).
-template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK, bool RAGGED = false>
+// NORM = false: no cart of [0, K) normalises its score (known on the host): the per-cart test of the flag and its branch
+// leave the walks (k_scan_p measured -23 % per walk from this; a run-time flag instead of the template parameter: no gain).
+template <typename Real, int DEPTH, bool TRACE, int MODE, int BLOCK, bool RAGGED = false, bool NORM = true>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 6 : 4)))
 void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                                                 const S0Node* __restrict__ table, WorkT<Real> w,
@@ -255,7 +257,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
         for (int u = 0; u < CNT; u++) {
           if (!dead) {
             s = s + lsv[u];                                                  // c/jda.c:396
-            if (p[u].norm != (Real)0) { const CartPar<Real> q = t_par[k + u]; s = (s - q.mean) / q.std; }   // c/jda.c:397 (rare)
+            if (NORM && p[u].norm != (Real)0) { const CartPar<Real> q = t_par[k + u]; s = (s - q.mean) / q.std; }   // c/jda.c:397 (rare)
             if (TRACE) hash = fnv_step(hash, lf[u]);
             kd = k + u;
             dead = s < p[u].th;                                              // c/jda.c:399
@@ -414,7 +416,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
             for (; k + 16 <= r1; k += 16) {
               if (__ballot(alive) == 0ull) break;
               const ThNorm<Real> pm = *(const ThNorm<Real>*)&t_par[k + (lane & 15)];   // lane u (mod 16): cart k+u
-              if (__ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
+              if (NORM && __ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
               // thresholds: lane u holds cart k+u's; broadcast with readlane HERE, with the whole wave
               // active -- inside the divergent block below the lanes without a live window would not
               // have loaded theirs
@@ -581,6 +583,15 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
     hipLaunchKernelGGL(kern, grid, block, lds_req, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
                        pix_bytes, handoff, chunk, cp_max, opts, 0);
   };
+  // (opts bit 1: no cart of [0, handoff) normalises -- the lean instantiation, dialect C without trace only)
+  if constexpr (sizeof(Real) == 4 && !TRACE) {
+    if (opts & 2) {
+      if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, false, false>);
+      else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, false, false>);
+      else go(k_scan<Real, 0, TRACE, MODE, BLOCK, false, false>);
+      return hipGetLastError();
+    }
+  }
   if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK>);
   else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK>);
   else go(k_scan<Real, 0, TRACE, MODE, BLOCK>);
@@ -629,6 +640,14 @@ hipError_t launch_scan_ragged_mode(const DevPlan* d_plan, const DevModelT<Real>&
     hipLaunchKernelGGL(kern, dim3((unsigned)blk_n), dim3(BLOCK), L.total, stream, d_plan, m, table, w, -1, 0,
                        pix_bytes, handoff, chunk, cp_max, opts, blk_base);
   };
+  if constexpr (sizeof(Real) == 4 && !TRACE) {
+    if (opts & 2) {
+      if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, true, false>);
+      else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, true, false>);
+      else go(k_scan<Real, 0, TRACE, MODE, BLOCK, true, false>);
+      return hipGetLastError();
+    }
+  }
   if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, true>);
   else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, true>);
   else go(k_scan<Real, 0, TRACE, MODE, BLOCK, true>);
