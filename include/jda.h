@@ -67,7 +67,10 @@ JDA_API void *jdaCascadorCreateFloat(const char *model);
  * Silently returns if the file cannot be created, like the reference. */
 JDA_API void jdaCascadorSerializeTo(void *cascador, const char *model);
 
-/* replaces reference c/jda.c:718-720 (c/jda.h:47). NULL is accepted. */
+/* replaces reference c/jda.c:718-720 (c/jda.h:47). NULL is accepted.
+ * Batches that were submitted (jdaDetectBatchSubmit*) and never waited for are drained.  Like the reference's, this
+ * must not race with a call on the same cascador from another thread: the reference frees what jdaDetect reads; here
+ * such a call is given up to ten seconds to return before the cascador goes (tests/test_reentrant.py). */
 JDA_API void jdaCascadorRelease(void *cascador);
 
 /* replaces reference c/jda.c:443-480 (c/jda.h:62-63).

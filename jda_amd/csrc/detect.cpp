@@ -110,6 +110,8 @@ static long long env_ll(const char* name, long long dflt) {
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 6000000) /* windows per chunk of a ragged batch */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
+  X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
+  X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
   X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
@@ -135,7 +137,14 @@ struct Knobs {
     JDA_KNOBS(X)
 #undef X
   }
+  // Values no code path can work with are refused (jdaSetOption returns -1): negative sizes and counts; the rest of
+  // a knob's range is clamped where it is used.
   bool set(const char* key, long long v) {
+    static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "host_chunk", "ragged_chunk_windows",
+                                               "h2d_min_bytes", "merge_blocks", "finish_merge", "wide_max", "lanes_min_windows",
+                                               "ragged_stage_threads", "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls"};
+    for (const char* k : non_negative) if (std::strcmp(key, k) == 0 && v < 0) return false;
+    if (std::strcmp(key, "workspace_mb") == 0 && v < 1) return false;
 #define X(name, env, dflt) if (std::strcmp(key, #name) == 0) { name = v; return true; }
     JDA_KNOBS(X)
 #undef X
@@ -270,6 +279,7 @@ struct HostPinned {
 // jdaDetect re-entrant on ONE cascador (the reference has no globals and no locks, c/jda.c:443-480).
 struct Lane {
   bool busy = false;
+  unsigned idle = 0;                         // lane hand-outs since this one was last used (free lanes only)
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;                // global-pixel scan launch of a lone lane, next to its LDS-tiled launches
   hipEvent_t ev[5] = {};
@@ -301,11 +311,19 @@ struct Lane {
     for (auto& e : ev_side) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return true;
   }
+  // The memory of a lane nobody has used for a while (a burst of concurrent callers leaves lanes behind, each with a
+  // workspace of up to workspace_mb): everything that is re-created on demand.  The lane is free and its holder has
+  // collected what ran on it, so nothing is in flight.
+  void trim() {
+    ws.release(); frames.release(); pyr.release(); rag_frames.release(); rag_raw.release(); rag_tab.release();
+    h_gid.release(); h_score.release(); h_shape.release(); h_tab.release(); h_raw.release();
+    cap = 0; trace = false; dim = 0; real_bytes = 0;
+    wf = WorkT<float>{}; wd = WorkT<double>{};
+  }
   void destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (side) (void)hipStreamSynchronize(side);
-    ws.release(); frames.release(); pyr.release(); rag_frames.release(); rag_raw.release(); rag_tab.release();
-    h_gid.release(); h_score.release(); h_shape.release(); h_tab.release(); h_raw.release();
+    trim();
     if (h_cnt) (void)hipHostFree(h_cnt);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
@@ -337,6 +355,7 @@ struct Cascador {
   hipStream_t h2d = nullptr;
   std::mutex h2d_mu;
   std::vector<std::unique_ptr<Lane>> lanes;
+  std::condition_variable lane_cv;           // a lane was given back (callers beyond max_lanes wait here, with mu)
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
   std::map<PlanKey, PlanEntry> plans;
@@ -387,8 +406,10 @@ static bool ensure_device(Cascador* c) {
 }
 
 // A free lane (caller holds c->mu): the one whose workspace fits `want_cap` windows most tightly, else the largest,
-// else a new one.
-static Lane* acquire_lane_locked(Cascador* c, size_t want_cap) {
+// else a new one -- unless the pool has reached max_lanes: then nullptr with *exhausted set (the caller waits for a
+// lane to come back, or goes on with the lanes it holds).  Free lanes that were passed over `lane_idle_calls` times
+// give their buffers back.
+static Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted = nullptr) {
   Lane* best = nullptr;
   for (auto& up : c->lanes) {
     Lane* l = up.get();
@@ -398,12 +419,20 @@ static Lane* acquire_lane_locked(Cascador* c, size_t want_cap) {
     if (fit != bfit ? fit : (fit ? l->cap < best->cap : l->cap > best->cap)) best = l;
   }
   if (!best) {
+    if ((long long)c->lanes.size() >= std::max<long long>(1, c->kn.max_lanes)) { if (exhausted) *exhausted = true; return nullptr; }
     std::unique_ptr<Lane> l(new (std::nothrow) Lane());
     if (!l || !l->create()) { if (l) l->destroy(); return nullptr; }
     best = l.get();
     c->lanes.push_back(std::move(l));
   }
+  const long long idle_max = c->kn.lane_idle_calls;
+  for (auto& up : c->lanes) {
+    Lane* l = up.get();
+    if (l->busy || l == best) continue;
+    if (idle_max > 0 && ++l->idle > (unsigned long long)idle_max && (l->ws.p || l->frames.p || l->rag_frames.p)) l->trim();
+  }
   best->busy = true;
+  best->idle = 0;
   return best;
 }
 
@@ -414,11 +443,31 @@ struct LaneSet {
   explicit LaneSet(Cascador* c_) : c(c_) {}
   LaneSet(const LaneSet&) = delete;
   LaneSet& operator=(const LaneSet&) = delete;
-  bool take(int n, size_t want_cap = 0) {
-    std::lock_guard<std::mutex> lk(c->mu);
+  // Up to n lanes in all.  With the pool at max_lanes and nothing free, a caller that holds no lane yet waits (callers
+  // queue up, they do not fail); one that already holds a lane goes on with what it has -- check v.size() -- so that
+  // two callers can never wait for each other's lanes.  all = true (a caller that holds none and needs all n, at most
+  // max_lanes of them): waits until it can have them all at once.
+  bool take(int n, size_t want_cap = 0, bool all = false) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    const int cap_lanes = (int)std::max<long long>(1, c->kn.max_lanes);
+    if (all && v.empty()) {
+      n = std::min(n, cap_lanes);
+      for (;;) {
+        int avail = cap_lanes - (int)c->lanes.size();
+        for (auto& up : c->lanes) avail += up->busy ? 0 : 1;
+        if (avail >= n) break;
+        c->lane_cv.wait(lk);
+      }
+    }
     while ((int)v.size() < n) {
-      Lane* l = acquire_lane_locked(c, want_cap);
-      if (!l) return false;
+      bool exhausted = false;
+      Lane* l = acquire_lane_locked(c, want_cap, &exhausted);
+      if (!l) {
+        if (!exhausted) return false;
+        if (!v.empty()) return true;
+        c->lane_cv.wait(lk);
+        continue;
+      }
       v.push_back(l);
     }
     return true;
@@ -426,8 +475,8 @@ struct LaneSet {
   Lane* detach(size_t i) { Lane* l = v[i]; v.erase(v.begin() + i); return l; }   // the caller keeps it (submitted batch)
   ~LaneSet() {
     if (v.empty()) return;
-    std::lock_guard<std::mutex> lk(c->mu);
-    for (Lane* l : v) l->busy = false;
+    { std::lock_guard<std::mutex> lk(c->mu); for (Lane* l : v) l->busy = false; }
+    c->lane_cv.notify_all();
   }
 };
 
@@ -746,18 +795,26 @@ static bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int di
     pe.dp = b.dp; pe.table = b.table; pe.table_cap = b.table_cap;
     if (pe.table_cap < entries) { if (pe.table) (void)hipFree(pe.table); pe.table = nullptr; pe.table_cap = 0; }
   }
-  if (!pe.dp) JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
-  JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
-  if (entries) {
-    if (!pe.table) {
-      pe.table_cap = std::max(entries, (size_t)16 * n0);      // room for 16 levels: most recycled tables fit the next plan
-      JDA_HIP(hipMalloc((void**)&pe.table, 2 * pe.table_cap * sizeof(S0Node)));   // cart-major tables + their level-major copy
+  // (a failure below must not lose the device allocations: whatever the entry holds goes back to the pool)
+  auto build = [&]() -> bool {
+    if (!pe.dp) JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
+    JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
+    if (entries) {
+      if (!pe.table) {
+        pe.table_cap = std::max(entries, (size_t)16 * n0);      // room for 16 levels: most recycled tables fit the next plan
+        JDA_HIP(hipMalloc((void**)&pe.table, 2 * pe.table_cap * sizeof(S0Node)));   // cart-major tables + their level-major copy
+      }
+      const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
+      const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
+      JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->aux));
+      // the scans that read the table run on the lanes' streams
+      JDA_HIP(hipStreamSynchronize(c->aux));
     }
-    const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
-    const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
-    JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->aux));
-    // the scans that read the table run on the lanes' streams
-    JDA_HIP(hipStreamSynchronize(c->aux));
+    return true;
+  };
+  if (!build()) {
+    if (pe.dp || pe.table) c->plan_pool.push_back({pe.dp, pe.table, pe.table ? pe.table_cap : 0});
+    return false;
   }
   pe.last_use = ++c->plan_clock;
   pe.pred_tail = c->pred_tail; pe.pred_out = c->pred_out;      // a new frame size starts from the cascador's last pass
@@ -1435,6 +1492,7 @@ struct PendingBatch {
   // host-frame submits: the H2D copy (blocking for pageable memory) and the scan launches run on a helper thread,
   // so that the submitting thread is free to collect the other ticket meanwhile
   std::thread issuer;
+  std::vector<const unsigned char*> host_ptrs;   // the caller's frame pointers, copied at Submit (only the frame BYTES must stay valid until Wait)
   bool issue_ok = true;
   std::string issue_err;
   void join_issuer() { if (issuer.joinable()) issuer.join(); }
@@ -1462,9 +1520,33 @@ struct HostFrames {
 // sub-batch by sub-batch).  `lanes` holds the call's first lane; a large batch takes a second one from the pool and
 // is split into sub-batches that alternate between the two (streams with their own workspace), see Pass.
 template <typename Real>
+static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+                            bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
+                            const TraceOut<Real>* trace, RunStats* rs, HostFrames host);
+
+// A pass that fails half way (an allocation, a launch, a detection list beyond its capacity) leaves work queued on the
+// lanes' streams: kernels that still read the caller's frames, copies out of the caller's host memory, writes into
+// the lanes' pinned buffers.  The lanes go back to the pool and the caller may free its frames as soon as this
+// returns, so everything queued is waited for first.
+template <typename Real>
 static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
                        bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
                        const TraceOut<Real>* trace, RunStats* rs, HostFrames host = HostFrames()) {
+  if (run_device_impl<Real>(c, lanes_held, pe, d_frames, stride, n, apply_th, th, user_stream, dets, trace, rs, host)) return true;
+  for (Lane* l : lanes_held.v) {
+    (void)hipStreamSynchronize(l->stream);
+    if (l->side) (void)hipStreamSynchronize(l->side);
+  }
+  if (user_stream) (void)hipStreamSynchronize(user_stream);
+  if (host.ptrs && c->h2d) (void)hipStreamSynchronize(c->h2d);
+  (void)hipGetLastError();
+  return false;
+}
+
+template <typename Real>
+static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+                            bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
+                            const TraceOut<Real>* trace, RunStats* rs, HostFrames host) {
   constexpr int dialect = Sel<Real>::dialect;
   const HostModel& hm = c->hm;
   const int dim = hm.dim();
@@ -1511,6 +1593,7 @@ static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const ui
   }
   const size_t cap = (size_t)fpp * (size_t)wpf;
   if (!lanes_held.take(lanes, cap)) return false;
+  lanes = std::min(lanes, (int)lanes_held.v.size());          // (the pool is at max_lanes: the sub-batches share the lane(s) at hand)
   for (int l = 0; l < lanes; l++)
     if (!ensure_workspace<Real>(lanes_held.v[l], cap, want_trace, dim)) return false;
 
@@ -1636,8 +1719,8 @@ class PostPool {
       if (!ready_.load(std::memory_order_acquire)) {
         const unsigned hwc = std::thread::hardware_concurrency();
         const int nw = (int)std::min<unsigned>(6, hwc > 2 ? hwc / 2 : 0);
-        for (int i = 0; i < nw; i++) workers_.emplace_back([this]() { loop(); });
-        if (nw > 0) ready_.store(true, std::memory_order_release); else auto_ = false;
+        spawn(nw);
+        if (!workers_.empty()) ready_.store(true, std::memory_order_release); else auto_ = false;
       }
     }
     const bool use = !ready_.load(std::memory_order_acquire) ? false : (heavy ? n >= 2 : n >= 64);
@@ -1676,8 +1759,15 @@ class PostPool {
     auto_ = want < 0;
     const unsigned hwc = std::thread::hardware_concurrency();
     const int nw = (int)std::max<long long>(0, std::min<long long>(want, hwc > 1 ? hwc - 1 : 0));
-    for (int i = 0; i < nw; i++) workers_.emplace_back([this]() { loop(); });
-    ready_.store(nw > 0);
+    spawn(nw);
+    ready_.store(!workers_.empty());
+  }
+  // (a thread that cannot be started is not an error: the job runs on fewer workers, or serially on the caller)
+  void spawn(int nw) {
+    for (int i = 0; i < nw; i++) {
+      try { workers_.emplace_back([this]() { loop(); }); }
+      catch (const std::system_error&) { break; }
+    }
   }
   ~PostPool() {
     { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -1940,7 +2030,10 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
   p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
   p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
-  if (host_frames) { p.host_frames = host_frames; p.host_fbytes = (size_t)width * height; }
+  if (host_frames) {
+    pb.host_ptrs.assign(host_frames, host_frames + n);       // (the helper thread reads them after Submit has returned)
+    p.host_frames = pb.host_ptrs.data(); p.host_fbytes = (size_t)width * height;
+  }
   auto give_up = [&]() { std::lock_guard<std::mutex> lk(c->mu); pb.reserved = false; return -1; };
   // opt->hip_stream: the stream the caller produced the frames on -- the scan is ordered behind the work
   // already queued there (the batch itself still runs on the lane's own stream)
@@ -1962,12 +2055,16 @@ static int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, 
     pb.issue_ok = true; pb.issue_err.clear();
     PendingBatch* pbp = &pb;
     const int dev = c->device;
-    pb.issuer = std::thread([pbp, dev]() {
+    auto issue = [pbp, dev]() {
       if (hipSetDevice(dev) != hipSuccess || !pbp->pass.issue_scan(nullptr, 0, nullptr, 0, nullptr)) {
         pbp->issue_ok = false;
         pbp->issue_err = g_err.empty() ? std::string("issuing the batch failed") : g_err;
       }
-    });
+    };
+    // (no C++ exception may cross the C ABI: when the process cannot start another thread the batch is issued here,
+    // as with host_submit_thread = 0 -- the ticket is committed already, Wait reports issue_ok)
+    try { pb.issuer = std::thread(issue); }
+    catch (const std::system_error&) { issue(); }
     return slot;
   }
   if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { (void)hipStreamSynchronize(ln->stream); return give_up(); }
@@ -2010,7 +2107,7 @@ static int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out)
     std::lock_guard<std::mutex> lk(c->mu);
     if (pb.pe && pb.pe->pins > 0) pb.pe->pins--;
     pb.pe = nullptr;
-    if (pb.lane) pb.lane->busy = false;
+    if (pb.lane) { pb.lane->busy = false; c->lane_cv.notify_all(); }
     pb.lane = nullptr;
     pb.active = false; pb.waiting = false;
   }
@@ -2440,11 +2537,11 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     starts.push_back(n);
   }
   const int n_chunks = (int)starts.size() - 1;
-  const int lanes = std::min(kRaggedLanes, n_chunks);
+  const int lanes = std::min(std::min(kRaggedLanes, n_chunks), (int)std::max<long long>(1, c->kn.max_lanes));
   struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
   LaneSet held(c);
-  if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0)) return -1;
+  if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0, true)) return -1;
   bool ok = true;
 
   // ---- host images, several chunks: a helper thread brings chunk after chunk into a buffer of the job (the first
@@ -2462,7 +2559,7 @@ static int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, con
     std::string err;
     ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
   } up;
-  if (helper && n_chunks > 1 && held.v[0]->rag_raw.reserve(tight[n] + 16)) {
+  if (helper && n_chunks > 1 && lanes > 1 && held.v[0]->rag_raw.reserve(tight[n] + 16)) {
     size_t most = 0;
     job.raw_off.assign(n_chunks + 1, 0);
     for (int k = 0; k < n_chunks; k++) { job.raw_off[k + 1] = tight[starts[k + 1]]; most = std::max(most, job.raw_off[k + 1] - job.raw_off[k]); }
@@ -2631,7 +2728,20 @@ void jdaCascadorSerializeTo(void* cascador, const char* model) {
 void jdaCascadorRelease(void* cascador) {
   Cascador* c = (Cascador*)cascador;
   if (!c) return;
-  for (int i = 0; c->pending && i < kTickets; i++) c->pending[i].join_issuer();    // a submitted batch nobody waited for
+  // Submitted batches nobody waited for are drained here (their helper threads joined, their streams synchronised by
+  // Lane::destroy).  A call still running on another thread is the caller's error, as with the reference, whose
+  // release frees what jdaDetect reads (c/jda.c:718-720); such a call is given ten seconds to return before the
+  // lanes go -- a race at shutdown then ends in a late but orderly release instead of a use-after-free.
+  for (int i = 0; c->pending && i < kTickets; i++) c->pending[i].join_issuer();
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    for (int i = 0; c->pending && i < kTickets; i++)
+      if (c->pending[i].active && c->pending[i].lane) { c->pending[i].lane->busy = false; c->pending[i].active = false; }
+    c->lane_cv.wait_for(lk, std::chrono::seconds(10), [&]() {
+      for (auto& l : c->lanes) if (l->busy) return false;
+      return true;
+    });
+  }
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
     for (auto& l : c->lanes) l->destroy();

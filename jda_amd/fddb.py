@@ -121,7 +121,7 @@ def detect_fold_ragged(casc, grays, c_call=None):
 
 
 def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, world=1, device=None, log=None,
-        ragged=None):
+        ragged=None, c_call=None):
     """The whole `jda fddb` run.  With world > 1 the images are split in contiguous blocks over the
     ranks, every rank detects its block, and the (image, rect, score, landmarks) rows
     are gathered on rank 0, which writes the ten fold-XX-out.txt files.  Returns per-fold stats on rank 0.
@@ -133,13 +133,16 @@ def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, 
     L = casc.L
     rows, local_stats, skipped = [], {}, []
     if ragged is None:
-        ragged = dialect == "c" and hasattr(casc, "detect_ragged")
+        # (the ragged entry is an additive symbol: an older libjda.so loaded through JDA_LIB_PATH may lack it -- then the
+        # fold goes image by image, like the reference's loop)
+        from . import api as japi
+        ragged = dialect == "c" and hasattr(japi.lib, "jdaDetectBatchRagged")
     pending = []                                              # (idx, gray) of the fold being collected
 
     def flush(fold):
         if not pending:
             return []
-        per_image, st = detect_fold_ragged(casc, [g for _, g in pending])
+        per_image, st = detect_fold_ragged(casc, [g for _, g in pending], c_call)
         local_stats.setdefault(fold, FoldStats()).add(st)
         done = [(i, r) for (i, _), r in zip(pending, per_image)]
         del pending[:]
@@ -162,7 +165,7 @@ def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, 
         elif ragged:
             pending.append((idx, gray))
         else:
-            rects, scores, shapes, st = detect_image(casc, gray, dialect, params)
+            rects, scores, shapes, st = detect_image(casc, gray, dialect, params, c_call)
             local_stats.setdefault(fold, FoldStats()).add(st)
             emit(idx, rects, scores, shapes)
         if ragged and (idx + 1 == hi or job[idx + 1][0] != fold):
