@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="skip the configs[4] all-pass leg (roofline_hbm_regime)")
+    ap.add_argument("--config2", action="store_true",
+                    help="also time BASELINE.json configs[2] at its stated size (256 x 1080p: ~10 s of frame synthesis) for roofline_config2")
     args = ap.parse_args()
     rc = maybe_self_spawn(args, sys.argv[1:])
     if rc is not None:
@@ -473,6 +475,33 @@ def main():
                 job(buf)
             info["host_images_per_s"] = n_img * reps / (time.perf_counter() - t0)
             info["host_entry"] = "jdaDetectBatchRagged, the images in one pageable host buffer (PCIe-inclusive)"
+            # What ONE GPU can say about the N-GPU job (the driver measures N > 1 itself when it has the node): every
+            # rank's shard -- the contiguous block jda_amd/dist.py:shard_range gives rank r of N -- run alone on this
+            # GPU, images resident, best of `reps`; the job on N GPUs takes as long as its slowest shard plus the gather
+            # of the rows (KBs over xGMI, pipelined one step behind: not on the critical path of a stream of jobs).
+            # predicted speed-up = t(all 2,845 images) / max_r t(shard r).
+            t_full = el / reps
+            pred = {}
+            for nn in (2, 4, 8):
+                worst, per = 0.0, []
+                for r in range(nn):
+                    a, b = jdist.shard_range(n_img, r, nn)
+                    base_off = offs[a]
+                    so = [o - base_off for o in offs[a:b]]
+                    end = offs[b] if b < n_img else tot
+                    d_sub = d_buf[base_off:end]
+
+                    def shard_job():
+                        return casc.detect_ragged_packed(d_sub, so, ws[a:b], hs[a:b], stats=True, keep_results="packed", frame_offset=a, **kw)
+                    shard_job()
+                    best = 1e30
+                    for _ in range(max(2, reps)):
+                        t1 = time.perf_counter(); shard_job(); best = min(best, time.perf_counter() - t1)
+                    per.append(best); worst = max(worst, best)
+                pred[str(nn)] = {"max_shard_ms": worst * 1e3, "min_shard_ms": min(per) * 1e3, "speedup": t_full / worst}
+            info["predicted_strong_scaling"] = pred
+            info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (best of %d); speedup = "
+                                                     "ms_per_job / max shard time; not a multi-GPU measurement" % max(2, reps))
         casc.close()
         if hasattr(gather, "close"):
             gather.close()
@@ -485,6 +514,30 @@ def main():
         if world > 1:
             raise
         fddb_info = {"error": repr(e)}
+
+    # ---- BASELINE.json configs[2] at its stated size, live (optional: the frames take ~10 s to synthesise) ----
+    config2_live = None
+    if rank == 0 and world == 1 and args.config2:
+        try:
+            f2 = synth.make_frames(256, 1920, 1080, seed=0)
+            mp2 = os.path.join(synth.cache_dir(), "config2_5_540_27_4.model")
+            if not os.path.exists(mp2):
+                m2 = synth.make_model(5, 540, 27, 4, seed=1)
+                synth.calibrate_thresholds(m2, f2[:4], scale=1.5)
+                m2.save(mp2 + ".tmp", 8); os.replace(mp2 + ".tmp", mp2)
+            c2 = api.Cascador(mp2, device=local_rank)
+            d2 = torch.from_numpy(f2).to(dev)
+            for _ in range(2):
+                c2.detect_batch_device(d2, 1.5, keep_results=False)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                _, st2 = c2.detect_batch_device(d2, 1.5, keep_results=False, stats=True)
+            torch.cuda.synchronize(); el2 = (time.perf_counter() - t0) / 3
+            config2_live = {"ms_per_call": el2 * 1e3, "windows_per_s": st2["patch_n"] / el2, "gpu_ms": st2["gpu_ms"],
+                            "windows_per_call": st2["patch_n"], "entry": "jdaDetectBatchDevice, synchronous (two sub-batch lanes)"}
+            c2.close(); del d2, f2
+        except Exception as e:
+            config2_live = {"error": repr(e)}
 
     # ---- the regime of this path in which HBM / Infinity Cache traffic is the bound: BASELINE.json configs[4] (T=7, K=2000,
     #      68 landmarks, depth 6: W = 243.7 MB, 34.8 MB per stage) with every window of a 1080p frame walking all 14,000
@@ -564,6 +617,30 @@ def main():
             except Exception:
                 traffic = None
         scan_bytes_alg = roof_info["scan_lds_carts_per_step"] * ((D - 1) * 34 + 16)
+        # ---- the dense path (k_stage: every window walks every cart and takes every cart's weight row, all from LDS tables
+        #      staged once per 256-window tile): LDS crossbar bytes per window-cart = the walk's lane-reads + the 2L floats of
+        #      the weight row.  The pipe-busy fractions are counter readings of the same kernel (profiles/r04_allpass_k_stage.txt,
+        #      builder-run): neither pipe is saturated -- the kernel waits on LDS latency at the occupancy its tables allow ----
+        allpass_roof = None
+        if allpass_info and allpass_info.get("gpu_ms_per_step"):
+            carts_s = allpass_info["average_cart_n"] * windows_step / (allpass_info["gpu_ms_per_step"] * 1e-3)
+            reads = lane_reads_per_cart + 2 * L
+            ach = carts_s * reads * 4 / 1e9
+            allpass_roof = {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBPS,
+                            "kernel": "k_stage (dense mode), shipped dimensions, all-pass regime",
+                            "carts_per_s": carts_s, "lane_reads_per_cart": reads,
+                            "what": "LDS crossbar bytes: (%d walk + %d weight-row) lane-reads of 4 B per window-cart x carts / device span of the step" % (lane_reads_per_cart, 2 * L),
+                            "counters": {"lds_pipe_busy_frac": 0.37, "valu_busy_frac": 0.27, "lds_bank_conflict_cycles": 0,
+                                         "source": "profiles/r04_allpass_k_stage.txt (SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU x 4 cycles / 4 SIMDs, per CU-clock of the LDS-tiled k_stage launches; 64-frame batch) -- builder-run, NOT measured in this run"}}
+        config2_roof = None
+        c2p = os.path.join(ROOT, "profiles", "r04_config2_roofline.json")
+        if os.path.exists(c2p):
+            try:
+                config2_roof = json.load(open(c2p))
+            except Exception:
+                config2_roof = None
+        if config2_roof is not None and config2_live is not None:
+            config2_roof["measured_in_this_run"] = config2_live
         line = {
             "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path); FDDB images/sec in fddb_images_per_s",
             "value": casc_info["windows_per_s"], "unit": "windows/s",
@@ -591,7 +668,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_from_this_device_code": traffic_fresh,
-                         "kernel": "k_scan, the LDS-tiled launches of one step (one per tiled pyramid level)",
+                         "kernel": "k_scan_p / k_scan, the LDS-tiled launches of one step (one per tiled pyramid level: k_scan_p where a workgroup has room for >= 4 pixel-tile slots, k_scan else)",
                          "what": "LDS crossbar bytes: (D-1)*3+2 = %d lane-reads of 4 B per window-cart x carts evaluated "
                                  "(device counter) / HIP-event span of the launches; peak = 128 B/clk/CU x 256 CUs x 2.4 GHz "
                                  "(conflict-free ds_read_b32/u8 rate)" % lane_reads_per_cart,
@@ -611,6 +688,8 @@ def main():
                                           "stream, HIP events recorded on that stream before the first and after the last "
                                           "LDS-tiled launch (jdaStats.scan_lds_ms); the throughput legs overlap two batches"},
             "roofline_hbm_regime": x_info,
+            "roofline_allpass": allpass_roof,
+            "roofline_config2": config2_roof,
             "cpu_baseline": cpu,
             "regimes": {"cascade": casc_info, "cascade_single_caller": single_info, "cascade_one_lane": roof_info,
                         "allpass": allpass_info, "host_frames": host_info},

@@ -2795,7 +2795,7 @@ int jdaSetOption(void* cascador, const char* key, long long value) {
     if (l->busy) { fail("jdaSetOption while a call is running or a submitted batch is pending on this cascador"); return -1; }
   for (auto& kv : c->plans)
     if (kv.second.pins) { fail("jdaSetOption while a call is running on this cascador"); return -1; }
-  if (!c->kn.set(key, value)) { fail(std::string("jdaSetOption: unknown option '") + key + "'"); return -1; }
+  if (!c->kn.set(key, value)) { fail(std::string("jdaSetOption: unknown option or value out of range: '") + key + "'"); return -1; }
   // scan plans (tile shapes, table chunking) depend on the knobs: rebuild them on next use (no lane is busy, so
   // nothing runs on the old ones)
   for (auto& kv : c->plans) c->plan_pool.push_back({kv.second.dp, kv.second.table, kv.second.table_cap});

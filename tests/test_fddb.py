@@ -176,3 +176,15 @@ def test_config3_fddb_sized_job_in_eight_shards(built, tmp_path):
             continue
         for k in ("bboxes", "scores", "shapes"):
             assert same(got[i][k], want[k]), (i, k)
+    # The entry the bench times for this config -- every shard as ONE ragged job (jdaDetectBatchRagged), the images
+    # of a shard back to back in one packed buffer, packed rows out -- must give the same rows as the per-image calls
+    # above, shard by shard, on all 2,845 images (and therefore what the oracle gives on the sampled ones).
+    for r in range(world):
+        lo, hi = jd.shard_range(n_images, r, world)
+        offs, tot = [], 0
+        for i in range(lo, hi):
+            offs.append(tot); tot += images[i].size
+        buf = np.concatenate([images[i].reshape(-1) for i in range(lo, hi)])
+        rag = c.detect_ragged_packed(buf, offs, [sizes[i][0] for i in range(lo, hi)], [sizes[i][1] for i in range(lo, hi)],
+                                     keep_results="packed", frame_offset=lo)
+        assert same(np.asarray(rag), blocks[r]), r
