@@ -89,6 +89,11 @@ def build_timing():
     return _build(os.path.join(HERE, "libjda_timing.so"), OBJDIR + "_timing", ["-DJDA_SCAN_TIMING"])
 
 
+def build_variant(name, defines):
+    """Experiment build with extra -D flags (A/B on one box through JDA_LIB_PATH); never the product."""
+    return _build(os.path.join(HERE, "libjda_%s.so" % name), OBJDIR + "_" + name, ["-D" + d for d in defines])
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -96,6 +101,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:      # python -m jda_amd.build --variant wpe5 JDA_SCAN_P_WAVES_PER_EU=5
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:])); sys.exit(0)
     if "--timing" in sys.argv:
         print(build_timing()); sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -84,6 +84,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(merge_blocks, "JDA_MERGE_BLOCKS", 2048) /* workgroups below which the LDS-tiled levels share one launch */ \
   X(side_small, "JDA_SIDE_SMALL", 1)                                                                   \
   X(side_stream, "JDA_SIDE_STREAM", 1)                                                                 \
+  X(side_after, "JDA_SIDE_AFTER", 0)        /* ... forked after this many LDS-tiled launches have been queued (the persistent scan takes its CUs first, the global-pixel workgroups fill what it leaves) */ \
   X(lanes_reverse, "JDA_LANES_REVERSE", 1)                                                             \
   X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
   X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
@@ -125,8 +126,13 @@ static long long env_ll(const char* name, long long dflt) {
   X(scan_p_b4, "JDA_SCAN_P_B4", 0)                                                                     \
   X(scan_p_handoff, "JDA_SCAN_P_HANDOFF", 0) /* ... carts of stage 0 it evaluates (0: `handoff`).  Its cart tables are loaded once per workgroup and its deep windows pooled over all tiles, so a later hand-off costs it little */ \
   X(scan_p_ring, "JDA_SCAN_P_RING", 256)    /* ... items per ring (rounded up to a power of two) */     \
-  X(scan_p_lg, "JDA_SCAN_P_LG", 64)         /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 pair tasks of 32 / 16 windows */ \
-  X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */
+  X(scan_p_lg, "JDA_SCAN_P_LG", 64)         /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 / 7 / 8 pair tasks of 32 / 16 / 8 / 4 windows, 9 a pair task of 1 to 4 windows taken as soon as one waits */ \
+  X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */ \
+  X(scan_p_tile_kb, "JDA_SCAN_P_TILE_KB", 0) /* ... its own cut of a level's tile in y: as many rows of windows as keep the pixel tile within this many KB (0: the plan's tile) */ \
+  X(scan_p_lds_kb, "JDA_SCAN_P_LDS_KB", 160) /* ... LDS a workgroup may take: what it leaves of the CU's 160 KB is where the other batch's kernels (global-pixel scan: 23.1 KB per workgroup, k_finish: 7.5 KB) find room next to it */ \
+  X(scan_p_win_max, "JDA_SCAN_P_WIN_MAX", 100000) /* ... largest window of a level it takes */ \
+  X(scan_p_grid, "JDA_SCAN_P_GRID", 0)      /* ... workgroups of a launch (0: one per CU x scan_p_wgs) */ \
+  X(scan_p_mid, "JDA_SCAN_P_MID", 1)        /* ... with scan_p_handoff >= K: windows that pass stage 0 go straight to the mid queue */
 
 struct Knobs {
 #define X(name, env, dflt) long long name = (dflt);
@@ -142,7 +148,7 @@ struct Knobs {
   bool set(const char* key, long long v) {
     static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "host_chunk", "ragged_chunk_windows",
                                                "h2d_min_bytes", "merge_blocks", "finish_merge", "wide_max", "lanes_min_windows",
-                                               "ragged_stage_threads", "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls"};
+                                               "ragged_stage_threads", "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls", "scan_p_tile_kb", "scan_p_grid"};
     for (const char* k : non_negative) if (std::strcmp(key, k) == 0 && v < 0) return false;
     if (std::strcmp(key, "workspace_mb") == 0 && v < 1) return false;
 #define X(name, env, dflt) if (std::strcmp(key, #name) == 0) { name = v; return true; }
@@ -235,6 +241,7 @@ struct PlanEntry {
   // of the detection list is copied back speculatively: the whole pass is ONE enqueue and one host wait.  The kernels
   // read the true lengths from the device counters (grid-stride), so a wrong prediction costs time, never results.
   double pred_tail = -1, pred_out = -1;
+  double pred_mid = -1;         // ... and the mid queue's (windows that passed stage 0)
   int pins = 0;                 // submitted batches that still use this plan (never evicted while > 0)
   unsigned long long last_use = 0;
 };
@@ -973,14 +980,14 @@ struct Pass {
   hipStream_t st = nullptr; hipEvent_t* ev = nullptr; unsigned long long* h_cnt = nullptr;
   // the plan's hints as they stood when the pass was set up (the plan is shared with concurrent callers: read and
   // written under c->mu only, see bind())
-  bool hint_dense = false; double pred_tail = -1, pred_out = -1;
+  bool hint_dense = false; double pred_tail = -1, pred_out = -1, pred_mid = -1;
   int busy_lanes = 1;               // lanes of the cascador in use when the pass was set up (concurrent callers)
   void bind(Lane* l, int index, hipStream_t stream) {
     ln = l; lane = index; st = stream ? stream : l->stream; ev = l->ev; h_cnt = l->h_cnt;
     timed = !rs || rs->timed || c->kn.debug_times;
     w = Sel<Real>::work(l); cap = l->cap;
     std::lock_guard<std::mutex> lk(c->mu);
-    hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out;
+    hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out; pred_mid = pe->pred_mid;
     busy_lanes = 0;
     for (auto& up : c->lanes) busy_lanes += up->busy ? 1 : 0;
   }
@@ -993,6 +1000,7 @@ struct Pass {
   bool timed = true;               // RunStats::timed
   bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
   bool counters_issued = false, results_pending = false;
+  bool mid_direct = false;         // a scan launch of this pass put stage-0 survivors into the mid queue itself (k_scan_p up to cart K)
   long long n_tail = -1;
   size_t n_out = 0, out_copied = 0;   // detections of the pass / how many of them are already on their way to the host
 
@@ -1014,6 +1022,8 @@ struct Pass {
   // k_finish reads the level-major copy of the stage-0 tables (second half of the allocation)
   const S0Node* s0_tbl() const { return (pe->fast_scan && pe->table && pe->lm_ok && c->kn.fin_s0) ? pe->table + pe->table_cap : nullptr; }
   const Knobs& kn() const { return c->kn; }
+  // k_filter0 + k_finish(survivors) can take this pass's hand-off queue (every level has a resolved stage-0 table)
+  bool filter0_ok() const { return kn().filter0 && s0_tbl() != nullptr && pe->fast_scan && !pe->any_untiled && !multi; }
   long long windows() const { return rag ? rag->windows : (long long)nf * pe->sp.windows; }
 
   bool dense_ok(int* pix_cap, int* lds_max) const {
@@ -1043,7 +1053,10 @@ struct Pass {
     return true;
   }
   bool read_counter(int counter) {     // asynchronous: the value is in h_cnt[0] after the next stream sync
-    JDA_HIP(hipMemcpyAsync(h_cnt, w.counters + counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    // (the hand-off count comes with the counters up to the mid queue's: h_cnt[kCntMid - kCntTail] = windows k_scan_p
+    // put there itself)
+    const size_t n = counter == kCntTail ? (size_t)(kCntMid - kCntTail + 1) : 1;
+    JDA_HIP(hipMemcpyAsync(h_cnt, w.counters + counter, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return true;
   }
 
@@ -1079,8 +1092,12 @@ struct Pass {
       if (!kn().scan_p || want_trace()) return false;
       const DevModelT<Real>& m = model();
       const DevLevel& lv = pe->hp.lv[level];
+      if (lv.win > kn().scan_p_win_max) return false;
       const int K = std::min(m.K, (int)(kn().scan_p_handoff > 0 ? kn().scan_p_handoff : kn().handoff));
       PScanCfg cfg{};
+      // all of stage 0 in this kernel: its survivors are what k_filter0 would leave in the mid queue (launch_finishers
+      // then takes the k_filter0 + k_finish(survivors) form whatever the size of the hand-off queue)
+      cfg.to_mid = (K == m.K && kn().scan_p_mid && filter0_ok()) ? 1 : 0;
       const long long bs[5] = {kn().scan_p_b0, kn().scan_p_b1, kn().scan_p_b2, kn().scan_p_b3, kn().scan_p_b4};
       int digits[kPScanMaxBuckets] = {6, 6, 6, 6, 6, 6}, nd = 0;
       { long long v = std::max<long long>(0, kn().scan_p_lg); int tmp[16]; int n = 0; while (v > 0 && n < 16) { tmp[n++] = (int)(v % 10); v /= 10; }
@@ -1091,7 +1108,7 @@ struct Pass {
         if (b <= last || b >= K) continue;
         cfg.bound[cfg.nb] = b;
         const int d = digits[cfg.nb];
-        cfg.lg[cfg.nb] = ((d == 4 || d == 5) && m.leaf_n <= 256) || d == 2 || d == 3 ? d : 6;
+        cfg.lg[cfg.nb] = ((d == 4 || d == 5 || d == 7 || d == 8 || d == 9) && m.leaf_n <= 256) || d == 2 || d == 3 ? d : 6;
         cfg.nb++;
         last = b;
       }
@@ -1106,20 +1123,41 @@ struct Pass {
         for (unsigned i = 0; i < (unsigned)(lv.tw * lv.th + 64) && ok; i++) ok = ((i * mg) >> 20) == i / (unsigned)lv.tw;
         cfg.tw_magic = ok ? (int)mg : 0; }
       cfg.opts = (int)kn().scan_p_opts;
-      cfg.slot_bytes = (lv.pitch * (lv.win + (lv.th - 1) * lv.step) + 15) & ~15;
+      // the kernel's own cut of the tile in y (same row pitch and tile width: the resolved node offsets hold): small
+      // tiles turn over faster and leave room for more slots.  Candidates are the heights whose windows fill their
+      // waves to 90 % (or the best filled one); the tallest that keeps the pixel tile within scan_p_tile_kb, else the
+      // smallest
+      cfg.th = lv.th;
+      if (kn().scan_p_tile_kb > 0) {
+        double top = 0;
+        auto fill_of = [&](int th) { const int n = lv.tw * th; return (double)n / (double)(((n + 63) / 64) * 64); };
+        for (int th = 1; th <= lv.th; th++) top = std::max(top, fill_of(th));
+        const double want = std::min(0.9, top);
+        int fit = 0, smallest = 0;
+        for (int th = 1; th <= lv.th; th++) {
+          if (fill_of(th) < want) continue;
+          if (!smallest) smallest = th;
+          if ((long long)lv.pitch * (lv.win + (th - 1) * lv.step) <= kn().scan_p_tile_kb * 1024) fit = th;
+        }
+        cfg.th = fit ? fit : smallest;
+      }
+      cfg.tiles_y = (lv.ny + cfg.th - 1) / cfg.th;
+      cfg.slot_bytes = (lv.pitch * (lv.win + (cfg.th - 1) * lv.step) + 15) & ~15;
       cfg.slots = 0;
       const long long fixed = (long long)scan_p_lds_bytes(cfg, K, m.node_n, m.leaf_n, block / 64);
-      const long long budget = (160 * 1024) / wgs;
+      const long long budget = std::max<long long>(16, std::min<long long>(160, kn().scan_p_lds_kb)) * 1024 / wgs;
       long long slots = (budget - fixed) / std::max(1, cfg.slot_bytes);
       if (kn().scan_p_slots > 0) slots = std::min<long long>(slots, kn().scan_p_slots);
       slots = std::min<long long>(slots, 8);
       if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
       if (kn().scan_p == 1 && slots < kn().scan_p_min_slots) return false;     // few resident windows per wave: k_scan's closed tiles do better there
       cfg.slots = (int)slots;
-      if (kn().scan_p == 1 && (long long)lv.tiles_x * lv.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
-      const hipError_t e = launch_scan_persistent(level, cfg, block, c->n_cus * wgs, pe->dp, pe->hp, m, pe->table, w, s);
+      if (kn().scan_p == 1 && (long long)lv.tiles_x * cfg.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
+      const int grid = kn().scan_p_grid > 0 ? (int)std::min<long long>(kn().scan_p_grid, 1 << 16) : c->n_cus * wgs;
+      const hipError_t e = launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s);
       if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return false; }
       if (e != hipSuccess) { fail(std::string("launch_scan_persistent failed: ") + hipGetErrorString(e)); return false; }
+      if (cfg.to_mid) mid_direct = true;
       return true;
     }
   }
@@ -1210,7 +1248,9 @@ struct Pass {
         // odd lanes go through the levels in the opposite order (big windows first): the launches of
         // one lane then run next to different ones of the other instead of next to their twins
         const bool rev = (lane & 1) && kn().lanes_reverse;
-        if (any_glb && solo && kn().side_stream && ln->ensure_side() && !fork_glb()) return false;
+        const bool side = any_glb && solo && kn().side_stream && ln->ensure_side();
+        int fork_in = side ? (int)std::max<long long>(0, kn().side_after) : -1;
+        if (fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
         if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
@@ -1219,7 +1259,9 @@ struct Pass {
           // big-window levels of a batch are short launches: merge all of them into one (at the first one met)
           if (mode == 3) { if (any_wide) { if (!scan(3, -1, st)) return false; any_wide = false; } continue; }
           if (!scan(1, l, st)) return false;
+          if (fork_in > 0 && --fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
         }
+        if (fork_in > 0 && !fork_glb()) return false;
       }
       lds_span = !side_pending && !(((lane & 1) && kn().lanes_reverse) && !small);   // LDS launches first, back to back
       if (lds_span && timed) JDA_HIP(hipEventRecord(ev[4], st));
@@ -1236,7 +1278,7 @@ struct Pass {
   // host reads the queue length first (after_tail).
   bool issue_rest() {
     int pix_cap, lds_max;
-    if (kn().predict && pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pred_tail >= 0.4)) {
+    if (kn().predict && pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pred_tail + std::max(0.0, pred_mid) >= 0.4)) {
       const long long nw = windows();
       const long long guess = std::min<long long>((long long)cap, (long long)(pred_tail * (double)nw * 1.1) + 64);
       if (!launch_finishers(guess)) return false;
@@ -1293,6 +1335,16 @@ struct Pass {
     const int gm = kn().fin_gm > 0 ? (int)kn().fin_gm : stage_groups();
     const int g2 = kn().fin_g2 > 0 ? (int)kn().fin_g2 : stage_groups();
     n_grid = std::max<long long>(n_grid, 1);
+    if (mid_direct) {
+      // the mid queue already holds stage-0 survivors (k_scan_p): the rest of the hand-off queue is filtered into it,
+      // then everybody goes through k_finish(survivors)
+      const long long nmid = pred_mid >= 0 ? (long long)(pred_mid * (double)windows() * 1.25) + 64 : 0;
+      const long long wg2 = std::min<long long>((long long)cap, std::max<long long>(std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)), nmid));
+      JDA_HIP(launch_filter0<Real>(want_trace(), pe->dp, model(), w, n_grid, s0_tbl(), st));
+      JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, g2, wg2, s0_tbl(), (int)kn().fin_tile, st, true));
+      finished = true;
+      return true;
+    }
     // (k_finish_wide is the LATENCY form: a whole CU per window.  With several callers on the cascador at once the
     // machine is shared and throughput counts: they get the one-wave-per-window kernel)
     if (n_grid <= kn().wide_max && busy_lanes <= kn().wide_busy_max && finish_wide_ok(hm().dim(), hm().K, hm().leaf_n(), (int)sizeof(Real), multi, Sel<Real>::dialect == JDA_DIALECT_CPP && c->similarity)) {
@@ -1310,7 +1362,7 @@ struct Pass {
       return true;
     }
     const long long wg2 = std::min<long long>(n_grid, std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)));
-    if (kn().filter0 && s0_tbl() != nullptr && pe->fast_scan && !pe->any_untiled && !multi) {
+    if (filter0_ok()) {
       // the dying majority is filtered by a lean kernel (four windows per workgroup, stage 0 only); the survivors --
       // a few per cent -- go through k_finish for the regression of stage 0 and every later stage
       JDA_HIP(launch_filter0<Real>(want_trace(), pe->dp, model(), w, n_grid, s0_tbl(), st));
@@ -1335,9 +1387,10 @@ struct Pass {
     if (finished) return true;
     JDA_HIP(hipStreamSynchronize(st));
     n_tail = (long long)std::min<unsigned long long>(h_cnt[0], cap);
+    const long long n_alive = n_tail + (mid_direct ? (long long)std::min<unsigned long long>(h_cnt[kCntMid - kCntTail], cap) : 0);
     int pix_cap, lds_max;
     const double dense_frac = (double)kn().dense_pct / 100.0;
-    if (dense_ok(&pix_cap, &lds_max) && (double)n_tail >= dense_frac * (double)windows() && n_tail > 4096) {
+    if (dense_ok(&pix_cap, &lds_max) && (double)n_alive >= dense_frac * (double)windows() && n_alive > 4096) {
       // most windows are still alive after the scan: start over in dense mode (the scan's work
       // is a small part of T*K carts per window) and remember the choice for the next pass
       { std::lock_guard<std::mutex> lk(c->mu); pe->dense_hint = true; }
@@ -1426,8 +1479,10 @@ struct Pass {
         c->pred_tail = pe->pred_tail;
         pe->pred_out = std::max((double)n_out / nw, pe->pred_out * 0.9);
         c->pred_out = pe->pred_out;
+        pe->pred_mid = std::max((double)h_cnt[kCntMid] / nw, pe->pred_mid * 0.9);
         int pix_cap, lds_max;
-        if (predicted && kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && ft >= dense_frac && h_cnt[kCntTail] > 4096)
+        const double f_alive = ft + (mid_direct ? (double)h_cnt[kCntMid] / nw : 0.0);     // (alive after the scan, or more)
+        if (predicted && kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && f_alive >= dense_frac && f_alive * nw > 4096)
           pe->dense_hint = true;       // this pass went through k_finish window by window; the next one runs dense
       }
       c->last_dense = pe->dense_hint;

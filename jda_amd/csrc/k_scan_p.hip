@@ -261,7 +261,12 @@ size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, 
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(1024)
+// Registers: launch_bounds(1024) alone lets the compiler take 128 (117 used); a workgroup of 768 threads is three waves
+// per SIMD, and what it leaves of the 512 registers decides which of the other batch's kernels can run next to it.
+#ifndef JDA_SCAN_P_WAVES_PER_EU
+#define JDA_SCAN_P_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(JDA_SCAN_P_WAVES_PER_EU)))
 void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node* __restrict__ table, WorkT<float> w,
               int level, PScanCfg cfg, int total_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -277,7 +282,8 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   uint8_t* lfw = lds + L.lfbuf + wv * 512;
   const DevLevel lv = plan->lv[level];
   const int W = plan->width;
-  const int tiles_per_frame = lv.tiles_x * lv.tiles_y;
+  const int TH = cfg.th;                               // rows of windows per tile: this kernel's own cut (<= the plan's)
+  const int tiles_per_frame = lv.tiles_x * cfg.tiles_y;
   const int G = gridDim.x;
   const int n_my = (total_blocks - (int)blockIdx.x + G - 1) / G;
   const int S = cfg.slots;
@@ -316,7 +322,13 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   const int NB = CF(kCfNb);
   // lane 8 + b: items a full task of ring b takes
   // (task form digit: 6 lane = window, 64 items; 3 / 2 lane = window, a full task is 32 / 16 items; 5 / 4 pair task of 32 / 16)
-  auto need_of = [](int d) { return d == 6 ? 64 : (d == 5 || d == 3) ? 32 : 16; };
+  // (... 7 / 8: pair task of 8 / 4 windows -- 64 / 128 carts per round: the deep cart ranges that few windows reach)
+  // (... 9: pair task of up to 4 windows taken as soon as ONE waits: a window that deep must not keep its tile's slot
+  //  waiting for company)
+  auto take_of = [](int d) { return d == 6 ? 64 : (d == 5 || d == 3) ? 32 : d == 7 ? 8 : (d == 8 || d == 9) ? 4 : 16; };
+  auto need_of = [&](int d) { return d == 9 ? 1 : take_of(d); };
+  auto is_pair = [](int d) { return d == 4 || d == 5 || d == 7 || d == 8 || d == 9; };
+  auto pair_lg = [](int d) { return d == 7 ? 3 : (d == 8 || d == 9) ? 2 : d; };
   const int need_v = need_of(__shfl(cfgv, kCfLg + ((lane - kRecRing) & 7)));
   typedef volatile __attribute__((address_space(3))) v4i* lds_rec_t;
   lds_rec_t rec_l = (lds_rec_t)(ctl->rec);
@@ -368,7 +380,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
     const int n = __popcll(mask);
     if (n == 0) return;
     unsigned gbase = 0;
-    if (lane == 0) gbase = (unsigned)atomicAdd(&w.counters[kCntTail], (unsigned long long)n);
+    if (lane == 0) gbase = (unsigned)atomicAdd(&w.counters[cfg.to_mid ? kCntMid : kCntTail], (unsigned long long)n);
     gbase = (unsigned)uni((int)gbase);
     if (alive) {
       const int rank = __popcll(mask & lanes_below(lane));
@@ -379,11 +391,14 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
       const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
       const unsigned slot = gbase + (unsigned)rank;
       if (slot < w.cap) {
-        w.q_gid[slot] = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
-        w.q_score[slot] = score;
-        w.q_kstart[slot] = (uint32_t)K;
-        w.q_xy[slot] = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
-        w.q_wf[slot] = (uint32_t)lv.win | ((uint32_t)frame << 16);
+        const uint32_t gid = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
+        const uint32_t xy = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
+        const uint32_t wf = (uint32_t)lv.win | ((uint32_t)frame << 16);
+        if (cfg.to_mid) {                  // stage 0 passed: k_finish(survivors) takes it from the mid queue, as k_filter0 leaves it
+          w.m_gid[slot] = gid; w.m_score[slot] = score; w.m_xy[slot] = xy; w.m_wf[slot] = wf;
+        } else {
+          w.q_gid[slot] = gid; w.q_score[slot] = score; w.q_kstart[slot] = (uint32_t)K; w.q_xy[slot] = xy; w.q_wf[slot] = wf;
+        }
       }
       handed += K;
     }
@@ -437,11 +452,11 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           const int rl_ = 31 - __builtin_clz(m_ring);
           const int b = rl_ - kRecRing;
           const int dg = CF(kCfLg + b);
-          const int full_n = need_of(dg);
-          const int need = m_full != 0u ? full_n : 1;
+          const int full_n = take_of(dg);
+          const int need = m_full != 0u ? need_of(dg) : 1;
           const int cmt = __builtin_amdgcn_readlane(r.x, rl_);
           int expv = __builtin_amdgcn_readlane(r.y, rl_);
-          const int item = (dg == 4 || dg == 5) ? (lane & (full_n - 1)) : lane;
+          const int item = is_pair(dg) ? (lane & (full_n - 1)) : lane;
           for (;;) {
             const int n = min(cmt - expv, full_n);
             t_it = make_uint2(0u, 0u);
@@ -500,8 +515,8 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
             st_relaxed(recw + 4 * s, 0);
           } else {
             const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
-            const int wx0 = tx * lv.tw, wy0 = ty * lv.th;
-            const int twe = min(lv.tw, lv.nx - wx0), the = min(lv.th, lv.ny - wy0);
+            const int wx0 = tx * lv.tw, wy0 = ty * TH;
+            const int twe = min(lv.tw, lv.nx - wx0), the = min(TH, lv.ny - wy0);
             const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
             const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
             const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
@@ -541,15 +556,16 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           // ---- t_n items of shared ring t_b (already in t_it) ----
           const int b = t_b;
           const int dg = CF(kCfLg + b);
-          if (dg == 4 || dg == 5) {
+          if (is_pair(dg)) {
             // pair form: walked here, survivors straight on
-            const int np = 1 << dg;
+            const int plg = pair_lg(dg);
+            const int np = 1 << plg;
             const int item = lane & (np - 1);
             const bool has_item = item < t_n;
             const bool valid = has_item && lane < np;
             bool alive = valid;
             float score = __uint_as_float(t_it.y);
-            p_pair<DEPTH>(c, lfw, dg, CF(kCfBound + b), CF(kCfBound + b + 1), lane, has_item, (int)(t_it.x & ((1u << kPBaseBits) - 1u)),
+            p_pair<DEPTH>(c, lfw, plg, CF(kCfBound + b), CF(kCfBound + b + 1), lane, has_item, (int)(t_it.x & ((1u << kPBaseBits) - 1u)),
                           alive, score, my_carts);
             if (valid && !alive) (void)__hip_atomic_fetch_add(recw + 4 * (int)(t_it.x >> (kPBaseBits + kPWidxBits)) + 3, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             JDA_PCAT(2);
@@ -626,12 +642,14 @@ hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int
   if (w.n_frames == 0) return hipSuccess;
   const DevLevel& lv = h_plan.lv[level];
   if (lv.tiled != 1 || cfg.nb < 0 || cfg.nb > kPScanMaxBuckets || cfg.slots < 1 || cfg.slots > kPSlotsMax) return hipErrorInvalidValue;
-  if (lv.tw * lv.th > (1 << kPWidxBits) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
+  if (cfg.th < 1 || cfg.th > lv.th || cfg.tiles_y != (lv.ny + cfg.th - 1) / cfg.th) return hipErrorInvalidValue;
+  if (cfg.to_mid && cfg.bound_last != m.K) return hipErrorInvalidValue;
+  if (lv.tw * cfg.th > (1 << kPWidxBits) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
   const int K = cfg.bound_last;
   const PLds L(K, m.node_n, m.leaf_n, cfg.ring_items, block / 64, cfg.slots, cfg.slot_bytes);
   if (L.total > 160 * 1024 || L.total > (1 << kPBaseBits)) return hipErrorInvalidValue;
   const int groups = (w.n_frames + 7) / 8;
-  const int total_blocks = groups * 8 * lv.tiles_x * lv.tiles_y;
+  const int total_blocks = groups * 8 * lv.tiles_x * cfg.tiles_y;
   int grid = std::min(total_blocks, grid_max);
   if (grid >= 8) grid &= ~7;             // block b runs on XCD b % 8: a workgroup's tiles b + j * grid stay on its XCD's frames
   auto go = [&](auto kern) {

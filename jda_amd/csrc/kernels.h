@@ -230,6 +230,9 @@ struct PScanCfg {
   int any_norm;                        // a cart of [0, bound_last) normalises its score (mean, std != 0, 1)
   int tw_magic;                        // ceil(2^20 / tile width in windows) where i / tw == (i * magic) >> 20 for every window index of a tile, else 0
   int ring_cap[kPScanMaxBuckets], ring_off[kPScanMaxBuckets], ring_items;     // items per ring / first item / all rings (scan_p_ring_caps)
+  int th, tiles_y;                     // the kernel's own cut of the level in y: rows of windows per tile, tiles per column (the
+                                       // row pitch and the tile width are the plan's: the resolved node offsets depend on them)
+  int to_mid;                          // bound_last == K: a window that passes every cart of stage 0 goes straight to the mid queue
 };
 void scan_p_ring_caps(PScanCfg* cfg, int waves);
 size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves);

@@ -6,7 +6,7 @@ cd $R
 for rep in 1 2; do
 for v in "$@"; do
   echo "=== $v"
-  env $v timeout 300 python bench.py --no-cpu --no-allpass --no-x --steps 60 2>/dev/null | python -c "
+  env $v timeout 300 python bench.py --no-cpu --no-allpass --no-x --steps 60 $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -30,8 +30,9 @@ for spec in (sys.argv[1:] or [""]):
             _, st = c.detect_batch_device(d, keep_results=False, stats=True); sts.append(st)
         torch.cuda.synchronize(); el = (time.perf_counter() - t0) / steps * 1e3
         g = np.mean([s["gpu_ms"] for s in sts]); sc = np.mean([s["scan_ms"] for s in sts])
-        print("%-60s step %.3f ms  gpu %.3f  scan %.3f  handoff %d  scan_carts %d  launches %d  dets %d" %
-              (spec or "(defaults)", el, g, sc, sts[-1]["handoff_n"], sts[-1]["scan_cart_n"], sts[-1]["scan_launches"], sts[-1]["face_patch_n"]), flush=True)
+        lds = np.mean([s["scan_lds_ms"] for s in sts])
+        print("%-60s step %.3f ms  gpu %.3f  scan %.3f  lds %.3f  handoff %d  scan_carts %d  launches %d  dets %d" %
+              (spec or "(defaults)", el, g, sc, lds, sts[-1]["handoff_n"], sts[-1]["scan_cart_n"], sts[-1]["scan_launches"], sts[-1]["face_patch_n"]), flush=True)
     except Exception as e:
         print("%-60s FAILED %r" % (spec, e), flush=True)
     c.close()
