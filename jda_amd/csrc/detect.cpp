@@ -113,12 +113,13 @@ static long long env_ll(const char* name, long long dflt) {
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
+  X(w_pad, "JDA_W_PAD", 1)                  /* k_finish gathers its weight rows from a copy whose rows start on 128-byte lines (0: from the tight table) */ \
   X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
   X(scan_p_min_slots, "JDA_SCAN_P_MIN_SLOTS", 4) /* ... pixel-tile slots a level's workgroup must have room for (scan_p = 1) */ \
   X(scan_p_wgs, "JDA_SCAN_P_WGS", 1)        /* ... workgroups per CU */                                 \
-  X(scan_p_slots, "JDA_SCAN_P_SLOTS", 0)    /* ... pixel-tile slots per workgroup (0: as many as fit, at most 8) */ \
+  X(scan_p_slots, "JDA_SCAN_P_SLOTS", 5)    /* ... pixel-tile slots per workgroup at most while other batches are in flight on the cascador (0: as many as fit, at most 8).  Five, not the six the 46-pixel level has room for: the 28 KB left per CU let workgroups of the other batch run next to it (submit/wait step 1.495 -> 1.45 ms) */ \
   X(scan_p_b0, "JDA_SCAN_P_B0", 32)         /* ... cart counts at which windows are re-bucketed */       \
   X(scan_p_b1, "JDA_SCAN_P_B1", 64)                                                                    \
   X(scan_p_b2, "JDA_SCAN_P_B2", 0)                                                                     \
@@ -131,6 +132,7 @@ static long long env_ll(const char* name, long long dflt) {
   X(scan_p_tile_kb, "JDA_SCAN_P_TILE_KB", 0) /* ... its own cut of a level's tile in y: as many rows of windows as keep the pixel tile within this many KB (0: the plan's tile) */ \
   X(scan_p_lds_kb, "JDA_SCAN_P_LDS_KB", 160) /* ... LDS a workgroup may take: what it leaves of the CU's 160 KB is where the other batch's kernels (global-pixel scan: 23.1 KB per workgroup, k_finish: 7.5 KB) find room next to it */ \
   X(scan_p_win_max, "JDA_SCAN_P_WIN_MAX", 100000) /* ... largest window of a level it takes */ \
+  X(scan_p_dyn, "JDA_SCAN_P_DYN", 1)        /* ... tiles dealt to the workgroups at run time (a workgroup that starts late takes fewer) instead of in fixed shares */ \
   X(scan_p_grid, "JDA_SCAN_P_GRID", 0)      /* ... workgroups of a launch (0: one per CU x scan_p_wgs) */ \
   X(scan_p_mid, "JDA_SCAN_P_MID", 1)        /* ... with scan_p_handoff >= K: windows that pass stage 0 go straight to the mid queue */
 
@@ -589,6 +591,13 @@ static bool upload_model(Cascador* c) {
   sz.take<NodeOff<Real>>(nodes.size()); sz.take<uint2>(nodes.size());
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
   sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
+  // k_finish's copy of the weight rows: every row on its own 128-byte lines (the file layout, c/jda.c:146, is what
+  // k_stage and k_finish_wide stage whole carts of; a wave-per-window gather of single rows pays per line touched)
+  const size_t w_rows_n = w.size() / (size_t)dim;
+  const int line_elems = 128 / (int)sizeof(Real);
+  const int w_pitch = c->kn.w_pad ? ((dim + line_elems - 1) / line_elems) * line_elems : dim;
+  const bool padded = w_pitch != dim && w_rows_n * (size_t)w_pitch < (1ull << 32);      // (k_finish keeps row offsets in 32 bits)
+  if (padded) sz.take<Real>(w_rows_n * (size_t)w_pitch);
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
   NodeOff<Real>* d_lm_off = cv.take<NodeOff<Real>>(nodes.size());
@@ -605,6 +614,7 @@ static bool upload_model(Cascador* c) {
   Real* d_ms = cv.take<Real>(dim);
   Real* d_ms_raw = cv.take<Real>(dim);
   Real* d_par0 = cv.take<Real>(par0.size());
+  Real* d_w_rows = padded ? cv.take<Real>(w_rows_n * (size_t)w_pitch) : d_w;
   JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
@@ -612,12 +622,17 @@ static bool upload_model(Cascador* c) {
   JDA_HIP(hipMemcpy(d_cstd, cstd.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_cnorm, cnorm.data(), carts, hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_w, w.data(), w.size() * sizeof(Real), hipMemcpyHostToDevice));
+  if (padded) {
+    JDA_HIP(hipMemset(d_w_rows, 0, w_rows_n * (size_t)w_pitch * sizeof(Real)));
+    JDA_HIP(hipMemcpy2D(d_w_rows, (size_t)w_pitch * sizeof(Real), d_w, (size_t)dim * sizeof(Real), (size_t)dim * sizeof(Real), w_rows_n, hipMemcpyDeviceToDevice));
+  }
   JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
   JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.lm_off = d_lm_off; m.lm_meta = d_lm_meta; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
+  m.w_rows = d_w_rows; m.w_pitch = padded ? w_pitch : dim;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   m.par0 = d_par0;
@@ -1000,6 +1015,7 @@ struct Pass {
   bool timed = true;               // RunStats::timed
   bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
   bool counters_issued = false, results_pending = false;
+  int p_launches = 0;              // k_scan_p launches of this pass so far (each deals its tiles from its own counter words)
   bool mid_direct = false;         // a scan launch of this pass put stage-0 survivors into the mid queue itself (k_scan_p up to cart K)
   long long n_tail = -1;
   size_t n_out = 0, out_copied = 0;   // detections of the pass / how many of them are already on their way to the host
@@ -1147,17 +1163,21 @@ struct Pass {
       const long long fixed = (long long)scan_p_lds_bytes(cfg, K, m.node_n, m.leaf_n, block / 64);
       const long long budget = std::max<long long>(16, std::min<long long>(160, kn().scan_p_lds_kb)) * 1024 / wgs;
       long long slots = (budget - fixed) / std::max(1, cfg.slot_bytes);
-      if (kn().scan_p_slots > 0) slots = std::min<long long>(slots, kn().scan_p_slots);
+      // (the cap only where another batch's kernels are in flight next to this pass -- a second lane of this call,
+      // other tickets or callers; alone, the workgroup takes every slot that fits)
+      if (kn().scan_p_slots > 0 && (!solo || busy_lanes > 1)) slots = std::min<long long>(slots, kn().scan_p_slots);
       slots = std::min<long long>(slots, 8);
       if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
       if (kn().scan_p == 1 && slots < kn().scan_p_min_slots) return false;     // few resident windows per wave: k_scan's closed tiles do better there
       cfg.slots = (int)slots;
       if (kn().scan_p == 1 && (long long)lv.tiles_x * cfg.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
+      cfg.dyn_slot = (kn().scan_p_dyn && p_launches < kCntMidScan - kCntTotal) ? p_launches : -1;
       const int grid = kn().scan_p_grid > 0 ? (int)std::min<long long>(kn().scan_p_grid, 1 << 16) : c->n_cus * wgs;
       const hipError_t e = launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s);
       if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return false; }
       if (e != hipSuccess) { fail(std::string("launch_scan_persistent failed: ") + hipGetErrorString(e)); return false; }
       if (cfg.to_mid) mid_direct = true;
+      p_launches++;
       return true;
     }
   }
@@ -1451,14 +1471,16 @@ struct Pass {
     const int T = hm().T;
     JDA_HIP(hipStreamSynchronize(st));
     results_pending = false;
-    for (int shd = 1; shd < kCntShards; shd++)     // fold the counter shards into shard 0
+    for (int shd = 1; shd < kCntShards; shd++) {   // fold the counter shards into shard 0
       for (int i = 0; i < kCntTotal; i++) h_cnt[i] += h_cnt[shd * kCntStride + i];
+      h_cnt[kCntMidScan] += h_cnt[shd * kCntStride + kCntMidScan];
+    }
     rs->carts += (long long)h_cnt[kCntCarts];
     rs->carts_scan += (long long)h_cnt[kCntCartsScan];
     rs->carts_scan_glb += (long long)h_cnt[kCntCartsScanGlb];
     rs->win_scan += (long long)h_cnt[kCntWinScan];
     for (int t = 0; t < T; t++) rs->stage_done[t] += (long long)h_cnt[kCntStage0 + t];
-    rs->tail += (long long)h_cnt[kCntTail];
+    rs->tail += (long long)h_cnt[kCntTail] + (long long)h_cnt[kCntMidScan];     // (alive at the scan's hand-off, whichever queue took them)
     const double nw = (double)windows();
     const double dense_frac = (double)kn().dense_pct / 100.0;
     n_tail = (long long)h_cnt[kCntTail];

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   constexpr bool kCpp = sizeof(Real) == 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x;
-  const int T = m.T, K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim;
+  const int T = m.T, K = m.K, node_n = m.node_n, leaf_n = m.leaf_n, dim = m.dim, w_pitch = m.w_pitch;
   const int dim_pad = (dim + 1) & ~1;
   Real* sh = (Real*)lds;                                     // current shape        [dim_pad] (the regression updates it
                                                              // in place: coordinate d is read and written by one lane only)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
           const int k = k0 + g * 64 + lane;
           ls[g] = 0; thk[g] = 0; mk[g] = 0; sk[g] = 1; nrm[g] = 0;
           if (k < K) {
-            lbf[k] = (uint32_t)(k * leaf_n + lf[g]) * (uint32_t)dim;
+            lbf[k] = (uint32_t)(k * leaf_n + lf[g]) * (uint32_t)w_pitch;
             ls[g] = leaf_tab[(unsigned)(k * leaf_n + lf[g])];
             thk[g] = cth[k];
             nrm[g] = cnorm[k];
@@ -165,15 +165,15 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         else if (t == 0 && s0_tbl) walk_carts_s0<2, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
         else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
         else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
-        if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)dim;
-        if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)dim;
+        if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)w_pitch;
+        if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)w_pitch;
       }
       __syncthreads();
       if (t == t_begin) JDA_FSTAMP();
       // ---- stage regression: K weight rows added strictly in cart order
       //      (c/jda.c:404-411); dialect CPP sums the delta from zero and adds it
       //      once (btcart.cpp:407-424) ----
-      const Real* wt = m.w + (size_t)t * K * leaf_n * dim;
+      const Real* wt = m.w_rows + (size_t)t * K * leaf_n * w_pitch;
       for (int d = lane; d < dim; d += 64) {
         Real acc = kCpp ? (Real)0 : sh[d];
         const Real* col = wt + d;

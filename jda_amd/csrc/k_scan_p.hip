@@ -285,7 +285,17 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   const int TH = cfg.th;                               // rows of windows per tile: this kernel's own cut (<= the plan's)
   const int tiles_per_frame = lv.tiles_x * cfg.tiles_y;
   const int G = gridDim.x;
-  const int n_my = (total_blocks - (int)blockIdx.x + G - 1) / G;
+  // Tiles are dealt in sequence v = class + classes * q (class = workgroup index mod 8 = its XCD: the frames of a group
+  // of 8 stay on one XCD's L2).  Static dealing gives workgroup b the q = b / 8 + j * G / 8 (its share is fixed: right when
+  // the launch has the machine to itself).  Dynamic dealing (cfg.dyn_slot >= 0) takes q from a device counter per class:
+  // a workgroup that gets its CU late -- another batch's kernels were on it -- takes fewer tiles instead of keeping the
+  // whole launch waiting for its fixed share.  The control block's "next tile" word is then 0 until a claim finds the
+  // sequence exhausted (n_my = 1).
+  const bool dyn = cfg.dyn_slot >= 0;
+  const int classes = G >= 8 ? 8 : 1;
+  const int tile_class = (int)blockIdx.x % classes;
+  unsigned long long* const dyn_cnt = w.counters + (size_t)tile_class * kCntStride + kCntTotal + (dyn ? cfg.dyn_slot : 0);
+  const int n_my = dyn ? 1 : (total_blocks - (int)blockIdx.x + G - 1) / G;
   const int S = cfg.slots;
 
 #ifdef JDA_SCAN_TIMING
@@ -343,7 +353,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
   const bool ilp8_fresh = (cfg.opts & 1) != 0, ilp8_bucket = (cfg.opts & 2) != 0;
   const bool any_norm = cfg.any_norm != 0;
 
-  unsigned my_carts = 0, handed = 0, win_cov = 0;
+  unsigned my_carts = 0, handed = 0, win_cov = 0, mids = 0;
   int idle_spins = 0;
 
   const int C = CF(kCfCap);                            // items per ring (a power of two)
@@ -401,6 +411,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
         }
       }
       handed += K;
+      if (cfg.to_mid) mids += 1;
     }
     lds_drain();                                         // (the slot records have been read before the references go)
   };
@@ -499,10 +510,19 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           int j = 0, frame = 0, trel = 0;
           bool have = false;
           for (;;) {
-            if (lane == 0) j = atomicAdd(recw + 4 * kRecMisc, 1);
-            j = uni(j);
-            if (j >= n_my) break;
-            const int v = (int)blockIdx.x + j * G;
+            int v;
+            if (dyn) {
+              unsigned long long q = 0;
+              if (lane == 0) q = atomicAdd(dyn_cnt, 1ull);
+              const long long vv = (long long)tile_class + (long long)classes * (long long)(unsigned)uni((int)(unsigned)q);
+              if (vv >= (long long)total_blocks) { st_relaxed(recw + 4 * kRecMisc, 1); break; }
+              v = (int)vv;
+            } else {
+              if (lane == 0) j = atomicAdd(recw + 4 * kRecMisc, 1);
+              j = uni(j);
+              if (j >= n_my) break;
+              v = (int)blockIdx.x + j * G;
+            }
             const int group = v / (8 * tiles_per_frame);
             const int rr = v - group * (8 * tiles_per_frame);
             frame = group * 8 + (rr & 7);
@@ -606,12 +626,12 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
 
   // ---- counters: rejected windows are final (DetectionStatisic.cart_gothrough_n); handed-off windows are counted
   //      by k_finish when they terminate.  One atomic set per workgroup, on this workgroup's counter shard. ----
-  unsigned v = my_carts, hv = handed, cv = win_cov;
+  unsigned v = my_carts, hv = handed, cv = win_cov, mv = mids;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); hv += __shfl_xor(hv, o); cv += __shfl_xor(cv, o); }
+  for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); hv += __shfl_xor(hv, o); cv += __shfl_xor(cv, o); mv += __shfl_xor(mv, o); }
   __syncthreads();
   int* red = (int*)(lds + L.lfbuf);      // (the pair scratch is idle now: 512 B per wave)
-  if (lane == 0) { red[wv] = (int)v; red[16 + wv] = (int)hv; red[32 + wv] = (int)cv; }
+  if (lane == 0) { red[wv] = (int)v; red[16 + wv] = (int)hv; red[32 + wv] = (int)cv; red[48 + wv] = (int)mv; }
 #ifdef JDA_SCAN_TIMING
   if (lane == 0) {
     for (int i = 0; i < 10; i++) { atomicAdd(&ctl->dbg[i], t_cat[i]); atomicAdd(&ctl->dbg[10 + i], (unsigned long long)n_cat[i]); }
@@ -619,8 +639,9 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
 #endif
   __syncthreads();
   if (tid == 0) {
-    unsigned long long sv = 0, sh = 0, sc = 0;
-    for (int i = 0; i < NW; i++) { sv += (unsigned)red[i]; sh += (unsigned)red[16 + i]; sc += (unsigned)red[32 + i]; }
+    unsigned long long sv = 0, sh = 0, sc = 0, sm = 0;
+    for (int i = 0; i < NW; i++) { sv += (unsigned)red[i]; sh += (unsigned)red[16 + i]; sc += (unsigned)red[32 + i]; sm += (unsigned)red[48 + i]; }
+    if (sm) atomicAdd(shard_counter(w.counters, kCntMidScan), sm);
     if (sv) atomicAdd(shard_counter(w.counters, kCntCarts), sv);
     atomicAdd(shard_counter(w.counters, kCntCartsScan), sv + sh);
     atomicAdd(shard_counter(w.counters, kCntWinScan), sc);
@@ -644,6 +665,7 @@ hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int
   if (lv.tiled != 1 || cfg.nb < 0 || cfg.nb > kPScanMaxBuckets || cfg.slots < 1 || cfg.slots > kPSlotsMax) return hipErrorInvalidValue;
   if (cfg.th < 1 || cfg.th > lv.th || cfg.tiles_y != (lv.ny + cfg.th - 1) / cfg.th) return hipErrorInvalidValue;
   if (cfg.to_mid && cfg.bound_last != m.K) return hipErrorInvalidValue;
+  if (cfg.dyn_slot >= kCntMidScan - kCntTotal) return hipErrorInvalidValue;
   if (lv.tw * cfg.th > (1 << kPWidxBits) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
   const int K = cfg.bound_last;
   const PLds L(K, m.node_n, m.leaf_n, cfg.ring_items, block / 64, cfg.slots, cfg.slot_bytes);

@@ -124,6 +124,8 @@ struct DevModelT {
   const uint8_t* cnorm;    // [T*K] 1 where (mean,std) != (0,1)
   const void* par0;        // {th, norm, mean, std} per cart [T*K], packed for LDS staging (k_scan, k_stage)
   const Real* w;           // [T][K*leaf_n][dim]
+  const Real* w_rows;      // the same rows w_pitch elements apart, each starting on a 128-byte line (k_finish gathers one row
+  int w_pitch;             // per cart: a tight 216-byte row straddles a third line in most positions); = w, dim when not padded
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
   int similarity;          // dialect CPP: Config::with_similarity_transform
@@ -171,7 +173,9 @@ enum Counter : int {
   kCntWinScan = kMaxStages + 4,    // windows k_scan covered
   kCntMid = kMaxStages + 5,        // length of the mid queue (allocator, shard 0 only)
   kCntCartsScanGlb = kMaxStages + 6,  // carts evaluated inside k_scan's global-pixel launches
-  kCntTotal = kMaxStages + 7
+  kCntTotal = kMaxStages + 7,
+  // spare words of a shard: [kCntTotal, kCntMidScan) deal k_scan_p's tiles (PScanCfg::dyn_slot, shards 0..7)
+  kCntMidScan = kCntStride - 1     // windows k_scan_p put into the mid queue itself (they count as handed off)
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
@@ -232,6 +236,7 @@ struct PScanCfg {
   int ring_cap[kPScanMaxBuckets], ring_off[kPScanMaxBuckets], ring_items;     // items per ring / first item / all rings (scan_p_ring_caps)
   int th, tiles_y;                     // the kernel's own cut of the level in y: rows of windows per tile, tiles per column (the
                                        // row pitch and the tile width are the plan's: the resolved node offsets depend on them)
+  int dyn_slot;                        // >= 0: tiles are dealt at run time from the counters' spare word kCntTotal + dyn_slot of shards 0..7 (zeroed with the counters); -1: fixed shares
   int to_mid;                          // bound_last == K: a window that passes every cart of stage 0 goes straight to the mid queue
 };
 void scan_p_ring_caps(PScanCfg* cfg, int waves);
