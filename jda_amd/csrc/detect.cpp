@@ -114,6 +114,8 @@ static long long env_ll(const char* name, long long dflt) {
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
   X(w_pad, "JDA_W_PAD", 1)                  /* k_finish gathers its weight rows from a copy whose rows start on 128-byte lines (0: from the tight table) */ \
+  X(lm_deep, "JDA_LM_DEEP", 1)              /* trees of five or more node levels: k_finish reads the levels from the fourth on as whole records grouped per path (0: every level from the level-major split copy) */ \
+  X(w_stream_mb, "JDA_W_STREAM_MB", 8)      /* ... with non-temporal loads when one stage's rows exceed this many MB (they would only push the stage's nodes out of L2); 0: never */ \
   X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
@@ -587,7 +589,20 @@ static bool upload_model(Cascador* c) {
         lm_meta[o].y = (uint32_t)s.th;
       }
 
+  // the last levels of deep trees once more, as whole records grouped under their ancestor on level split - 1
+  // (kernels.h: lm_deep_index): level-major, each of those levels costs a wave of 64 carts one line per lane and array
+  const unsigned levels = (unsigned)h.D - 1u;
+  const unsigned split = (c->kn.lm_deep && levels >= 5u) ? 3u : levels;
+  const size_t deep_per_cart = (size_t)node_n - ((1u << split) - 1u);
+  std::vector<Node> lm_deep(deep_per_cart * (size_t)h.T * h.K);
+  if (deep_per_cart)
+    for (size_t t = 0; t < (size_t)h.T; t++)
+      for (unsigned k = 0; k < (unsigned)h.K; k++)
+        for (unsigned d = split; d < levels; d++)
+          for (unsigned n = (1u << d) - 1u; n < (2u << d) - 1u; n++)
+            lm_deep[(t * h.K) * deep_per_cart + lm_deep_index(k, d, n, levels, split)] = nodes[(t * h.K + k) * node_n + n];
   Carver sz(nullptr);
+  sz.take<Node>(lm_deep.size());
   sz.take<NodeOff<Real>>(nodes.size()); sz.take<uint2>(nodes.size());
   sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
   sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
@@ -600,6 +615,8 @@ static bool upload_model(Cascador* c) {
   if (padded) sz.take<Real>(w_rows_n * (size_t)w_pitch);
   if (!mo.buf.reserve(sz.off + 256)) return false;
   Carver cv(mo.buf.p);
+  Node* d_lm_deep = cv.take<Node>(lm_deep.size());
+  if (!lm_deep.empty()) JDA_HIP(hipMemcpy(d_lm_deep, lm_deep.data(), lm_deep.size() * sizeof(Node), hipMemcpyHostToDevice));
   NodeOff<Real>* d_lm_off = cv.take<NodeOff<Real>>(nodes.size());
   uint2* d_lm_meta = cv.take<uint2>(nodes.size());
   JDA_HIP(hipMemcpy(d_lm_off, lm_off.data(), nodes.size() * sizeof(NodeOff<Real>), hipMemcpyHostToDevice));
@@ -632,7 +649,9 @@ static bool upload_model(Cascador* c) {
   DevModelT<Real>& m = mo.m;
   m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
   m.nodes = d_nodes; m.lm_off = d_lm_off; m.lm_meta = d_lm_meta; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
+  m.lm_deep = d_lm_deep; m.lm_split = (int)split;
   m.w_rows = d_w_rows; m.w_pitch = padded ? w_pitch : dim;
+  m.w_stream = (c->kn.w_stream_mb > 0 && (size_t)h.K * leaf_n * (size_t)m.w_pitch * sizeof(Real) > (size_t)c->kn.w_stream_mb << 20) ? 1 : 0;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
   m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
   m.par0 = d_par0;

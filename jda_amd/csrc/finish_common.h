@@ -170,7 +170,8 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
                                            int depth, int node_n, const typename DL::Real* sh, int win,
                                            const View& v0, const View& v1, const View& v2,
                                            const Stp<typename DL::Real>& stp, bool apply_st, int* leaf,
-                                           const uint8_t* tile = nullptr, int tpitch = 0) {
+                                           const uint8_t* tile = nullptr, int tpitch = 0,
+                                           const typename DL::Node* __restrict__ stage_deep = nullptr, int split = 1 << 20) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
@@ -178,14 +179,21 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
     // the level's records of the wave's 64 carts are consecutive (kernels.h: lm_index)
     const unsigned first = (1u << d) - 1u, lvl = (unsigned)K * first - first;
     typename DL::Node nd[G];
+    if (d >= split) {
+      // the last levels of a deep tree: whole records, grouped under the path's ancestor (kernels.h: lm_deep_index)
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      const unsigned o = lvl + ((unsigned)k[g] << d) + (unsigned)node[g];
-      const NodeOff<typename DL::Real> f = stage_off[o];
-      const uint2 mt = stage_meta[o];
-      nd[g].o1x = f.o1x; nd[g].o1y = f.o1y; nd[g].o2x = f.o2x; nd[g].o2y = f.o2y;
-      nd[g].lm1x2 = (int)(mt.x & 0x7fffu); nd[g].lm2x2 = (int)((mt.x >> 15) & 0x7fffu); nd[g].scale = (int)(mt.x >> 30);
-      nd[g].th = (int)mt.y;
+      for (int g = 0; g < G; g++)
+        nd[g] = stage_deep[lm_deep_index((unsigned)k[g], (unsigned)d, (unsigned)node[g], (unsigned)(depth - 1), (unsigned)split)];
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const unsigned o = lvl + ((unsigned)k[g] << d) + (unsigned)node[g];
+        const NodeOff<typename DL::Real> f = stage_off[o];
+        const uint2 mt = stage_meta[o];
+        nd[g].o1x = f.o1x; nd[g].o1y = f.o1y; nd[g].o2x = f.o2x; nd[g].o2y = f.o2y;
+        nd[g].lm1x2 = (int)(mt.x & 0x7fffu); nd[g].lm2x2 = (int)((mt.x >> 15) & 0x7fffu); nd[g].scale = (int)(mt.x >> 30);
+        nd[g].th = (int)mt.y;
+      }
     }
     int feat[G];
 #pragma unroll

@@ -17,7 +17,7 @@ namespace jda {
 // time.  Workgroups of 2-4 independent waves lift that to the register limit, measured: no gain -- the launches
 // are bound by the CU's texture addresser / L1 (TA_BUSY 70-75 % on average, 95 % on the busiest CU with 16
 // windows), not by the number of windows in flight.)
-template <typename DL, bool TRACE, int kG, bool MULTI, bool ST>
+template <typename DL, bool TRACE, int kG, bool MULTI, bool ST, bool STREAM = false>
 __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                WorkT<typename DL::Real> w, int multi_i, float inv_sqrt2,
                                                int t_begin, int t_end, int apply_th, typename DL::Real final_th,
@@ -97,6 +97,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     for (int t = t_begin; t < t_end; t++) {
       const NodeOff<Real>* n_off = (const NodeOff<Real>*)m.lm_off + (size_t)t * K * node_n;
       const uint2* n_meta = m.lm_meta + (size_t)t * K * node_n;
+      const int n_split = m.lm_split;
+      const typename DL::Node* n_deep = (const typename DL::Node*)m.lm_deep + (size_t)t * K * (node_n - ((1 << min(n_split, m.D - 1)) - 1));
       const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
       const Real* cth = m.cth + (size_t)t * K;
       const Real* cmean = m.cmean + (size_t)t * K;
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
         if (t == 0 && s0_tbl && use_tile) walk_carts_s0<kG, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
         else if (t == 0 && s0_tbl) walk_carts_s0<kG, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
-        else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
-        else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch, n_deep, n_split);
+        else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, nullptr, 0, n_deep, n_split);
 #pragma unroll
         for (int g = 0; g < kG; g++) {
           const int k = k0 + g * 64 + lane;
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
         if (t == 0 && s0_tbl && use_tile) walk_carts_s0<2, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
         else if (t == 0 && s0_tbl) walk_carts_s0<2, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
-        else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch);
-        else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf);
+        else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch, n_deep, n_split);
+        else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, nullptr, 0, n_deep, n_split);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)w_pitch;
         if (k0 + 64 + lane < k_first) lbf[k0 + 64 + lane] = (uint32_t)((k0 + 64 + lane) * leaf_n + lf[1]) * (uint32_t)w_pitch;
       }
@@ -180,8 +182,10 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         int k = 0;
         for (; k + 32 <= K; k += 32) {          // 32 row loads in flight, then 32 ordered adds
           Real r[32];
+          // (STREAM is a template parameter: as a run-time branch the optimiser merges the two forms of the load and
+          // drops the non-temporal hint)
 #pragma unroll
-          for (int u = 0; u < 32; u++) r[u] = col[lbf[k + u]];
+          for (int u = 0; u < 32; u++) r[u] = STREAM ? __builtin_nontemporal_load(col + lbf[k + u]) : col[lbf[k + u]];
 #pragma unroll
           for (int u = 0; u < 32; u++) acc = acc + r[u];
         }
@@ -442,6 +446,16 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   auto pick = [&](auto trace_tag, auto multi_tag, auto st_tag) {
     constexpr bool TR = decltype(trace_tag)::value, MU = decltype(multi_tag)::value;
     constexpr bool STT = decltype(st_tag)::value && sizeof(Real) == 8;
+    if constexpr (!TR && !MU && !STT) {
+      // a stage's weight rows far larger than L2 (DevModelT::w_stream): the form that reads them with non-temporal loads
+      if (m.w_stream) {
+        if (groups >= 4) go(k_finish<DL, false, 4, false, false, true>);
+        else if (groups == 3) go(k_finish<DL, false, 3, false, false, true>);
+        else if (groups >= 2) go(k_finish<DL, false, 2, false, false, true>);
+        else go(k_finish<DL, false, 1, false, false, true>);
+        return;
+      }
+    }
     if (groups >= 4) go(k_finish<DL, TR, 4, MU, STT>);
     else if (groups == 3) go(k_finish<DL, TR, 3, MU, STT>);
     else if (groups >= 2) go(k_finish<DL, TR, 2, MU, STT>);

@@ -113,6 +113,8 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
     for (int t = 0; t < T && alive; t++) {
       const NodeOff<Real>* n_off = (const NodeOff<Real>*)m.lm_off + (size_t)t * K * node_n;
       const uint2* n_meta = m.lm_meta + (size_t)t * K * node_n;
+      const int n_split = m.lm_split;
+      const typename DL::Node* n_deep = (const typename DL::Node*)m.lm_deep + (size_t)t * K * (node_n - ((1 << min(n_split, m.D - 1)) - 1));
       const Real* leaf_tab = m.leaf + (size_t)t * K * leaf_n;
       const Real* cth = m.cth + (size_t)t * K;
       const Real* cmean = m.cmean + (size_t)t * K;
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
         kk[0] = min(k, K - 1);
         if (t == 0 && s0_tbl && use_tile) walk_carts_s0<1, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
         else if (t == 0 && s0_tbl) walk_carts_s0<1, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
-        else if (use_tile) walk_carts<DL, 1, false, false, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf, tile, tpitch);
-        else walk_carts<DL, 1, false, false>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf);
+        else if (use_tile) walk_carts<DL, 1, false, false, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf, tile, tpitch, n_deep, n_split);
+        else walk_carts<DL, 1, false, false>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf, nullptr, 0, n_deep, n_split);
         if (k < K) {
           lbf[k] = (uint32_t)(k * leaf_n + lf[0]) * (uint32_t)dim;
           lsc[k] = leaf_tab[(unsigned)(k * leaf_n + lf[0])];

@@ -96,6 +96,16 @@ __host__ __device__ inline unsigned lm_index(unsigned K, unsigned k, unsigned d,
   return K * first + (k << d) + (node - first);
 }
 
+// Levels d >= split of a tree with `levels` node levels: the nodes below one ancestor on level split - 1 form a group of
+// lm_deep_group(levels, split) records in level order; the groups of a cart are consecutive, carts follow each other.
+__host__ __device__ inline unsigned lm_deep_group(unsigned levels, unsigned split) { return (2u << (levels - split)) - 2u; }
+__host__ __device__ inline unsigned lm_deep_index(unsigned k, unsigned d, unsigned node, unsigned levels, unsigned split) {
+  const unsigned rel = node - ((1u << d) - 1u);               // position on its level
+  const unsigned below = d - split + 1u;                      // levels between the ancestor and this node
+  const unsigned anc = rel >> below, within = rel & ((1u << below) - 1u);
+  return ((k << (split - 1u)) + anc) * lm_deep_group(levels, split) + ((1u << below) - 2u) + within;
+}
+
 // Stage-0 node with its pixel offsets resolved for one level (DESIGN.md
 // "stage-0 hoist"): in stage 0 every window holds the mean shape, so the
 // feature coordinates depend only on (node, window size).
@@ -117,6 +127,9 @@ struct DevModelT {
   const void* nodes;       // NodeF / NodeD  [T*K*node_n]
   const void* lm_off;      // NodeOff<Real> [T*K*node_n], level-major (lm_index): k_finish's copy of the offsets
   const uint2* lm_meta;    // the same nodes' {lm1x2 | lm2x2 << 15 | scale << 30, th}
+  const void* lm_deep;     // NodeF / NodeD of the levels from lm_split on, grouped per (cart, ancestor on level lm_split - 1) in level
+  int lm_split;            // order (lm_deep_index): a deep tree's last levels of one path share a line or two instead of one line
+                           // per level and array.  lm_split = D - 1: no such levels (depth <= 5), everything level-major
   const Real* leaf;        // [T*K*leaf_n]
   const Real* cth;         // [T*K]
   const Real* cmean;       // [T*K]
@@ -126,6 +139,8 @@ struct DevModelT {
   const Real* w;           // [T][K*leaf_n][dim]
   const Real* w_rows;      // the same rows w_pitch elements apart, each starting on a 128-byte line (k_finish gathers one row
   int w_pitch;             // per cart: a tight 216-byte row straddles a third line in most positions); = w, dim when not padded
+  int w_stream;            // a stage's weight rows are far larger than an XCD's L2: k_finish reads them with non-temporal loads, so that
+                           // they pass through L2 without evicting the stage's split nodes (3 MB for K=2000, D=6)
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
   int similarity;          // dialect CPP: Config::with_similarity_transform

@@ -26,9 +26,11 @@ def sums(path, counter):
 
 
 def group(name):
-    m = re.search(r"k_scan<\w+, \d+, \w+, (\d), \d+(?:, \w+)?>", name)
+    m = re.search(r"k_scan<\w+, \d+, \w+, (\d), \d+(?:, \w+)*>", name)
     if m:
         return "k_scan_global" if m.group(1) == "2" else "k_scan_lds"
+    if "k_scan_p<" in name:          # the persistent form of the LDS-tiled scan
+        return "k_scan_lds"
     for k in ("k_filter0", "k_finish_wide", "k_finish", "k_stage", "k_prep_stage0", "k_enqueue", "k_resize"):
         if k in name:
             return k
