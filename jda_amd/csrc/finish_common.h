@@ -175,26 +175,34 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
-  for (int d = 0; d < depth - 1; d++) {
+  const int levels = depth - 1;
+  const int shallow = min(levels, split);
+  for (int d = 0; d < shallow; d++) {
     // the level's records of the wave's 64 carts are consecutive (kernels.h: lm_index)
     const unsigned first = (1u << d) - 1u, lvl = (unsigned)K * first - first;
     typename DL::Node nd[G];
-    if (d >= split) {
-      // the last levels of a deep tree: whole records, grouped under the path's ancestor (kernels.h: lm_deep_index)
 #pragma unroll
-      for (int g = 0; g < G; g++)
-        nd[g] = stage_deep[lm_deep_index((unsigned)k[g], (unsigned)d, (unsigned)node[g], (unsigned)(depth - 1), (unsigned)split)];
-    } else {
-#pragma unroll
-      for (int g = 0; g < G; g++) {
-        const unsigned o = lvl + ((unsigned)k[g] << d) + (unsigned)node[g];
-        const NodeOff<typename DL::Real> f = stage_off[o];
-        const uint2 mt = stage_meta[o];
-        nd[g].o1x = f.o1x; nd[g].o1y = f.o1y; nd[g].o2x = f.o2x; nd[g].o2y = f.o2y;
-        nd[g].lm1x2 = (int)(mt.x & 0x7fffu); nd[g].lm2x2 = (int)((mt.x >> 15) & 0x7fffu); nd[g].scale = (int)(mt.x >> 30);
-        nd[g].th = (int)mt.y;
-      }
+    for (int g = 0; g < G; g++) {
+      const unsigned o = lvl + ((unsigned)k[g] << d) + (unsigned)node[g];
+      const NodeOff<typename DL::Real> f = stage_off[o];
+      const uint2 mt = stage_meta[o];
+      nd[g].o1x = f.o1x; nd[g].o1y = f.o1y; nd[g].o2x = f.o2x; nd[g].o2y = f.o2y;
+      nd[g].lm1x2 = (int)(mt.x & 0x7fffu); nd[g].lm2x2 = (int)((mt.x >> 15) & 0x7fffu); nd[g].scale = (int)(mt.x >> 30);
+      nd[g].th = (int)mt.y;
     }
+    int feat[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI, ST, TILE>(nd[g], sh, win, v0, v1, v2, stp, apply_st, tile, tpitch);
+#pragma unroll
+    for (int g = 0; g < G; g++) node[g] = 2 * node[g] + (feat[g] <= nd[g].th ? 1 : 2);   // c/jda.c:392-393
+  }
+  // the last levels of a deep tree (a loop of its own: no iteration for the shipped depth, and the loop above keeps the
+  // code it had): whole records, grouped under the path's ancestor (kernels.h: lm_deep_index)
+  for (int d = shallow; d < levels; d++) {
+    typename DL::Node nd[G];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      nd[g] = stage_deep[lm_deep_index((unsigned)k[g], (unsigned)d, (unsigned)node[g], (unsigned)levels, (unsigned)split)];
     int feat[G];
 #pragma unroll
     for (int g = 0; g < G; g++) feat[g] = node_feature<DL, MULTI, ST, TILE>(nd[g], sh, win, v0, v1, v2, stp, apply_st, tile, tpitch);
