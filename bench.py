@@ -22,8 +22,8 @@ call jdaDetect(.., 1.25, 0.1, 40, -1, -0.5) (reference c/main.cpp:25), in the
 finish).  The all-pass regime is measured as a secondary line in "regimes".
 
 The K timed steps go through the library's submit/wait entry points (jdaDetectBatchSubmit /
-jdaDetectBatchWait): the scan of step i+1 is queued before step i is collected, so two batches are in flight
-per GPU from ONE host thread and the GPU works while the host parts of a step run.  Every step is a complete
+jdaDetectBatchWait): steps i+1 and i+2 are queued before step i is collected (--depth 3, the library's three tickets),
+so up to three batches are in flight per GPU from ONE host thread and the GPU works while the host parts of a step run.  Every step is a complete
 pass over one batch and all K finish inside the timed region.  --depth 1 uses one synchronous
 jdaDetectBatchDevice call per step instead; that figure is reported next to the headline in "config" and
 "regimes".
@@ -157,8 +157,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--dims", type=str, default="5,540,27,4")
-    ap.add_argument("--depth", type=int, default=2,
-                    help="batches in flight per rank: 2 = submit/wait pipeline from one host thread (default), "
+    ap.add_argument("--depth", type=int, default=3,
+                    help="batches in flight per rank: 2 / 3 = submit/wait pipeline from one host thread, one / two batches queued ahead (default 3), "
                          "1 = one synchronous call per step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
@@ -276,7 +276,7 @@ def main():
         """depth 2: the K steps go through the submit/wait entry points, two batches in flight from this one thread.
         Every step is still one complete pass over one batch, and all K are finished inside the timed region."""
         mp = model_path(dims, regime, 1, calib)
-        depth = max(1, min(depth, 2, steps))
+        depth = max(1, min(depth, 3, steps))          # (the library has three tickets)
         cascs = [api.Cascador(mp, device=local_rank)]
         casc = cascs[0]
 
@@ -312,13 +312,14 @@ def main():
             for _ in range(warmup):
                 step()
         elif warmup > 0:                 # warm up the path that is timed (its lanes hold a whole batch each)
-            ticket = submit()
+            q = [submit() for _ in range(min(depth - 1, warmup))]
+            issued = len(q)
             for i in range(warmup):
-                nxt = submit() if i + 1 < warmup else None
-                rows = casc.wait_batch(ticket, keep_results="packed", frame_offset=rank * B)
+                if issued < warmup:
+                    q.append(submit()); issued += 1
+                rows = casc.wait_batch(q.pop(0), keep_results="packed", frame_offset=rank * B)
                 if world > 1:
                     gather.start(rows)
-                ticket = nxt
         gather.drain()
         barrier()
         t0 = time.perf_counter()
@@ -332,15 +333,17 @@ def main():
             # two batches in flight from this one thread: the scan of step i+1 is queued before step i is
             # collected (jdaDetectBatchSubmit / jdaDetectBatchWait), so the GPU works on it while the host parts of
             # step i run (queue-length reads, D2H, sort, NMS, result assembly, gather)
-            ticket = submit()
+            # (depth 3: two batches are queued ahead of the one being collected)
+            q = [submit() for _ in range(min(depth - 1, steps))]
+            issued = len(q)
             for i in range(steps):
-                nxt = submit() if i + 1 < steps else None
-                rows, st = casc.wait_batch(ticket, stats=True, keep_results="packed", frame_offset=rank * B)
+                if issued < steps:
+                    q.append(submit()); issued += 1
+                rows, st = casc.wait_batch(q.pop(0), stats=True, keep_results="packed", frame_offset=rank * B)
                 if world > 1:
                     gather.start(rows)
                 n_det = len(rows)
                 stats.append(st)
-                ticket = nxt
         gather.drain()
         barrier()
         el = time.perf_counter() - t0

@@ -13,10 +13,12 @@ c = api.Cascador(mp)
 K = int(os.environ.get("PIPE_STEPS", "40"))
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    t = c.submit_batch_device(ds[0])
+    A = int(os.environ.get("PIPE_AHEAD", "1"))         # batches submitted ahead of the one being waited for
+    q = [c.submit_batch_device(ds[j % R]) for j in range(min(A, K))]
+    issued = len(q)
     for i in range(K):
-        nxt = c.submit_batch_device(ds[(i + 1) % R]) if i + 1 < K else None
-        rows = c.wait_batch(t, keep_results="packed")
-        t = nxt
+        if issued < K:
+            q.append(c.submit_batch_device(ds[issued % R])); issued += 1
+        rows = c.wait_batch(q.pop(0), keep_results="packed")
     torch.cuda.synchronize()
     print("submit/wait %.4f ms per step (%d rows)" % ((time.perf_counter() - t0) / K * 1e3, len(rows)), flush=True)
