@@ -1,0 +1,578 @@
+// libjda.so: the extern "C" entry points of include/jda.h (reference interface: c/jda.h:18-68) and of the batch,
+// trace and dialect-CPP extensions, on top of detect.cpp / tickets.cpp / ragged.cpp.
+#include "detect.h"
+
+// =============================================================================
+// C ABI
+// =============================================================================
+
+using namespace jda;
+
+extern "C" {
+
+const char* jdaGetLastError(void) { return g_err.c_str(); }
+
+static void* create_impl(const char* path, int real_bytes) {
+  g_err.clear();
+  Cascador* c = new (std::nothrow) Cascador();
+  if (!c) return nullptr;
+  c->kn.load();
+  std::string err;
+  if (!load_model(path, real_bytes, &c->hm, &err)) {
+    g_err = err;   // reference returns NULL silently (c/jda.c:487-488); keep the reason retrievable
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void* jdaCascadorCreateDouble(const char* model) { return create_impl(model, 8); }
+void* jdaCascadorCreateFloat(const char* model) { return create_impl(model, 4); }
+void* jdaCascadorCreate(const char* model) { return create_impl(model, 0); }
+
+void jdaCascadorSerializeTo(void* cascador, const char* model) {
+  if (!cascador) return;
+  (void)save_model_f32(((Cascador*)cascador)->hm, model);
+}
+
+void jdaCascadorRelease(void* cascador) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return;
+  // Submitted batches nobody waited for are drained here (their helper threads joined, their streams synchronised by
+  // Lane::destroy).  A call still running on another thread is the caller's error, as with the reference, whose
+  // release frees what jdaDetect reads (c/jda.c:718-720); such a call is given ten seconds to return before the
+  // lanes go -- a race at shutdown then ends in a late but orderly release instead of a use-after-free.
+  for (int i = 0; c->pending && i < kTickets; i++) c->pending[i].join_issuer();
+  {
+    std::unique_lock<std::mutex> lk(c->mu);
+    for (int i = 0; c->pending && i < kTickets; i++)
+      if (c->pending[i].active && c->pending[i].lane) { c->pending[i].lane->busy = false; c->pending[i].active = false; }
+    c->lane_cv.wait_for(lk, std::chrono::seconds(10), [&]() {
+      for (auto& l : c->lanes) if (l->busy) return false;
+      return true;
+    });
+  }
+  if (c->dev_init) {
+    (void)hipSetDevice(c->device);
+    for (auto& l : c->lanes) l->destroy();
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->h2d) { (void)hipStreamSynchronize(c->h2d); (void)hipStreamDestroy(c->h2d); }
+    for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
+    for (auto& b : c->plan_pool) { if (b.dp) (void)hipFree(b.dp); if (b.table) (void)hipFree(b.table); }
+    c->mf.buf.release(); c->md.buf.release();
+  }
+  delete[] c->pending;
+  delete c;
+}
+
+int jdaCascadorInfo(void* cascador, jdaModelInfo* info) {
+  if (!cascador || !info) return -1;
+  const HostModel& h = ((Cascador*)cascador)->hm;
+  info->T = h.T; info->K = h.K; info->landmark_n = h.L; info->tree_depth = h.D;
+  info->multi_scale = h.multi_scale() ? 1 : 0; info->source_real_bytes = h.real_bytes;
+  return 0;
+}
+
+int jdaSetSimilarityTransform(void* cascador, int on) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lock(c->mu);
+  for (auto& l : c->lanes)
+    if (l->busy) { fail("jdaSetSimilarityTransform while a call is running on this cascador"); return -1; }
+  on = on ? 1 : 0;
+  if (c->similarity != on) {
+    c->similarity = on;
+    c->md.ready = false;          // the fp64 node table depends on it (stage-0 offsets carry the transform)
+  }
+  return 0;
+}
+
+int jdaSetDevice(void* cascador, int device) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->dev_init && c->device != device) { fail("jdaSetDevice after first use"); return -1; }
+  c->device = device;
+  return 0;
+}
+
+int jdaSetOption(void* cascador, const char* key, long long value) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !key) { fail("jdaSetOption: null cascador or key"); return -1; }
+  std::lock_guard<std::mutex> lock(c->mu);
+  for (auto& l : c->lanes)
+    if (l->busy) { fail("jdaSetOption while a call is running or a submitted batch is pending on this cascador"); return -1; }
+  for (auto& kv : c->plans)
+    if (kv.second.pins) { fail("jdaSetOption while a call is running on this cascador"); return -1; }
+  if (!c->kn.set(key, value)) { fail(std::string("jdaSetOption: unknown option or value out of range: '") + key + "'"); return -1; }
+  // scan plans (tile shapes, table chunking) depend on the knobs: rebuild them on next use (no lane is busy, so
+  // nothing runs on the old ones)
+  for (auto& kv : c->plans) c->plan_pool.push_back({kv.second.dp, kv.second.table, kv.second.table_cap});
+  c->plans.clear();
+  return 0;
+}
+
+long long jdaGetOption(void* cascador, const char* key) {
+  Cascador* c = (Cascador*)cascador;
+  long long v = 0;
+  if (!c || !key || !c->kn.get(key, &v)) { fail("jdaGetOption: unknown option"); return -1; }
+  return v;
+}
+
+int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
+                    long long* n_windows, int* n_levels) {
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { g_err = err; return -1; }
+  if (n_windows) *n_windows = sp.windows;
+  if (n_levels) *n_levels = (int)sp.levels.size();
+  return 0;
+}
+
+void jdaDetectOptionsInit(jdaDetectOptions* opt) {
+  if (!opt) return;
+  std::memset(opt, 0, sizeof(*opt));
+  opt->dialect = JDA_DIALECT_C; opt->nms = 1; opt->nms_overlap = 0.3f; opt->cpp_step = 5;
+}
+
+int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
+                         int width, int height, float scale, float step, int min_size, int max_size,
+                         float th, const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;  // ignored like the reference (c/jda.c:333)
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchDevice runs dialect C; use jdaDetectBatchCpp"); return -1; }
+  if (!cascador) { fail("null cascador"); return -1; }
+  return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatchSubmit(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
+                         int width, int height, float scale, float step, int min_size, int max_size,
+                         float th, const jdaDetectOptions* opt) {
+  (void)step;
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmit runs dialect C"); return -1; }
+  if (!cascador) { fail("null cascador"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  return submit_c_device(c, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt);
+}
+
+int jdaDetectBatchSubmitHost(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                             float scale, float step, int min_size, int max_size, float th,
+                             const jdaDetectOptions* opt) {
+  (void)step;
+  g_err.clear();
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmitHost runs dialect C"); return -1; }
+  if (!cascador || !frames) { fail("null cascador or frames"); return -1; }
+  if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  return submit_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, frames);
+}
+
+int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* out) {
+  g_err.clear();
+  if (!cascador) { fail("null cascador"); return -1; }
+  Cascador* c = (Cascador*)cascador;
+  return wait_c_device(c, ticket, stats, out);
+}
+
+int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                   float scale, float step, int min_size, int max_size, float th,
+                   const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
+  for (int i = 0; i < n; i++) if (!frames[i]) { fail("null frame pointer"); return -1; }
+  return detect_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, out, frames);
+}
+
+int jdaDetectBatchRagged(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
+                         float scale, float step, int min_size, int max_size, float th,
+                         const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !images || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRagged runs dialect C"); return -1; }
+  return detect_ragged(c, images, nullptr, nullptr, widths, heights, n, scale, min_size, max_size, th, opt, out);
+}
+
+int jdaDetectBatchRaggedDevice(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
+                               const int* heights, int n, float scale, float step, int min_size, int max_size, float th,
+                               const jdaDetectOptions* opt, jdaResult* out) {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedDevice runs dialect C"); return -1; }
+  return detect_ragged(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, out);
+}
+
+jdaResult jdaDetect(void* cascador, unsigned char* data, int width, int height,
+                    float scale, float step, int min_size, int max_size, float th) {
+  Cascador* c = (Cascador*)cascador;
+  jdaResult r;
+  r.n = 0; r.landmark_n = c ? c->hm.L : 0; r.bboxes = nullptr; r.shapes = nullptr; r.scores = nullptr;
+  if (!c || !data) { fail("jdaDetect: null cascador or image"); return empty_result(r.landmark_n); }
+  const unsigned char* frames[1] = {data};
+  if (jdaDetectBatch(cascador, frames, 1, width, height, scale, step, min_size, max_size, th, nullptr, &r) != 0) {
+    jdaResultRelease(r);
+    return empty_result(c->hm.L);
+  }
+  return r;
+}
+
+void jdaResultRelease(jdaResult result) {
+  std::free(result.bboxes);
+  std::free(result.shapes);
+  std::free(result.scores);
+}
+
+int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                  float scale, int min_size, int max_size, int* carts_n, float* score,
+                  unsigned int* path_hash, float* shapes) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
+  PlanEntry* pe = nullptr;
+  if (!begin_call<float>(c, key, sp, JDA_DIALECT_C, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
+  TraceOut<float> tr{carts_n, score, path_hash, shapes};
+  RunStats rs;
+  if (!run_device<float>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.f, nullptr, nullptr, &tr, &rs,
+                         HostFrames{frames, (size_t)width * height})) return -1;
+  return 0;
+}
+
+int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int height,
+                    unsigned char* half, int* hw, int* hh, unsigned char* quarter, int* qw, int* qh) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !data || width <= 0 || height <= 0) { fail("bad arguments"); return -1; }
+  const float r = 1.f / sqrtf(2.f);
+  const int w1 = (int)((float)width * r), h1 = (int)((float)height * r), w2 = width / 2, h2 = height / 2;
+  if (hw) *hw = w1; if (hh) *hh = h1; if (qw) *qw = w2; if (qh) *qh = h2;
+  if (!half && !quarter) return 0;
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
+  const unsigned char* frames[1] = {data};
+  size_t stride = 0;
+  if (!stage_frames(ln, frames, 1, (size_t)width * height, &stride)) return -1;
+  auto one = [&](unsigned char* dst, int dw, int dh) -> bool {
+    if (!dst || dw < 1 || dh < 1) return true;
+    if (!ln->pyr.reserve((size_t)dw * dh + 256)) return false;
+    JDA_HIP(launch_resize((const uint8_t*)ln->frames.p, stride, 1, width, height, (uint8_t*)ln->pyr.p,
+                          (size_t)dw * dh, dw, dh, (float)(width - 1) / dw, (float)(height - 1) / dh, ln->stream));
+    JDA_HIP(hipMemcpyAsync(dst, ln->pyr.p, (size_t)dw * dh, hipMemcpyDeviceToHost, ln->stream));
+    JDA_HIP(hipStreamSynchronize(ln->stream));
+    return true;
+  };
+  if (!one(half, w1, h1) || !one(quarter, w2, h2)) return -1;
+  return 0;
+}
+
+int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                     int minimum_size, int step, double factor, int* carts_n, double* score,
+                     unsigned int* path_hash, double* shapes) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
+  if (!cpp_model_complete(c)) return -1;
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
+  unsigned long long fb; std::memcpy(&fb, &factor, 8);
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
+  PlanEntry* pe = nullptr;
+  if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
+  TraceOut<double> tr{carts_n, score, path_hash, shapes};
+  RunStats rs;
+  if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs,
+                          HostFrames{frames, (size_t)width * height})) return -1;
+  return 0;
+}
+
+int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height, unsigned char* out, int ow, int oh) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !data || !out || width <= 0 || height <= 0 || ow <= 0 || oh <= 0) { fail("bad arguments"); return -1; }
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
+  const unsigned char* frames[1] = {data};
+  size_t stride = 0;
+  if (!stage_frames(ln, frames, 1, (size_t)width * height, &stride)) return -1;
+  auto run = [&]() -> bool {
+    if (!ln->pyr.reserve((size_t)ow * oh + 256)) return false;
+    JDA_HIP(launch_resize_cv((const uint8_t*)ln->frames.p, stride, 1, width, height, (uint8_t*)ln->pyr.p,
+                             (size_t)ow * oh, ow, oh, ln->stream));
+    JDA_HIP(hipMemcpyAsync(out, ln->pyr.p, (size_t)ow * oh, hipMemcpyDeviceToHost, ln->stream));
+    JDA_HIP(hipStreamSynchronize(ln->stream));
+    return true;
+  };
+  return run() ? 0 : -1;
+}
+
+int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                             int origin_size, int step, double factor, double overlap, int nms,
+                             jdaStats* stats, jdaResultD* out) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L, dim = c->hm.dim();
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  if (origin_size < 1 || step < 1 || !(factor > 1.0)) { fail("origin_size/step must be positive and factor > 1"); return -1; }
+  if (c->hm.multi_scale()) { fail("method 0 supports only scale==0 split nodes (its per-window half/quarter patches are not reproduced)"); return -1; }
+  if (!cpp_model_complete(c)) return -1;
+  if (!begin_device(c)) return -1;
+  LaneSet lanes(c);
+  if (!lanes.take(1)) return -1;
+  Lane* ln = lanes.v[0];
+  size_t stride0 = 0;
+  if (!stage_frames(ln, frames, n, (size_t)width * height, &stride0)) return -1;
+
+  // per level: rects (already scaled back), scores, normalised shapes, per frame, in scan order
+  struct Cand { int rect[4]; double score; size_t shape_at; };
+  std::vector<std::vector<Cand>> per_frame(n);
+  std::vector<double> shape_pool;
+  RunStats rs_total;
+  long long patch_total = 0;
+  // level images ping-pong inside one buffer; level 0 is the staged input
+  DevBuf levels;
+  const size_t lvl_stride = ((size_t)width * height + 255) & ~(size_t)255;
+  auto body = [&]() -> bool {
+    if (!levels.reserve(2 * lvl_stride * (size_t)std::max(n, 1))) return false;
+    const uint8_t* cur = (const uint8_t*)ln->frames.p;
+    size_t cur_stride = stride0;
+    int w = width, h = height, li = 0;
+    double scale = 1.;
+    while (w >= origin_size && h >= origin_size) {               // cascador.cpp:283
+      ScanPlan sp; std::string err;
+      if (!plan_single_level(w, h, origin_size, step, &sp, &err)) { fail(err); return false; }
+      PlanKey key{w, h, 2 /* method 0 level */, origin_size, step, c->similarity, 0ull};
+      PlanEntry* pe = nullptr;
+      if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return false;
+      PlanPin pin{c, pe};
+      RawDets<double> dets;
+      RunStats rs;
+      if (!run_device<double>(c, lanes, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return false;
+      rs_total.carts += rs.carts; rs_total.out += rs.out; rs_total.gpu_ms += rs.gpu_ms; rs_total.scan_ms += rs.scan_ms;
+      rs_total.carts_scan += rs.carts_scan; rs_total.win_scan += rs.win_scan; rs_total.scan_launches += rs.scan_launches;
+      rs_total.tail += rs.tail;
+      for (int t = 0; t < c->hm.T; t++) rs_total.stage_done[t] += rs.stage_done[t];
+      patch_total += sp.windows * n;
+      for (size_t i = 0; i < dets.gid.size(); i++) {
+        const WinRef wr = locate(sp, dets.gid[i]);
+        Cand cd;
+        int rx = wr.x, ry = wr.y, rw = wr.win, rh = wr.win;
+        rx = (int)(rx * scale); ry = (int)(ry * scale); rw = (int)(rw * scale); rh = (int)(rh * scale);   // cascador.cpp:292-294
+        cd.rect[0] = rx; cd.rect[1] = ry; cd.rect[2] = rw; cd.rect[3] = rh;
+        cd.score = dets.score[i];
+        cd.shape_at = shape_pool.size();
+        shape_pool.insert(shape_pool.end(), dets.shape.begin() + i * dim, dets.shape.begin() + (i + 1) * dim);
+        per_frame[wr.frame].push_back(cd);
+      }
+      scale *= factor;                                            // cascador.cpp:299
+      const int nw = (int)(w / factor), nh = (int)(h / factor);   // cascador.cpp:300-301
+      if (nw < 1 || nh < 1) break;
+      uint8_t* nxt = (uint8_t*)levels.p + (size_t)(li & 1) * lvl_stride * (size_t)n;
+      JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, ln->stream));   // cascador.cpp:302
+      JDA_HIP(hipStreamSynchronize(ln->stream));
+      cur = nxt; cur_stride = lvl_stride; w = nw; h = nh; li++;
+    }
+    return true;
+  };
+  const bool ok = body();
+  levels.release();
+  if (!ok) return -1;
+
+  const double t0 = now_ms();
+  size_t total = 0;
+  for (auto& v : per_frame) total += v.size();
+  parallel_for(n, [&](int f) {
+    const std::vector<Cand>& cs = per_frame[f];
+    const size_t cnt = cs.size();
+    std::vector<int> rc(cnt * 4);
+    std::vector<double> sc(cnt);
+    for (size_t i = 0; i < cnt; i++) { std::memcpy(&rc[4 * i], cs[i].rect, 16); sc[i] = cs[i].score; }
+    std::vector<int> pick;
+    if (nms) pick = nms_dialect_cpp(rc.data(), sc.data(), (int)cnt, overlap);
+    else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
+    jdaResultD& r = out[f];
+    r.n = (int)pick.size(); r.landmark_n = L;
+    r.rects = (int*)std::malloc(std::max<size_t>(1, pick.size() * 4) * sizeof(int));
+    r.scores = (double*)std::malloc(std::max<size_t>(1, pick.size()) * sizeof(double));
+    r.shapes = (double*)std::malloc(std::max<size_t>(1, pick.size() * dim) * sizeof(double));
+    for (size_t i = 0; i < pick.size(); i++) {
+      const int k = pick[i];
+      std::memcpy(r.rects + 4 * i, &rc[4 * k], 4 * sizeof(int));
+      r.scores[i] = sc[k];
+      double* sh = r.shapes + i * dim;
+      std::memcpy(sh, &shape_pool[cs[k].shape_at], dim * sizeof(double));
+      relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
+    }
+  }, total < 6000);
+  fill_stats(stats, rs_total, patch_total, c->hm.T, c->hm.K, now_ms() - t0);
+  return 0;
+}
+
+int jdaNmsC(const int* bboxes, const float* scores, int n, float overlap, unsigned char* keep) {
+  if (n < 0 || (n > 0 && (!bboxes || !scores || !keep))) return -1;
+  std::vector<int> k = nms_dialect_c(bboxes, scores, n, overlap);
+  std::memset(keep, 0, (size_t)n);
+  for (int i : k) keep[i] = 1;
+  return (int)k.size();
+}
+
+int jdaNmsCpp(const int* rects, const double* scores, int n, double overlap, int* picked) {
+  if (n < 0 || (n > 0 && (!rects || !scores || !picked))) return -1;
+  std::vector<int> k = nms_dialect_cpp(rects, scores, n, overlap);
+  std::copy(k.begin(), k.end(), picked);
+  return (int)k.size();
+}
+
+int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* rows, int capacity_rows) {
+  if (!results || n < 0) return -1;
+  long long total = 0;
+  for (int i = 0; i < n; i++) total += results[i].n;
+  if (!rows) return (int)total;
+  if (total > capacity_rows) return -1;
+  float* o = rows;
+  for (int i = 0; i < n; i++) {
+    const jdaResult& r = results[i];
+    const int dim = 2 * r.landmark_n;
+    for (int j = 0; j < r.n; j++) {
+      o[0] = (float)(frame_offset + i);
+      o[1] = (float)r.bboxes[3 * j]; o[2] = (float)r.bboxes[3 * j + 1]; o[3] = (float)r.bboxes[3 * j + 2];
+      o[4] = r.scores[j];
+      std::memcpy(o + 5, r.shapes + (size_t)j * dim, dim * sizeof(float));
+      o += 5 + dim;
+    }
+  }
+  return (int)total;
+}
+
+void jdaResultsRelease(jdaResult* results, int n) {
+  if (!results) return;
+  for (int i = 0; i < n; i++) {
+    std::free(results[i].bboxes); std::free(results[i].shapes); std::free(results[i].scores);
+    results[i].bboxes = nullptr; results[i].shapes = nullptr; results[i].scores = nullptr; results[i].n = 0;
+  }
+}
+
+// Tile plan of a dialect-C call without touching a device (tests, tools): per level 10 ints
+// {win, step, nx, ny, mode, tw, th, pitch, tiles_x, tiles_y}.  Returns the number of levels.
+int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int min_size, int max_size, int* out, int cap_levels) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c) return -1;
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { fail(err); return -1; }
+  if ((int)sp.levels.size() > kMaxLevels) return -1;
+  PlanEntry pe;
+  bool s0_plain = true;
+  const size_t n0 = (size_t)c->hm.K * c->hm.node_n();
+  for (size_t i = 0; i < n0; i++) s0_plain = s0_plain && c->hm.nodes[i].scale == 0;
+  assign_tiles(sp, c->hm, c->kn, s0_plain, 4, &pe);
+  for (int i = 0; i < pe.hp.n_levels && i < cap_levels && out; i++) {
+    const DevLevel& d = pe.hp.lv[i];
+    const int v[10] = {d.win, d.step, d.nx, d.ny, d.tiled, d.tw, d.th, d.pitch, d.tiles_x, d.tiles_y};
+    std::memcpy(out + 10 * i, v, sizeof v);
+  }
+  return pe.hp.n_levels;
+}
+
+long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
+  return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
+}
+
+#ifdef JDA_SCAN_TIMING
+// timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
+__attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {
+  Cascador* c = (Cascador*)cascador;
+  if (!c || c->lanes.empty() || !c->lanes[0]->wf.dbg) return -1;
+  return hipMemcpy(out, c->lanes[0]->wf.dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
+void jdaResultDRelease(jdaResultD result) {
+  std::free(result.rects);
+  std::free(result.shapes);
+  std::free(result.scores);
+}
+
+int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                      int minimum_size, int step, double factor, double overlap, int nms,
+                      jdaStats* stats, jdaResultD* out) {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L, dim = c->hm.dim();
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  if (!cpp_model_complete(c)) return -1;
+  ScanPlan sp; std::string err;
+  if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
+  unsigned long long fb; std::memcpy(&fb, &factor, 8);
+  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
+  PlanEntry* pe = nullptr;
+  if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
+  PlanPin pin{c, pe};
+  LaneSet lanes(c);
+  size_t stride = 0;
+  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
+  RawDets<double> dets;
+  RunStats rs;
+  if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, &dets, nullptr, &rs,
+                          HostFrames{frames, (size_t)width * height})) return -1;
+  const double t0 = now_ms();
+  std::vector<size_t> first(n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] / (uint32_t)sp.windows == (uint32_t)f) i++;
+    }
+    first[n] = i;
+  }
+  parallel_for(n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    std::vector<int> rc(cnt * 4);
+    for (size_t i = 0; i < cnt; i++) {
+      const WinRef wr = locate(sp, dets.gid[a + i]);
+      rc[4 * i] = wr.x; rc[4 * i + 1] = wr.y; rc[4 * i + 2] = wr.win; rc[4 * i + 3] = wr.win;
+    }
+    std::vector<int> pick;
+    if (nms) pick = nms_dialect_cpp(rc.data(), &dets.score[a], (int)cnt, overlap);
+    else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
+    jdaResultD& r = out[f];
+    r.n = (int)pick.size(); r.landmark_n = L;
+    r.rects = (int*)std::malloc(std::max<size_t>(1, pick.size() * 4) * sizeof(int));
+    r.scores = (double*)std::malloc(std::max<size_t>(1, pick.size()) * sizeof(double));
+    r.shapes = (double*)std::malloc(std::max<size_t>(1, pick.size() * dim) * sizeof(double));
+    for (size_t i = 0; i < pick.size(); i++) {
+      const int k = pick[i];
+      std::memcpy(r.rects + 4 * i, &rc[4 * k], 4 * sizeof(int));
+      r.scores[i] = dets.score[a + k];
+      double* sh = r.shapes + i * dim;
+      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(double));
+      relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
+    }
+  }, dets.gid.size() < 6000);
+  fill_stats(stats, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// libjda.so, host side: the device of a cascador, its lanes (stream + workspace + staging buffers) and their workspaces.
+#include "host.h"
+
+namespace jda {
+
+// ---------------------------------------------------------------- device init, lanes
+
+// Makes the cascador's device current for the calling thread; first use picks the device (caller holds c->mu then).
+bool ensure_device(Cascador* c) {
+  if (c->dev_init) {
+    JDA_HIP(hipSetDevice(c->device));
+    return true;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    fail("no usable HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) +
+         "); libjda has no CPU fallback for the cascade");
+    return false;
+  }
+  if (c->device < 0) {
+    int cur = 0;
+    JDA_HIP(hipGetDevice(&cur));
+    c->device = cur;
+  }
+  if (c->device >= n) { fail("device ordinal out of range"); return false; }
+  JDA_HIP(hipSetDevice(c->device));
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
+  JDA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  c->dev_init = true;
+  return true;
+}
+
+// A free lane (caller holds c->mu): the one whose workspace fits `want_cap` windows most tightly, else the largest,
+// else a new one -- unless the pool has reached max_lanes: then nullptr with *exhausted set (the caller waits for a
+// lane to come back, or goes on with the lanes it holds).  Free lanes that were passed over `lane_idle_calls` times
+// give their buffers back.
+Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted) {
+  Lane* best = nullptr;
+  for (auto& up : c->lanes) {
+    Lane* l = up.get();
+    if (l->busy) continue;
+    if (!best) { best = l; continue; }
+    const bool fit = l->cap >= want_cap, bfit = best->cap >= want_cap;
+    if (fit != bfit ? fit : (fit ? l->cap < best->cap : l->cap > best->cap)) best = l;
+  }
+  if (!best) {
+    if ((long long)c->lanes.size() >= std::max<long long>(1, c->kn.max_lanes)) { if (exhausted) *exhausted = true; return nullptr; }
+    std::unique_ptr<Lane> l(new (std::nothrow) Lane());
+    if (!l || !l->create()) { if (l) l->destroy(); return nullptr; }
+    best = l.get();
+    c->lanes.push_back(std::move(l));
+  }
+  const long long idle_max = c->kn.lane_idle_calls;
+  for (auto& up : c->lanes) {
+    Lane* l = up.get();
+    if (l->busy || l == best) continue;
+    if (idle_max > 0 && ++l->idle > (unsigned long long)idle_max && (l->ws.p || l->frames.p || l->rag_frames.p)) l->trim();
+  }
+  best->busy = true;
+  best->idle = 0;
+  return best;
+}
+
+// ---------------------------------------------------------------- workspace
+
+template <typename Real>
+size_t bytes_per_window(int dim, bool trace) {
+  size_t b = (4 + sizeof(Real) + 4 + 8) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real)) + 8 + 4;
+  if (trace) b += 4 + 4 + sizeof(Real) + 4 + (size_t)dim * sizeof(Real);
+  return b;
+}
+
+// The lane's per-window arrays for `cap` windows of dialect Real (grow-only; the lane is idle: its holder has
+// collected whatever ran on it).
+template <typename Real>
+bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim) {
+  if (ln->cap >= cap && (ln->trace || !trace) && ln->dim == dim && ln->real_bytes == (int)sizeof(Real)) return true;
+  trace = trace || (ln->trace && ln->dim == dim && ln->real_bytes == (int)sizeof(Real));
+  cap = std::max(cap, ln->real_bytes == (int)sizeof(Real) && ln->dim == dim ? ln->cap : (size_t)0);
+  WorkT<Real>& w = Sel<Real>::work(ln);
+  auto carve = [&](Carver& cv) {
+    w.q_gid = cv.take<uint32_t>(cap);
+    w.q_score = cv.take<Real>(cap);
+    w.q_kstart = cv.take<uint32_t>(cap);
+    w.q_xy = cv.take<uint32_t>(cap);
+    w.q_wf = cv.take<uint32_t>(cap);
+    w.q_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
+    w.m_gid = cv.take<uint32_t>(cap);
+    w.m_score = cv.take<Real>(cap);
+    w.m_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
+    w.m_shape = cv.take<Real>(cap * dim);
+    w.m_xy = cv.take<uint32_t>(cap);
+    w.m_wf = cv.take<uint32_t>(cap);
+    w.st_carts = cv.take<int>(cap);
+    w.out_gid = cv.take<uint32_t>(cap);
+    w.out_score = cv.take<Real>(cap);
+    w.out_shape = cv.take<Real>(cap * dim);
+    w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
+#ifdef JDA_SCAN_TIMING
+    w.dbg = cv.take<unsigned long long>(65536 * 32);
+#endif
+    if (trace) {
+      w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
+      w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
+    } else {
+      w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
+    }
+  };
+  if (ln->stream) (void)hipStreamSynchronize(ln->stream);      // nothing may still use the old carving
+  w = WorkT<Real>{};
+  Carver sz(nullptr);
+  carve(sz);
+  if (!ln->ws.reserve(sz.off + 256)) {
+    // the old allocation is gone: forget every pointer carved out of it
+    ln->cap = 0; ln->trace = false; ln->real_bytes = 0;
+    ln->wf = WorkT<float>{}; ln->wd = WorkT<double>{};
+    return false;
+  }
+  Carver cv(ln->ws.p);
+  carve(cv);
+  w.cap = (unsigned)cap;
+  ln->cap = cap; ln->trace = trace; ln->dim = dim; ln->real_bytes = (int)sizeof(Real);
+  return true;
+}
+
+// Copies a run of host frames to the staging buffer (frame i at dst + i*stride) on a stream.
+// Frames that lie back to back in host memory (one array) go as ONE strided copy: 256 separate
+// 300-KB copies from pageable memory reach ~15 GB/s, one copy of the batch 57 GB/s (tools/pcie_bw.py).
+bool copy_frames_h2d(uint8_t* dst, size_t stride, const unsigned char* const* frames, int n, size_t fbytes,
+                            hipStream_t st) {
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && frames[j] == frames[j - 1] + fbytes) j++;
+    if (j - i == 1) {
+      JDA_HIP(hipMemcpyAsync(dst + (size_t)i * stride, frames[i], fbytes, hipMemcpyHostToDevice, st));
+    } else if (stride == fbytes) {
+      JDA_HIP(hipMemcpyAsync(dst + (size_t)i * stride, frames[i], fbytes * (size_t)(j - i), hipMemcpyHostToDevice, st));
+    } else {
+      JDA_HIP(hipMemcpy2DAsync(dst + (size_t)i * stride, stride, frames[i], fbytes, fbytes, (size_t)(j - i),
+                               hipMemcpyHostToDevice, st));
+    }
+    i = j;
+  }
+  return true;
+}
+
+template size_t bytes_per_window<float>(int, bool);
+template size_t bytes_per_window<double>(int, bool);
+template bool ensure_workspace<float>(Lane*, size_t, bool, int);
+template bool ensure_workspace<double>(Lane*, size_t, bool, int);
+
+}  // namespace jda

@@ -1,0 +1,178 @@
+// libjda.so, host side: the model's device copies (split nodes in the layouts the kernels read, leaf scores, cart
+// parameters, regression weights).  File layout: reference c/jda.c:114-180, 499-560.
+#include "host.h"
+
+namespace jda {
+
+template <typename Real>
+bool upload_model(Cascador* c) {
+  ModelOnDevice<Real>& mo = Sel<Real>::model(c);
+  if (mo.ready) return true;
+  const HostModel& h = c->hm;
+  using Node = typename std::conditional<sizeof(Real) == 4, NodeF, NodeD>::type;
+  const size_t carts = (size_t)h.carts();
+  const int node_n = h.node_n(), leaf_n = h.leaf_n(), dim = h.dim();
+  std::vector<Node> nodes(carts * node_n);
+  // stage-0 similarity transform, reference data.cpp:64-114 (see stp_calc in k_finish.hip for the
+  // restated OpenCV details); identity when off
+  double stp0[5] = {1., 1., 0., 0., 1.};
+  if (sizeof(Real) == 8 && c->similarity) {
+    const int L = h.L;
+    std::vector<double> s1(dim), t1(dim), t2(dim);
+    const std::vector<double>& s2 = h.mean_shape;
+    const volatile double zero = 0.;
+    for (int i = 0; i < dim; i++) s1[i] = s2[i] + zero;
+    double x1c = 0., y1c = 0., x2c = 0., y2c = 0.;
+    for (int i = 0; i < L; i++) { x1c += s1[2 * i]; y1c += s1[2 * i + 1]; x2c += s2[2 * i]; y2c += s2[2 * i + 1]; }
+    x1c /= (double)L; y1c /= (double)L; x2c /= (double)L; y2c /= (double)L;
+    for (int i = 0; i < L; i++) {
+      t1[2 * i] = s1[2 * i] - x1c; t1[2 * i + 1] = s1[2 * i + 1] - y1c;
+      t2[2 * i] = s2[2 * i] - x2c; t2[2 * i + 1] = s2[2 * i + 1] - y2c;
+    }
+    auto cvnorm = [](const std::vector<double>& v) {
+      double a = 0.; size_t i = 0; const size_t n = v.size();
+      for (; i + 4 <= n; i += 4) { const double v0 = v[i], v1 = v[i + 1], v2 = v[i + 2], v3 = v[i + 3]; a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3; }
+      for (; i < n; i++) a += v[i] * v[i];
+      return std::sqrt(a);
+    };
+    const double scale1 = cvnorm(t1), scale2 = cvnorm(t2);
+    stp0[0] = scale1 / scale2;
+    const double a1 = 1. / scale1, a2 = 1. / scale2;
+    for (int i = 0; i < dim; i++) { t1[i] = t1[i] * a1 + zero; t2[i] = t2[i] * a2 + zero; }
+    double num = 0., den = 0.;
+    for (int i = 0; i < L; i++) {
+      num += t1[2 * i + 1] * t2[2 * i] - t1[2 * i] * t2[2 * i + 1];
+      den += t1[2 * i] * t2[2 * i] + t1[2 * i + 1] * t2[2 * i + 1];
+    }
+    const double norm = std::sqrt(num * num + den * den);
+    const double sn = num / norm, cs = den / norm;
+    stp0[1] = cs; stp0[2] = -sn; stp0[3] = sn; stp0[4] = cs;
+  }
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const SplitNode& s = h.nodes[i];
+    Node& d = nodes[i];
+    d.scale = s.scale; d.lm1x2 = s.lm1 * 2; d.lm2x2 = s.lm2 * 2; d.th = s.th;
+    if (sizeof(Real) == 4) {
+      // plain narrowing casts, reference c/jda.c:525-532
+      d.o1x = (Real)s.off[0]; d.o1y = (Real)s.off[1]; d.o2x = (Real)s.off[2]; d.o2y = (Real)s.off[3];
+    } else {
+      // STParameter::Apply on each offset pair (data.hpp:42-45, data.cpp:33-34) with the parameter
+      // that is the same for every window: the identity when the similarity transform is off, and
+      // -- for STAGE 0 only, where every window holds the mean shape -- Calc(mean+0, mean) when it is
+      // on.  Later stages keep the raw offsets; k_finish applies each window's own parameter.
+      const bool raw = c->similarity && i >= (size_t)h.K * node_n;
+      const volatile double sc = stp0[0], r00 = stp0[1], r01 = stp0[2], r10 = stp0[3], r11 = stp0[4];
+      if (raw) {
+        d.o1x = (Real)s.off[0]; d.o1y = (Real)s.off[1]; d.o2x = (Real)s.off[2]; d.o2y = (Real)s.off[3];
+      } else {
+        d.o1x = (Real)(sc * (r00 * s.off[0] + r01 * s.off[1]));
+        d.o1y = (Real)(sc * (r10 * s.off[0] + r11 * s.off[1]));
+        d.o2x = (Real)(sc * (r00 * s.off[2] + r01 * s.off[3]));
+        d.o2y = (Real)(sc * (r10 * s.off[2] + r11 * s.off[3]));
+      }
+    }
+  }
+  auto cast = [](const std::vector<double>& v) {
+    std::vector<Real> o(v.size());
+    for (size_t i = 0; i < v.size(); i++) o[i] = (Real)v[i];
+    return o;
+  };
+  std::vector<Real> leaf = cast(h.leaf_score), cth = cast(h.cart_th), cmean = cast(h.cart_mean),
+                    cstd = cast(h.cart_std), w = cast(h.w), ms = cast(h.mean_shape), ms_raw = cast(h.mean_shape);
+  if (sizeof(Real) == 8) {
+    const volatile double zero = 0.;
+    for (auto& v : ms) v = (Real)((double)v + zero);   // RandomShape with zero shift, data.cpp:225-236
+  }
+  std::vector<uint8_t> cnorm(carts);
+  for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);
+  std::vector<Real> par0(carts * 4);             // {th, norm, mean, std} per cart (CartPar), packed for LDS staging
+  for (size_t k = 0; k < carts; k++) { par0[4 * k] = cth[k]; par0[4 * k + 1] = cnorm[k] ? (Real)1 : (Real)0; par0[4 * k + 2] = cmean[k]; par0[4 * k + 3] = cstd[k]; }
+
+  // level-major split copy of the nodes for k_finish (kernels.h: NodeOff, lm_index)
+  std::vector<NodeOff<Real>> lm_off(nodes.size());
+  std::vector<uint2> lm_meta(nodes.size());
+  for (size_t t = 0; t < (size_t)h.T; t++)
+    for (unsigned k = 0; k < (unsigned)h.K; k++)
+      for (unsigned d = 0, n = 0; n < (unsigned)node_n; n++) {
+        while (n >= (2u << d) - 1u) d++;
+        const Node& s = nodes[(t * h.K + k) * node_n + n];
+        const size_t o = t * (size_t)h.K * node_n + lm_index((unsigned)h.K, k, d, n);
+        lm_off[o].o1x = s.o1x; lm_off[o].o1y = s.o1y; lm_off[o].o2x = s.o2x; lm_off[o].o2y = s.o2y;
+        lm_meta[o].x = (uint32_t)s.lm1x2 | ((uint32_t)s.lm2x2 << 15) | ((uint32_t)s.scale << 30);
+        lm_meta[o].y = (uint32_t)s.th;
+      }
+
+  // the last levels of deep trees once more, as whole records grouped under their ancestor on level split - 1
+  // (kernels.h: lm_deep_index): level-major, each of those levels costs a wave of 64 carts one line per lane and array
+  const unsigned levels = (unsigned)h.D - 1u;
+  const unsigned split = (c->kn.lm_deep && levels >= 5u) ? 3u : levels;
+  const size_t deep_per_cart = (size_t)node_n - ((1u << split) - 1u);
+  std::vector<Node> lm_deep(deep_per_cart * (size_t)h.T * h.K);
+  if (deep_per_cart)
+    for (size_t t = 0; t < (size_t)h.T; t++)
+      for (unsigned k = 0; k < (unsigned)h.K; k++)
+        for (unsigned d = split; d < levels; d++)
+          for (unsigned n = (1u << d) - 1u; n < (2u << d) - 1u; n++)
+            lm_deep[(t * h.K) * deep_per_cart + lm_deep_index(k, d, n, levels, split)] = nodes[(t * h.K + k) * node_n + n];
+  Carver sz(nullptr);
+  sz.take<Node>(lm_deep.size());
+  sz.take<NodeOff<Real>>(nodes.size()); sz.take<uint2>(nodes.size());
+  sz.take<Node>(nodes.size()); sz.take<Real>(leaf.size()); sz.take<Real>(carts); sz.take<Real>(carts);
+  sz.take<Real>(carts); sz.take<uint8_t>(carts); sz.take<Real>(w.size()); sz.take<Real>(dim); sz.take<Real>(dim); sz.take<Real>(par0.size());
+  // k_finish's copy of the weight rows: every row on its own 128-byte lines (the file layout, c/jda.c:146, is what
+  // k_stage and k_finish_wide stage whole carts of; a wave-per-window gather of single rows pays per line touched)
+  const size_t w_rows_n = w.size() / (size_t)dim;
+  const int line_elems = 128 / (int)sizeof(Real);
+  const int w_pitch = c->kn.w_pad ? ((dim + line_elems - 1) / line_elems) * line_elems : dim;
+  const bool padded = w_pitch != dim && w_rows_n * (size_t)w_pitch < (1ull << 32);      // (k_finish keeps row offsets in 32 bits)
+  if (padded) sz.take<Real>(w_rows_n * (size_t)w_pitch);
+  if (!mo.buf.reserve(sz.off + 256)) return false;
+  Carver cv(mo.buf.p);
+  Node* d_lm_deep = cv.take<Node>(lm_deep.size());
+  if (!lm_deep.empty()) JDA_HIP(hipMemcpy(d_lm_deep, lm_deep.data(), lm_deep.size() * sizeof(Node), hipMemcpyHostToDevice));
+  NodeOff<Real>* d_lm_off = cv.take<NodeOff<Real>>(nodes.size());
+  uint2* d_lm_meta = cv.take<uint2>(nodes.size());
+  JDA_HIP(hipMemcpy(d_lm_off, lm_off.data(), nodes.size() * sizeof(NodeOff<Real>), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_lm_meta, lm_meta.data(), nodes.size() * sizeof(uint2), hipMemcpyHostToDevice));
+  Node* d_nodes = cv.take<Node>(nodes.size());
+  Real* d_leaf = cv.take<Real>(leaf.size());
+  Real* d_cth = cv.take<Real>(carts);
+  Real* d_cmean = cv.take<Real>(carts);
+  Real* d_cstd = cv.take<Real>(carts);
+  uint8_t* d_cnorm = cv.take<uint8_t>(carts);
+  Real* d_w = cv.take<Real>(w.size());
+  Real* d_ms = cv.take<Real>(dim);
+  Real* d_ms_raw = cv.take<Real>(dim);
+  Real* d_par0 = cv.take<Real>(par0.size());
+  Real* d_w_rows = padded ? cv.take<Real>(w_rows_n * (size_t)w_pitch) : d_w;
+  JDA_HIP(hipMemcpy(d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_leaf, leaf.data(), leaf.size() * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cth, cth.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cmean, cmean.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cstd, cstd.data(), carts * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_cnorm, cnorm.data(), carts, hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_w, w.data(), w.size() * sizeof(Real), hipMemcpyHostToDevice));
+  if (padded) {
+    JDA_HIP(hipMemset(d_w_rows, 0, w_rows_n * (size_t)w_pitch * sizeof(Real)));
+    JDA_HIP(hipMemcpy2D(d_w_rows, (size_t)w_pitch * sizeof(Real), d_w, (size_t)dim * sizeof(Real), (size_t)dim * sizeof(Real), w_rows_n, hipMemcpyDeviceToDevice));
+  }
+  JDA_HIP(hipMemcpy(d_ms, ms.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_ms_raw, ms_raw.data(), dim * sizeof(Real), hipMemcpyHostToDevice));
+  JDA_HIP(hipMemcpy(d_par0, par0.data(), par0.size() * sizeof(Real), hipMemcpyHostToDevice));
+  DevModelT<Real>& m = mo.m;
+  m.T = h.T; m.K = h.K; m.L = h.L; m.D = h.D; m.node_n = node_n; m.leaf_n = leaf_n; m.dim = dim;
+  m.nodes = d_nodes; m.lm_off = d_lm_off; m.lm_meta = d_lm_meta; m.leaf = d_leaf; m.cth = d_cth; m.cmean = d_cmean; m.cstd = d_cstd;
+  m.lm_deep = d_lm_deep; m.lm_split = (int)split;
+  m.w_rows = d_w_rows; m.w_pitch = padded ? w_pitch : dim;
+  m.w_stream = (c->kn.w_stream_mb > 0 && (size_t)h.K * leaf_n * (size_t)m.w_pitch * sizeof(Real) > (size_t)c->kn.w_stream_mb << 20) ? 1 : 0;
+  m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
+  m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
+  m.par0 = d_par0;
+  mo.ready = true;
+  return true;
+}
+
+template bool upload_model<float>(Cascador*);
+template bool upload_model<double>(Cascador*);
+
+}  // namespace jda

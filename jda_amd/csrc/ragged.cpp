@@ -1,0 +1,583 @@
+// libjda.so, host side: images of different sizes as ONE job (jdaDetectBatchRagged[Device]; the reference's FDDB loop,
+// src/test.cpp:100-170, is one Detect per image).
+#include "detect.h"
+
+namespace jda {
+
+// ---------------------------------------------------------------- ragged batches (images of different sizes)
+//
+// The reference's FDDB loop calls Detect once per image (src/test.cpp:100-170), the C API once per jdaDetect; on a
+// GPU that is one latency-bound pass per image.  A ragged job runs a list of differently sized images as a few
+// passes: the window sizes of c/jda.c:331-333 are the same series for every image (an image uses the prefix that fits
+// it), so the levels, their tile shapes and stage-0 tables are shared, and the images are staged with ONE row pitch.
+// Per image the results are those of jdaDetect on that image.
+
+struct RaggedJob {
+  int n = 0;
+  const int* widths = nullptr; const int* heights = nullptr;
+  const unsigned char* const* host_imgs = nullptr;     // tight images in host memory, or
+  const uint8_t* d_base = nullptr; const size_t* d_offsets = nullptr;   // ... on the device at d_base + d_offsets[i]
+  int pitch = 0;                    // common row pitch of the staged images (multiple of 16)
+  ScanPlan levels;                  // global level list; nx, ny = nominal (mean) grids, width = pitch
+  std::vector<int> n_lv;            // levels image i has (a prefix of the global list)
+  PlanEntry* pe = nullptr;
+  uint8_t* d_job_raw = nullptr;     // host job with a helper thread: every chunk's tight images go here ...
+  std::vector<size_t> raw_off;      // ... chunk k at d_job_raw + raw_off[k]
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Levels of image (w, h): the prefix of the job's global list whose windows fit (c/jda.c:321-322,332).
+static int ragged_levels_of(const RaggedJob& job, int w, int h) {
+  const int lim = std::min(w, h);
+  int k = 0;
+  while (k < (int)job.levels.levels.size() && job.levels.levels[k].win <= lim) k++;
+  return k;
+}
+
+// Geometry of a ragged call: common pitch, global levels with nominal grids, the plan (tile shapes + tables).
+// Returns 0 = ok, 1 = this job needs the per-image fallback, -1 = error.
+static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size, int max_size) {
+  int max_w = 0, max_min = 0;
+  for (int i = 0; i < job->n; i++) {
+    if (job->widths[i] <= 0 || job->heights[i] <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
+    if (job->widths[i] > 65535 || job->heights[i] > 65535) { fail("images wider or taller than 65535 pixels are not supported"); return -1; }
+    max_w = std::max(max_w, job->widths[i]);
+    max_min = std::max(max_min, std::min(job->widths[i], job->heights[i]));
+  }
+  std::string err;
+  if (!plan_dialect_c(max_min, max_min, scale, min_size, max_size, &job->levels, &err)) { fail(err); return -1; }
+  const int nl = (int)job->levels.levels.size();
+  if (nl > kMaxLevels) return 1;
+  int pitch = (max_w + 15) & ~15;
+  if ((pitch & 255) == 0) pitch += 16;            // keep rows of neighbouring tiles off one memory channel
+  job->pitch = pitch;
+  job->levels.width = pitch; job->levels.height = max_min;
+  // nominal grids: the mean over the images that have the level (tile shapes are chosen for them)
+  std::vector<double> sx(nl, 0.0), sy(nl, 0.0);
+  std::vector<long long> cnt(nl, 0);
+  job->n_lv.resize(job->n);
+  for (int i = 0; i < job->n; i++) {
+    const int k = ragged_levels_of(*job, job->widths[i], job->heights[i]);
+    job->n_lv[i] = k;
+    for (int l = 0; l < k; l++) {
+      const Level& lv = job->levels.levels[l];
+      sx[l] += (job->widths[i] - lv.win) / lv.step + 1; sy[l] += (job->heights[i] - lv.win) / lv.step + 1; cnt[l]++;
+    }
+  }
+  unsigned long long h = 1469598103934665603ull;
+  for (int l = 0; l < nl; l++) {
+    Level& lv = job->levels.levels[l];
+    // quantised, so that jobs over similar image sets share a plan
+    // (rounded UP: a nominal grid one window narrower than the images' cuts every row of tiles in two)
+    const int qx = cnt[l] ? std::max(1, (int)std::ceil(sx[l] / (double)cnt[l] / 4.0) * 4) : 1;
+    const int qy = cnt[l] ? std::max(1, (int)std::ceil(sy[l] / (double)cnt[l] / 4.0) * 4) : 1;
+    lv.nx = qx; lv.ny = qy; lv.base = 0;
+    h = (h ^ (unsigned long long)(qx * 65536 + qy)) * 1099511628211ull;
+  }
+  job->levels.windows = 0;
+  unsigned sb; std::memcpy(&sb, &scale, 4);
+  PlanKey key{pitch, nl, 3 /* ragged, dialect C */, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, h};
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!get_plan(c, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
+  if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
+  if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
+  for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;
+  return 0;
+}
+
+// The level's tile re-cut for an image's own grid of nx x ny windows: as few tiles per row as the level's widest tile
+// allows, evenly wide; the slack of a narrower tile goes into its height (up to 512 windows and the LDS the level's
+// launch may use), again evenly.  An FDDB-sized image (77 x 64 windows of 46 pixels) gets 2 x 5 tiles of 39 x 13 windows
+// (99 % of a 512-lane first phase) instead of 2 x 7 of 50 x 10 (60 %).
+static void ragged_tile(const DevLevel& d, int nx, int ny, int th_lds, int* tw, int* th) {
+  if (d.tiled == 2) th_lds = 512;                                  // global-pixel "tiles" are only window groups: no LDS limit
+  const int tx = (nx + d.tw - 1) / d.tw;
+  *tw = (nx + tx - 1) / tx;
+  const int cap = std::max(1, std::min(th_lds, 512 / *tw));
+  const int ty = (ny + cap - 1) / cap;
+  *th = (ny + ty - 1) / ty;
+}
+// rows of windows a tile of level d may hold within lds_budget bytes of pixels
+static int ragged_th_lds(const DevLevel& d, int pix_budget) {
+  const int rows = pix_budget / std::max(1, d.pitch);
+  return std::max(d.th, (rows - d.win) / std::max(1, d.step) + 1);
+}
+
+// Tables of images [i0, i0 + n) into the lane's pinned table buffer (and, for host images that do not lie back to
+// back, the images into the lane's pinned staging buffer).
+static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
+  const DevPlan& hp = job.pe->hp;
+  const int nl = hp.n_levels;
+  ch->i0 = i0; ch->n = n; ch->pitch = job.pitch;
+  ch->widths = job.widths + i0; ch->heights = job.heights + i0;
+  ch->host_imgs = job.host_imgs ? job.host_imgs + i0 : nullptr;
+  ch->d_raw = job.d_base;
+  // ---- counts ----
+  // How far a re-cut tile's pixels may outgrow the level's nominal tile (taller, narrower tiles for narrow images): as
+  // far as the workgroups per CU stay what the nominal tile allows -- measured, a flat 1.4x took the 71/88-pixel levels
+  // from 2 workgroups per CU to 1 and cost more than the fuller first phase gained.
+  int th_lds[kMaxLevels];
+  {
+    const HostModel& hm = c->hm;
+    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), 4));
+    for (int l = 0; l < nl; l++) {
+      const DevLevel& d = hp.lv[l];
+      if (d.tiled == 2) { th_lds[l] = d.th; continue; }
+      const int nominal = d.pitch * (d.win + (d.th - 1) * d.step);
+      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), 4, false, d.tw * d.th > 256 ? 512 : 256);
+      const int per_cu = std::max(1, (160 * 1024) / (fixed + nominal));
+      const int room = (160 * 1024) / per_cu - fixed - 64;
+      th_lds[l] = ragged_th_lds(d, std::max(nominal, std::min(room, nominal * (int)c->kn.ragged_tile_grow_pct / 100)));
+    }
+  }
+  int n_segs = 0;
+  long long n_blk = 0;
+  for (int i = 0; i < n; i++) {
+    const int W = job.widths[i0 + i], H = job.heights[i0 + i];
+    n_segs += job.n_lv[i0 + i];
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      const int nx = (W - d.win) / d.step + 1, ny = (H - d.win) / d.step + 1;
+      int tw, th;
+      ragged_tile(d, nx, ny, th_lds[l], &tw, &th);
+      n_blk += (long long)((nx + tw - 1) / tw) * ((ny + th - 1) / th);
+    }
+  }
+  if (n_blk > 0x7fffffffLL) { fail("ragged chunk has too many tiles"); return false; }
+  ch->n_segs = n_segs; ch->n_blk = (int)n_blk;
+  size_t o = 0;
+  ch->off_segs = o; o = align_up(o + (size_t)n_segs * sizeof(RagSeg), 256);
+  ch->off_blk = o; o = align_up(o + (size_t)n_blk * sizeof(RagBlk), 256);
+  ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
+  ch->off_rimg = o; o = align_up(o + (size_t)n * sizeof(RagImg), 256);
+  ch->table_bytes = o;
+  if (!ln->h_tab.reserve(o) || !ln->rag_tab.reserve(o)) return false;
+  uint8_t* tab = (uint8_t*)ln->h_tab.p;
+  RagSeg* segs = (RagSeg*)(tab + ch->off_segs);
+  RagBlk* blk = (RagBlk*)(tab + ch->off_blk);
+  unsigned long long* img_off = (unsigned long long*)(tab + ch->off_imgoff);
+  RagImg* rimg = (RagImg*)(tab + ch->off_rimg);
+  // ---- images and segments ----
+  ch->gid_base.assign(n + 1, 0);
+  std::vector<int> seg_first(n + 1, 0);
+  size_t dst = 0, src = 0;
+  long long gid = 0;
+  int max_h = 0, si = 0;
+  bool contiguous = job.host_imgs != nullptr;
+  for (int i = 0; i < n; i++) {
+    const int W = job.widths[i0 + i], H = job.heights[i0 + i];
+    max_h = std::max(max_h, H);
+    img_off[i] = dst;
+    rimg[i].dst_off = dst; rimg[i].w = W; rimg[i].h = H;
+    if (job.host_imgs) {
+      if (!job.host_imgs[i0 + i]) { fail("null image pointer"); return false; }
+      if (i > 0 && job.host_imgs[i0 + i] != job.host_imgs[i0 + i - 1] + (size_t)job.widths[i0 + i - 1] * job.heights[i0 + i - 1]) contiguous = false;
+      rimg[i].src_off = src;                         // tight, back to back in the staging copy
+      src += (size_t)W * H;
+    } else {
+      rimg[i].src_off = job.d_offsets[i0 + i];
+    }
+    dst += align_up((size_t)H * job.pitch, 256);
+    ch->gid_base[i] = (uint32_t)gid;
+    seg_first[i] = si;
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      RagSeg& sg = segs[si++];
+      sg.img_off = img_off[i]; sg.gid_base = (uint32_t)gid;
+      sg.nx = (uint16_t)((W - d.win) / d.step + 1); sg.ny = (uint16_t)((H - d.win) / d.step + 1);
+      int tw, th;
+      ragged_tile(d, sg.nx, sg.ny, th_lds[l], &tw, &th);
+      sg.tw = (uint16_t)tw; sg.th = (uint16_t)th;
+      sg.tiles_x = (uint16_t)((sg.nx + tw - 1) / tw);
+      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = 0;
+      sg.win = d.win; sg.step = d.step; sg.pitch = d.pitch; sg.s0_table = d.s0_table; sg.tiled = d.tiled;
+      sg.pad2 = sg.pad3 = sg.pad4 = 0;
+      gid += (long long)sg.nx * sg.ny;
+    }
+  }
+  seg_first[n] = si;
+  ch->gid_base[n] = (uint32_t)gid;
+  if (gid > 0x7fffffffLL) { fail("ragged chunk has too many windows"); return false; }
+  ch->windows = gid; ch->frame_bytes = dst + 256; ch->max_h = max_h;
+  ch->raw_bytes = job.host_imgs ? src : 0;
+  ch->host_contiguous = contiguous;
+  if (!ln->rag_frames.reserve(ch->frame_bytes)) return false;
+  if (job.host_imgs && !job.d_job_raw) {
+    if (!ln->rag_raw.reserve(src + 16)) return false;
+    if (!contiguous) {
+      if (!ln->h_raw.reserve(src + 16)) return false;
+      uint8_t* hr = (uint8_t*)ln->h_raw.p;
+      for (int i = 0; i < n; i++) std::memcpy(hr + rimg[i].src_off, job.host_imgs[i0 + i], (size_t)rimg[i].w * rimg[i].h);
+    }
+  }
+  // ---- block map and launches: one launch per LDS-tiled level (all of them in one when the chunk is small), one for
+  //      the big-window LDS levels, one for the global-pixel levels.  Inside a launch the tiles of 8 images interleave,
+  //      so that an image's tiles mostly land on one XCD's L2 (block b -> XCD b % 8). ----
+  ch->launches.clear();
+  int bi = 0;
+  auto emit_group = [&](int l, int g0) {
+    {
+      int tiles[8], seg[8], most = 0;
+      const int ge = std::min(n, g0 + 8);
+      for (int i = g0; i < ge; i++) {
+        tiles[i - g0] = 0; seg[i - g0] = -1;
+        if (l < job.n_lv[i0 + i]) {
+          const RagSeg& sg = segs[seg_first[i] + l];
+          tiles[i - g0] = (int)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
+          seg[i - g0] = seg_first[i] + l;
+          most = std::max(most, tiles[i - g0]);
+        }
+      }
+      for (int t = 0; t < most; t++)
+        for (int j = 0; j < ge - g0; j++)
+          if (t < tiles[j]) { blk[bi].seg = (uint32_t)seg[j]; blk[bi].tile = (uint32_t)t; bi++; }
+    }
+  };
+  auto emit_level = [&](int l) { for (int g0 = 0; g0 < n; g0 += 8) emit_group(l, g0); };
+  // pixel bytes / windows of the largest tile any image of the chunk cut from level l
+  int th_max[kMaxLevels], win_max[kMaxLevels];
+  for (int l = 0; l < nl; l++) { th_max[l] = 1; win_max[l] = 1; }
+  long long lds_blocks = 0;
+  for (int i = 0; i < n; i++)
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const RagSeg& sg = segs[seg_first[i] + l];
+      th_max[l] = std::max<int>(th_max[l], sg.th); win_max[l] = std::max<int>(win_max[l], (int)sg.tw * sg.th);
+      if (hp.lv[l].tiled == 1) lds_blocks += (long long)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
+    }
+  auto pix_of = [&](int l) { const DevLevel& d = hp.lv[l]; return d.pitch * (d.win + (th_max[l] - 1) * d.step); };
+  const bool small = lds_blocks <= c->kn.merge_blocks;
+  auto merged = [&](int mode) {
+    RaggedChunk::Launch L{mode, 256, 0, bi, 0};
+    // (group-major: the eight images of a group go through every level of the launch before the next group starts, so
+    // that they stay in L2 from level to level -- level-major order cost the global-pixel launch 47 %)
+    for (int g0 = 0; g0 < n; g0 += 8)
+      for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode) emit_group(l, g0);
+    for (int l = 0; l < nl; l++) if (hp.lv[l].tiled == mode && mode != 2) L.pix_bytes = std::max(L.pix_bytes, pix_of(l));
+    L.blk_n = bi - L.blk_base;
+    if (L.blk_n > 0) ch->launches.push_back(L);
+  };
+  if (small) merged(1);
+  else
+    for (int l = 0; l < nl; l++)
+      if (hp.lv[l].tiled == 1) {
+        RaggedChunk::Launch L{1, win_max[l] > 256 ? 512 : 256, pix_of(l), bi, 0};
+        emit_level(l);
+        L.blk_n = bi - L.blk_base;
+        if (L.blk_n > 0) ch->launches.push_back(L);
+      }
+  merged(3);
+  merged(2);
+  if (bi != ch->n_blk) { fail("internal: ragged block map size"); return false; }
+  return true;
+}
+
+// NMS, relocation and the jdaResult of every image of a ragged chunk (dets sorted by gid = image, level, y, x).
+static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets,
+                          const jdaDetectOptions* opt, jdaResult* out) {
+  const double t0 = now_ms();
+  const int L = c->hm.L, dim = c->hm.dim();
+  const bool do_nms = !opt || opt->nms;
+  const float overlap = opt ? opt->nms_overlap : 0.3f;
+  const DevPlan& hp = job.pe->hp;
+  std::vector<size_t> first(ch.n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < ch.n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] < ch.gid_base[f + 1]) i++;
+    }
+    first[ch.n] = i;
+  }
+  parallel_for(ch.n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    static thread_local std::vector<int> bb, keep;
+    bb.resize(cnt * 3);
+    const int W = ch.widths[f], H = ch.heights[f];
+    int l = 0;
+    uint32_t lbase = ch.gid_base[f];
+    int nx = 0, cntl = 0;
+    auto level_grid = [&](int lv) {
+      const DevLevel& d = hp.lv[lv];
+      nx = (W - d.win) / d.step + 1;
+      cntl = nx * ((H - d.win) / d.step + 1);
+    };
+    if (cnt) level_grid(0);
+    for (size_t i = 0; i < cnt; i++) {          // gids ascend: levels are walked once
+      const uint32_t g = dets.gid[a + i];
+      while (g >= lbase + (uint32_t)cntl) { lbase += (uint32_t)cntl; l++; level_grid(l); }
+      const uint32_t rel = g - lbase;
+      const DevLevel& d = hp.lv[l];
+      bb[3 * i] = (int)(rel % (uint32_t)nx) * d.step; bb[3 * i + 1] = (int)(rel / (uint32_t)nx) * d.step; bb[3 * i + 2] = d.win;
+    }
+    if (do_nms) nms_dialect_c_into(bb.data(), &dets.score[a], (int)cnt, overlap, &keep);
+    else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
+    jdaResult& r = out[f];
+    r.n = (int)keep.size(); r.landmark_n = L;
+    r.bboxes = (int*)std::malloc(std::max<size_t>(1, keep.size() * 3) * sizeof(int));
+    r.scores = (float*)std::malloc(std::max<size_t>(1, keep.size()) * sizeof(float));
+    r.shapes = (float*)std::malloc(std::max<size_t>(1, keep.size() * dim) * sizeof(float));
+    for (size_t i = 0; i < keep.size(); i++) {
+      const int k = keep[i];
+      std::memcpy(r.bboxes + 3 * i, &bb[3 * k], 3 * sizeof(int));
+      r.scores[i] = dets.score[a + k];
+      float* sh = r.shapes + i * dim;
+      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
+      relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
+    }
+  }, dets.gid.size() < 6000);
+  return now_ms() - t0;
+}
+
+static void add_stats(RunStats* a, const RunStats& b) {
+  a->carts += b.carts; a->out += b.out; a->carts_scan += b.carts_scan; a->carts_scan_glb += b.carts_scan_glb;
+  a->win_scan += b.win_scan; a->tail += b.tail; a->gpu_ms += b.gpu_ms; a->scan_ms += b.scan_ms;
+  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes;
+  for (int t = 0; t < kMaxStages; t++) a->stage_done[t] += b.stage_done[t];
+}
+
+// A ragged job: images of different sizes, in host memory (host_imgs) or on the device (d_base + d_offsets).
+int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                         const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
+                         const jdaDetectOptions* opt, jdaResult* out) {
+  const double t_call = now_ms();
+  if (!c || !out || n < 0 || !widths || !heights || (!host_imgs && !(d_base && d_offsets))) { fail("bad arguments"); return -1; }
+  const int L = c->hm.L;
+  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  if (n == 0) return 0;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+  }
+  RunStats total;
+  long long patch_n = 0;
+  double post_ms = 0;
+  jdaDetectOptions o1;
+  jdaStats st1;
+  auto finish = [&]() {
+    fill_stats(opt ? opt->stats : nullptr, total, patch_n, c->hm.T, c->hm.K, post_ms);
+    if (opt && opt->stats) opt->stats->call_ms = now_ms() - t_call;
+    return 0;
+  };
+  // per-image passes: models the ragged scan does not cover (multi-scale split nodes, levels without a tile), and
+  // cascades that reject so little that the dense kernel is the right tool
+  auto fallback = [&]() -> int {
+    for (int i = 0; i < n; i++) {
+      if (opt) o1 = *opt; else jdaDetectOptionsInit(&o1);
+      o1.stats = &st1; o1.hip_stream = nullptr;
+      const int W = widths[i], H = heights[i];
+      if (W <= 0 || H <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
+      int rc;
+      if (host_imgs) {
+        const unsigned char* one[1] = {host_imgs[i]};
+        rc = detect_c_device(c, nullptr, 0, 1, W, H, scale, min_size, max_size, th, &o1, out + i, one);
+      } else {
+        rc = detect_c_device(c, d_base + d_offsets[i], (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
+      }
+      if (rc != 0) return -1;
+      total.carts += st1.cart_total_n; total.out += st1.face_patch_n; total.carts_scan += st1.scan_cart_n;
+      total.win_scan += st1.scan_patch_n; total.tail += st1.handoff_n; total.gpu_ms += st1.gpu_ms; total.scan_ms += st1.scan_ms;
+      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes;
+      for (int t = 0; t < 16 && t < kMaxStages; t++) total.stage_done[t] += st1.stage_done_n[t];
+      patch_n += st1.patch_n; post_ms += st1.host_ms;
+    }
+    return finish();
+  };
+  if (c->hm.multi_scale()) return fallback();
+  RaggedJob job;
+  job.n = n; job.widths = widths; job.heights = heights; job.host_imgs = host_imgs; job.d_base = d_base; job.d_offsets = d_offsets;
+  const int prep = ragged_prepare(c, &job, scale, min_size, max_size);
+  PlanPin pin{c, job.pe};
+  if (prep < 0) return -1;
+  if (prep > 0) return fallback();
+  if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
+    for (int i = 0; i < n; i++) out[i] = empty_result(L);
+    return finish();
+  }
+
+  // ---- chunks: as many images as make ragged_chunk_windows windows (<= 65535 images, the queues pack the index
+  //      in 16 bits), walked through up to three lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
+  //      the host builds and issues chunk i and post-processes chunk i-3 ----
+  const DevPlan& hp = job.pe->hp;
+  // host images: uploaded by a helper thread, below (packed = every image right behind the one before in memory)
+  bool helper = host_imgs != nullptr && c->kn.ragged_uploader != 0, packed = helper;
+  std::vector<size_t> tight(helper ? (size_t)n + 1 : 0, 0);       // image i at tight[i] of the job's tight image buffer
+  for (int i = 0; i < n && helper; i++) {
+    if (!host_imgs[i] || widths[i] <= 0 || heights[i] <= 0) { helper = false; break; }
+    if (i > 0 && host_imgs[i] != host_imgs[i - 1] + (size_t)widths[i - 1] * heights[i - 1]) packed = false;
+    tight[i + 1] = tight[i] + (size_t)widths[i] * heights[i];
+  }
+  std::vector<int> starts;
+  {
+    long long wsum = 0; int cnt = 0;
+    const long long full = std::max<long long>(1, c->kn.ragged_chunk_windows);
+    long long target = full;
+    starts.push_back(0);
+    for (int i = 0; i < n; i++) {
+      long long wi = 0;
+      for (int l = 0; l < job.n_lv[i]; l++)
+        wi += (long long)((widths[i] - hp.lv[l].win) / hp.lv[l].step + 1) * ((heights[i] - hp.lv[l].win) / hp.lv[l].step + 1);
+      if (wi > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
+      // (a job whose pixels still have to come over the link starts with a quarter and a half chunk: the GPU has work
+      // after a quarter of a chunk's upload time instead of a whole one)
+      if (helper) target = starts.size() == 1 ? full / 4 : (starts.size() == 2 ? full / 2 : full);
+      if (cnt > 0 && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
+      wsum += wi; cnt++;
+    }
+    starts.push_back(n);
+  }
+  const int n_chunks = (int)starts.size() - 1;
+  const int lanes = std::min(std::min(kRaggedLanes, n_chunks), (int)std::max<long long>(1, c->kn.max_lanes));
+  struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
+  std::vector<Slot> slots(lanes);
+  LaneSet held(c);
+  if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0, true)) return -1;
+  bool ok = true;
+
+  // ---- host images, several chunks: a helper thread brings chunk after chunk into a buffer of the job (the first
+  //      lane's) on the cascador's upload stream and waits for each upload on the host; this thread builds tables,
+  //      enqueues passes and post-processes meanwhile, and only waits for a chunk's pixels right before it enqueues that
+  //      chunk.  (Issued here, every pageable upload blocked this thread for a millisecond, and staging 2,845 separate
+  //      arrays with one memcpy loop took longer than the GPU needs for the job.)  Images that lie back to back go up
+  //      straight from the caller's memory; separate arrays are gathered into two pinned buffers (the first two lanes')
+  //      by `ragged_stage_threads` copy threads, chunk k+1 while chunk k is on the link. ----
+  struct Uploader {
+    std::thread th;
+    std::mutex mu; std::condition_variable cv;
+    int ready = 0;                 // chunks [0, ready) are on the device
+    bool failed = false, stop = false;
+    std::string err;
+    ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
+  } up;
+  if (helper && n_chunks > 1 && lanes > 1 && held.v[0]->rag_raw.reserve(tight[n] + 16)) {
+    size_t most = 0;
+    job.raw_off.assign(n_chunks + 1, 0);
+    for (int k = 0; k < n_chunks; k++) { job.raw_off[k + 1] = tight[starts[k + 1]]; most = std::max(most, job.raw_off[k + 1] - job.raw_off[k]); }
+    if (packed || (held.v[0]->h_raw.reserve(most + 16) && held.v[1]->h_raw.reserve(most + 16))) {
+      job.d_job_raw = (uint8_t*)held.v[0]->rag_raw.p;
+      const int dev = c->device;
+      const int copy_threads = (int)std::max<long long>(1, std::min<long long>(16, c->kn.ragged_stage_threads));
+      uint8_t* stage[2] = {(uint8_t*)held.v[0]->h_raw.p, (uint8_t*)held.v[1]->h_raw.p};
+      auto uploader = [&, dev, copy_threads, stage]() {
+        bool good = hipSetDevice(dev) == hipSuccess;
+        auto publish = [&](int k_done) {
+          std::lock_guard<std::mutex> lk(up.mu);
+          if (good) up.ready = k_done;
+          else { up.failed = true; up.err = std::string("upload of a ragged chunk failed: ") + hipGetErrorString(hipGetLastError()); }
+          up.cv.notify_all();
+        };
+        auto drain = [&]() {          // the uploads queued so far are on the device
+          std::lock_guard<std::mutex> lk(c->h2d_mu);
+          good = good && hipStreamSynchronize(c->h2d) == hipSuccess;
+        };
+        for (int k = 0; k < n_chunks && good; k++) {
+          { std::lock_guard<std::mutex> lk(up.mu); if (up.stop) return; }
+          const double t_up = now_ms();
+          const size_t bytes = job.raw_off[k + 1] - job.raw_off[k];
+          const uint8_t* src = host_imgs[0] + job.raw_off[k];
+          if (!packed) {
+            // gather the chunk's images into pinned buffer k & 1 (its last upload, chunk k-2, was drained one round ago)
+            uint8_t* dst = stage[k & 1];
+            const int a = starts[k], b = starts[k + 1];
+            auto copy_range = [&](int i0, int i1) {
+              for (int i = i0; i < i1; i++) std::memcpy(dst + (tight[i] - tight[a]), host_imgs[i], tight[i + 1] - tight[i]);
+            };
+            std::vector<std::thread> ts;
+            int i0 = a;
+            for (int t = 0; t < copy_threads && i0 < b; t++) {
+              const size_t upto = tight[a] + bytes * (size_t)(t + 1) / (size_t)copy_threads;
+              int i1 = i0;
+              while (i1 < b && (tight[i1 + 1] <= upto || t == copy_threads - 1)) i1++;
+              if (i1 == i0) continue;
+              if (t == copy_threads - 1 || i1 == b) { copy_range(i0, b); i0 = b; }
+              else {
+                try { ts.emplace_back(copy_range, i0, i1); } catch (...) { copy_range(i0, i1); }   // (no thread to be had: copy here)
+                i0 = i1;
+              }
+            }
+            if (i0 < b) copy_range(i0, b);
+            for (auto& t : ts) t.join();
+            src = dst;
+          }
+          if (k > 0 && !packed) { drain(); publish(k); }           // chunk k-1 has arrived while this one was gathered
+          {
+            std::lock_guard<std::mutex> lk(c->h2d_mu);
+            if (!c->h2d) good = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking) == hipSuccess;
+            good = good && hipMemcpyAsync(job.d_job_raw + job.raw_off[k], src, bytes, hipMemcpyHostToDevice, c->h2d) == hipSuccess;
+          }
+          if (packed || k == n_chunks - 1) { drain(); publish(k + 1); }
+          if (c->kn.debug_times) fprintf(stderr, "[jda] ragged upload %d: %.3f MB at %.3f..%.3f ms\n", k, bytes / 1e6, t_up - t_call, now_ms() - t_call);
+        }
+        if (!good) publish(0);
+      };
+      try { up.th = std::thread(uploader); }
+      catch (...) { job.d_job_raw = nullptr; }          // (no thread to be had: the chunks upload themselves, as without a helper)
+    }
+  }
+  auto collect = [&](Slot& sl) -> bool {
+    Pass<float>& p = sl.pass;
+    sl.busy = false;
+    if (!p.after_tail() || !p.issue_counters() || !p.after_counters() || !p.collect()) return false;
+    float ms_scan = 0, ms_all = 0;
+    if (p.timed) {
+      (void)hipEventElapsedTime(&ms_scan, p.ev[1], p.ev[2]);
+      (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
+    }
+    sl.rs.scan_ms += ms_scan; sl.rs.gpu_ms += ms_all;
+    post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+    add_stats(&total, sl.rs);
+    patch_n += sl.ch.windows;
+    return true;
+  };
+  for (int ci = 0; ci < n_chunks && ok; ci++) {
+    const int lane = ci % lanes;
+    Slot& sl = slots[lane];
+    if (sl.busy && !collect(sl)) { ok = false; break; }
+    sl.dets = RawDets<float>(); sl.rs = RunStats(); sl.rs.timed = opt && opt->stats;
+    Lane* ln = held.v[lane];
+    if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
+    if (sl.ch.windows == 0) {                        // images too small for any window
+      post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+      continue;
+    }
+    // workspace: every lane holds a whole chunk (its previous chunk has been collected above)
+    {
+      const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(c->kn.ragged_chunk_windows, 0x7fffffffLL))
+                                       : (size_t)sl.ch.windows;
+      if (!ensure_workspace<float>(ln, want, false, c->hm.dim())) { ok = false; break; }
+    }
+    Pass<float>& p = sl.pass;
+    p = Pass<float>();
+    p.c = c; p.pe = job.pe; p.trace = nullptr; p.dets = &sl.dets; p.rs = &sl.rs; p.apply_th = true; p.th = th; p.multi = false;
+    p.solo = lanes == 1;
+    p.bind(ln, lane, nullptr);
+    p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
+    p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
+    p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
+    if (job.d_job_raw) {
+      const double t_w = now_ms();
+      std::unique_lock<std::mutex> lk(up.mu);
+      up.cv.wait(lk, [&] { return up.ready > ci || up.failed; });
+      if (c->kn.debug_times) fprintf(stderr, "[jda] ragged chunk %d: waited for its pixels %.3f..%.3f ms\n", ci, t_w - t_call, now_ms() - t_call);
+      if (up.failed) { fail(up.err); ok = false; break; }
+      sl.ch.d_uploaded = job.d_job_raw + job.raw_off[ci];
+    }
+    if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { ok = false; break; }
+    sl.busy = true;
+  }
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: all chunks issued at %.3f ms\n", now_ms() - t_call);
+  // drain in chunk order
+  for (int k = 0; k < lanes && ok; k++) {
+    Slot& sl = slots[(n_chunks + k) % lanes];
+    if (sl.busy && !collect(sl)) ok = false;
+  }
+  if (!ok) {
+    for (Lane* l : held.v) (void)hipStreamSynchronize(l->stream);
+    return -1;
+  }
+  for (int i = 0; i < n; i++)
+    if (!out[i].bboxes) out[i] = empty_result(L);     // (chunks fill every image; belt and braces)
+  return finish();
+}
+
+}  // namespace jda
