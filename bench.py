@@ -538,6 +538,21 @@ def main():
             torch.cuda.synchronize(); el2 = (time.perf_counter() - t0) / 3
             config2_live = {"ms_per_call": el2 * 1e3, "windows_per_s": st2["patch_n"] / el2, "gpu_ms": st2["gpu_ms"],
                             "windows_per_call": st2["patch_n"], "entry": "jdaDetectBatchDevice, synchronous (two sub-batch lanes)"}
+            # the same batches through submit / wait, two queued ahead of the one being collected (the host's sort + NMS of
+            # 15 k detections behind the other batches' kernels); warmed up in this mode: a ticket's lane holds a whole batch
+            def pipe2(k):
+                q = [c2.submit_batch_device(d2, 1.5) for _ in range(min(2, k))]
+                issued = len(q)
+                for _ in range(k):
+                    if issued < k:
+                        q.append(c2.submit_batch_device(d2, 1.5)); issued += 1
+                    c2.wait_batch(q.pop(0), keep_results=False)
+            pipe2(4)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            pipe2(8)
+            torch.cuda.synchronize(); elp = (time.perf_counter() - t0) / 8
+            config2_live["submit_wait_ms_per_call"] = elp * 1e3
+            config2_live["submit_wait_windows_per_s"] = st2["patch_n"] / elp
             c2.close(); del d2, f2
         except Exception as e:
             config2_live = {"error": repr(e)}

@@ -1,15 +1,15 @@
 """BASELINE.json configs[2] at its stated size: 256 x 1920x1080 frames resident in HBM, scale 1.5 (8 window sizes: 40, 60, 90,
 135, 202, 303, 455, 683 px; c/jda.c:331-333), shipped model dimensions in the cascade regime -- 32,089,600 windows per call.
    python tools/config2.py [sync|pipe] [steps]     (run it under rocprofv3 for the kernel trace / counter passes)
-sync: one jdaDetectBatchDevice call per step; pipe: jdaDetectBatchSubmit / Wait, two batches in flight (the host's sort + NMS
-of one batch behind the other's kernels).  Prints one JSON line."""
+sync: one jdaDetectBatchDevice call per step; pipe: jdaDetectBatchSubmit / Wait, CFG2_AHEAD (2) batches queued ahead (the host's
+sort + NMS of one batch behind the others' kernels).  Prints one JSON line."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from jda_amd import synth, api
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "sync"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n = int(os.environ.get("CFG2_BATCH", "256"))
 frames = synth.make_frames(n, 1920, 1080, seed=0)
 mp = os.path.join(synth.cache_dir(), "config2_5_540_27_4.model")
@@ -20,21 +20,23 @@ if not os.path.exists(mp):
 c = api.Cascador(mp)
 d = torch.from_numpy(frames).cuda()
 kw = dict(scale=1.5)
-for _ in range(2):
-    c.detect_batch_device(d, keep_results=False, **kw)
+ahead = int(os.environ.get("CFG2_AHEAD", "2"))      # pipe: batches queued ahead of the one being collected (three tickets exist)
+def run(steps, sts):
+    if mode == "pipe":
+        q = [c.submit_batch_device(d, stats=True, **kw) for _ in range(min(ahead, steps))]
+        issued = len(q)
+        for _ in range(steps):
+            if issued < steps:
+                q.append(c.submit_batch_device(d, stats=True, **kw)); issued += 1
+            _, st = c.wait_batch(q.pop(0), stats=True, keep_results=False); sts.append(st)
+    else:
+        for _ in range(steps):
+            _, st = c.detect_batch_device(d, keep_results=False, stats=True, **kw); sts.append(st)
+run(4, [])              # warm-up in the mode that is timed: a ticket's lane holds the whole batch (its workspace is allocated here)
 torch.cuda.synchronize()
 sts = []
 t0 = time.perf_counter()
-if mode == "pipe":
-    t = c.submit_batch_device(d, stats=True, **kw)
-    for _ in range(steps):
-        t2 = c.submit_batch_device(d, stats=True, **kw)
-        _, st = c.wait_batch(t, stats=True, keep_results=False); sts.append(st)
-        t = t2
-    c.wait_batch(t, keep_results=False)
-else:
-    for _ in range(steps):
-        _, st = c.detect_batch_device(d, keep_results=False, stats=True, **kw); sts.append(st)
+run(steps, sts)
 torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / steps
 st = sts[-1]
