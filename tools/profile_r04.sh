@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py --config2 > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --no-cpu --no-allpass > $O/bench_run2.json 2>> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
 V="python $R/tools/variants.py"
