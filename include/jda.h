@@ -244,8 +244,8 @@ JDA_API int jdaDetectBatchWait(void *cascador, int ticket, jdaStats *stats, jdaR
  * of its ticket (uploads of at least `h2d_min_bytes` go batch after batch through one upload stream of the cascador,
  * smaller ones on the ticket's own stream), then scanned like jdaDetectBatchSubmit.  The copy and the scan launches
  * are issued by a helper thread AFTER this call has returned, so in EVERY case -- pageable or pinned frames --
- * both the frame bytes and the frames[] pointer array itself must stay valid and unchanged until
- * jdaDetectBatchWait for this ticket has returned (do not reuse a capture buffer or a stack array before that).
+ * the frame BYTES must stay valid and unchanged until jdaDetectBatchWait for this ticket has returned (do not reuse
+ * a capture buffer before that).  The frames[] pointer array itself is copied by this call and may go at once.
  * A ticket lives for copy + kernels + host work while the copy alone takes about half of that: keep TWO
  * batches submitted ahead of the one being waited for and the PCIe link never idles. */
 JDA_API int jdaDetectBatchSubmitHost(void *cascador, const unsigned char *const *frames, int n,
