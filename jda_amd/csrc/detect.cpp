@@ -15,11 +15,11 @@ bool plan_c_call(Cascador* c, size_t stride, int width, int height, float scale,
   std::string err;
   if (!plan_dialect_c(width, height, scale, min_size, max_size, sp, &err)) { fail(err); return false; }
   if (stride < (size_t)width * height) { fail("frame_stride smaller than a frame"); return false; }
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::unique_lock<std::mutex> lk(c->mu);
   if (!ensure_device(c) || !upload_model<float>(c)) return false;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{width, height, JDA_DIALECT_C, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, 0ull};
-  return get_plan(c, key, *sp, JDA_DIALECT_C, pe);
+  return get_plan(c, lk, key, *sp, JDA_DIALECT_C, pe);
 }
 
 // Dialect CPP walks stages [0, current_stage_idx) and then carts [0, current_cart_idx] of the next one

@@ -243,6 +243,8 @@ struct PlanEntry {
   bool lm_ok = false;           // every tiled level's windows fit k_finish's stage-0 table ((x, y) in 11 bits each)
   bool any_untiled = false;
   size_t table_cap = 0;         // S0Node entries the table allocation holds (evicted allocations are recycled)
+  bool building = false;        // its device tables are being made by the thread that inserted it (outside Cascador::mu): others wait on plan_cv
+  bool failed = false;          // ... and that failed: waiters give up, the last one removes the entry
   bool dense_hint = false;      // the last pass on this plan kept most windows alive: go straight to k_stage
   // Hand-off queue length and detections of earlier passes on this plan, as fractions of the pass's windows (< 0:
   // none yet).  With a prediction the finishing launches are sized and queued right behind the scan, and a prefix
@@ -370,6 +372,7 @@ struct Cascador {
   hipStream_t h2d = nullptr;
   std::mutex h2d_mu;
   std::vector<std::unique_ptr<Lane>> lanes;
+  std::condition_variable plan_cv;           // a plan's device tables are ready (or failed), with mu
   std::condition_variable lane_cv;           // a lane was given back (callers beyond max_lanes wait here, with mu)
   ModelOnDevice<float> mf;
   ModelOnDevice<double> md;
@@ -448,9 +451,13 @@ template <typename Real> bool upload_model(Cascador* c);
 
 // ---------------------------------------------------------------- scan plans (plans.cpp)
 
-// The plan of (frame size, call parameters), built on first use.  Caller holds c->mu.  The plan comes back PINNED
-// (PlanEntry::pins): it is not evicted -- its device tables are not recycled -- until unpin_plan.
-bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out, bool ragged = false);
+// The plan of (frame size, call parameters), built on first use.  The caller holds c->mu through `lk`; a miss builds the
+// plan's device tables with the lock RELEASED (allocation, a blocking copy, a kernel and a stream wait: concurrent
+// callers on other frame sizes -- a per-image loop over differently sized images from several threads -- go on meanwhile,
+// callers on the same key wait for it).  The plan comes back PINNED (PlanEntry::pins): it is not evicted -- its device
+// tables are not recycled -- until unpin_plan.
+bool get_plan(Cascador* c, std::unique_lock<std::mutex>& lk, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out,
+              bool ragged = false);
 void unpin_plan(Cascador* c, PlanEntry* pe);
 // How k_scan covers every level of a plan (tile shapes, pixel modes, offsets of the stage-0 tables); ragged: see plans.cpp.
 void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool fast_scan, int real_bytes, PlanEntry* pe,

@@ -139,11 +139,22 @@ void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool
   }
 }
 
-// The plan of (frame size, call parameters), built on first use.  Caller holds c->mu.  The plan comes back PINNED
-// (PlanEntry::pins): it is not evicted -- its device tables are not recycled -- until unpin_plan.
-bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out, bool ragged) {
+// The plan of (frame size, call parameters), built on first use (host.h).
+bool get_plan(Cascador* c, std::unique_lock<std::mutex>& lk, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** out,
+              bool ragged) {
   auto it = c->plans.find(key);
-  if (it != c->plans.end()) { it->second.last_use = ++c->plan_clock; it->second.pins++; *out = &it->second; return true; }
+  if (it != c->plans.end()) {
+    PlanEntry& e = it->second;          // (map nodes do not move, and a pinned entry is not evicted)
+    e.last_use = ++c->plan_clock; e.pins++;
+    while (e.building) c->plan_cv.wait(lk);
+    if (e.failed) {
+      if (--e.pins == 0) c->plans.erase(key);
+      fail("the scan plan of this frame size could not be built (see the first caller's error)");
+      return false;
+    }
+    *out = &e;
+    return true;
+  }
   // bounded cache: a stream of differently sized images (FDDB) must not pile up device tables
   const size_t cap = (size_t)std::max<long long>(2, c->kn.plan_cache);
   while (c->plans.size() >= cap) {
@@ -174,14 +185,28 @@ bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, 
       entries += n0;
       if (pe.hp.lv[i].win > 2047) pe.lm_ok = false;      // (x, y) inside the window: 11 bits each
     }
+  S0Node* stale_table = nullptr;
   if (!c->plan_pool.empty()) {            // recycle an evicted plan's allocations
     Cascador::PlanBuffers b = c->plan_pool.back();
     c->plan_pool.pop_back();
     pe.dp = b.dp; pe.table = b.table; pe.table_cap = b.table_cap;
-    if (pe.table_cap < entries) { if (pe.table) (void)hipFree(pe.table); pe.table = nullptr; pe.table_cap = 0; }
+    if (pe.table_cap < entries) { stale_table = pe.table; pe.table = nullptr; pe.table_cap = 0; }      // (too small: freed below, without the lock)
   }
+  pe.last_use = ++c->plan_clock;
+  pe.pred_tail = c->pred_tail; pe.pred_out = c->pred_out;      // a new frame size starts from the cascador's last pass
+  pe.dense_hint = c->last_dense;
+  pe.pins = 1;
+  pe.building = true;
+  const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
+  const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
+  const int K = c->hm.K, node_n = c->hm.node_n();
+  hipStream_t aux = c->aux;
+  PlanEntry& e = c->plans.emplace(key, std::move(pe)).first->second;
+  // ---- device side, without the lock: only this thread touches the entry's device pointers while `building` ----
+  lk.unlock();
   // (a failure below must not lose the device allocations: whatever the entry holds goes back to the pool)
-  auto build = [&]() -> bool {
+  if (stale_table) (void)hipFree(stale_table);
+  auto build = [&](PlanEntry& pe) -> bool {
     if (!pe.dp) JDA_HIP(hipMalloc((void**)&pe.dp, sizeof(DevPlan)));
     JDA_HIP(hipMemcpy(pe.dp, &pe.hp, sizeof(DevPlan), hipMemcpyHostToDevice));
     if (entries) {
@@ -189,24 +214,25 @@ bool get_plan(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, 
         pe.table_cap = std::max(entries, (size_t)16 * n0);      // room for 16 levels: most recycled tables fit the next plan
         JDA_HIP(hipMalloc((void**)&pe.table, 2 * pe.table_cap * sizeof(S0Node)));   // cart-major tables + their level-major copy
       }
-      const void* nodes = dialect == JDA_DIALECT_C ? c->mf.m.nodes : c->md.m.nodes;
-      const void* ms = dialect == JDA_DIALECT_C ? (const void*)c->mf.m.mean_shape : (const void*)c->md.m.mean_shape;
-      JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, c->hm.K, c->hm.node_n(), pe.table, pe.table + pe.table_cap, c->aux));
+      JDA_HIP(launch_prep_stage0(dialect, pe.dp, pe.hp, nodes, ms, K, node_n, pe.table, pe.table + pe.table_cap, aux));
       // the scans that read the table run on the lanes' streams
-      JDA_HIP(hipStreamSynchronize(c->aux));
+      JDA_HIP(hipStreamSynchronize(aux));
     }
     return true;
   };
-  if (!build()) {
-    if (pe.dp || pe.table) c->plan_pool.push_back({pe.dp, pe.table, pe.table ? pe.table_cap : 0});
+  const bool ok = build(e);
+  lk.lock();
+  e.building = false;
+  if (!ok) {
+    if (e.dp || e.table) c->plan_pool.push_back({e.dp, e.table, e.table ? e.table_cap : 0});
+    e.dp = nullptr; e.table = nullptr; e.table_cap = 0;
+    e.failed = true;
+    if (--e.pins == 0) c->plans.erase(key);       // (callers that wait for this plan see `failed` and remove it when the last has left)
+    c->plan_cv.notify_all();
     return false;
   }
-  pe.last_use = ++c->plan_clock;
-  pe.pred_tail = c->pred_tail; pe.pred_out = c->pred_out;      // a new frame size starts from the cascador's last pass
-  pe.dense_hint = c->last_dense;
-  pe.pins = 1;
-  auto ins = c->plans.emplace(key, std::move(pe));
-  *out = &ins.first->second;
+  c->plan_cv.notify_all();
+  *out = &e;
   return true;
 }
 

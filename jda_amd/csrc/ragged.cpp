@@ -78,8 +78,8 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
   job->levels.windows = 0;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{pitch, nl, 3 /* ragged, dialect C */, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, h};
-  std::lock_guard<std::mutex> lk(c->mu);
-  if (!get_plan(c, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
+  std::unique_lock<std::mutex> lk(c->mu);
+  if (!get_plan(c, lk, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
   if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
   if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
   for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;

@@ -190,9 +190,9 @@ struct PlanPin {           // unpins on scope exit
 // The shared part of an entry, under c->mu: device, the model of dialect Real on the device, the plan (pinned).
 template <typename Real>
 static bool begin_call(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** pe) {
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::unique_lock<std::mutex> lk(c->mu);
   if (!ensure_device(c) || !upload_model<Real>(c)) return false;
-  return get_plan(c, key, sp, dialect, pe);
+  return get_plan(c, lk, key, sp, dialect, pe);
 }
 
 

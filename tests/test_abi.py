@@ -128,7 +128,7 @@ def test_options_round_trip_and_start_from_the_environment(built, model_file, mo
     from jda_amd import api
     p, _ = model_file((2, 8, 5, 3), 8, seed=1)
     documented = {"handoff": 128, "lanes": 2, "dense": 1, "plan_cache": 64, "predict": 1, "wide_max": 1024,
-                  "wide_busy_max": 2, "ragged_chunk_windows": 6000000, "ragged_tile_grow_pct": 150, "filter0": 1,
+                  "wide_busy_max": 2, "ragged_chunk_windows": 4000000, "ragged_tile_grow_pct": 150, "filter0": 1,
                   "kernel_d2h": 1, "h2d_stream": 1, "h2d_min_bytes": 8 << 20, "ragged_uploader": 1,
                   "ragged_stage_threads": 4}
     for k in list(os.environ):

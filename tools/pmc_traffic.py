@@ -37,13 +37,17 @@ def group(name):
     return None
 
 
+DEVICE_HEADERS = ("kernels.h", "kernels_common.h", "finish_common.h", "scan_walk.h")
+
+
 def kernel_sources_sha256():
-    """Hash of the device code (csrc/*.hip, *.h) the counters were taken on: bench.py compares it with the sources it
-    runs on, so a traffic figure echoed from a stale file is flagged in the line."""
+    """Hash of the device code the counters were taken on (csrc/*.hip and the headers they include; the host-side
+    headers of the same directory are not device code): bench.py compares it with the sources it runs on, so a traffic
+    figure echoed from a stale file is flagged in the line."""
     import glob, hashlib, os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jda_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + [os.path.join(root, x) for x in DEVICE_HEADERS]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()
 
