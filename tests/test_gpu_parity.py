@@ -958,6 +958,56 @@ def test_wide_finish_equals_wave_finish_and_the_oracle(built, gpu, model_file, d
             assert same(a[k], b[k]), ("cpp", k)
 
 
+@pytest.mark.parametrize("dims,kw", [((2, 64, 68, 6), dict(cart_th=-0.7)), ((3, 40, 9, 7), dict(cart_th=-0.9, norm_every=7)),
+                                     ((3, 70, 27, 4), dict(cart_th=-0.8))])
+def test_finish_table_layouts_do_not_change_results(built, gpu, model_file, monkeypatch, dims, kw):
+    """k_finish reads the regression weights from a copy whose rows start on 128-byte lines (w_pad), with non-temporal
+    loads where a stage's rows exceed w_stream_mb, and the last levels of trees with five or more node levels from
+    records grouped per path (lm_deep; jda_amd/csrc/kernels.h: lm_deep_index).  None of it may change a bit: per-window
+    trace and detections under every combination equal the plain layouts' and the oracle's (c/jda.c:357-426), in both
+    dialects (the options are read when a cascador is created)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file(dims, 8, seed=93, **kw)
+    frames = synth.make_frames(2, 260, 190, seed=94)
+    monkeypatch.setenv("JDA_W_PAD", "0"); monkeypatch.setenv("JDA_LM_DEEP", "0"); monkeypatch.setenv("JDA_W_STREAM_MB", "0")
+    plain = api.Cascador(p)
+    plain.set_option("wide_max", 0)            # the wave-per-window kernel is the one that reads these tables
+    _compare_trace(plain, Oracle(p), frames[:1])
+    want_t, want_d, want_c = plain.trace(frames), plain.detect_batch(frames), plain.trace_cpp(frames, 20, 5, 1.2)
+    for pad, deep in ((1, 1), (1, 0), (0, 1)):
+        monkeypatch.setenv("JDA_W_PAD", str(pad)); monkeypatch.setenv("JDA_LM_DEEP", str(deep))
+        c = api.Cascador(p)
+        c.set_option("wide_max", 0)
+        t, d, tc = c.trace(frames), c.detect_batch(frames), c.trace_cpp(frames, 20, 5, 1.2)
+        for k in want_t:
+            assert same(want_t[k], t[k]), (pad, deep, k)
+        for a, b in zip(want_d, d):
+            _compare_detect(a, b)
+        for k in want_c:
+            assert same(want_c[k], tc[k]), (pad, deep, "cpp", k)
+        c.close()
+    plain.close()
+
+
+def test_streamed_weight_rows_give_the_same_detections(built, gpu, model_file, monkeypatch):
+    """The non-temporal form of the row loads (STREAM instantiation of k_finish) on a model small enough to check against
+    the oracle: forced by a threshold of one megabyte (300 carts x 32 leaves x 640-byte rows = 6.1 MB per stage)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file((2, 300, 68, 6), 8, seed=95, cart_th=-0.6)
+    frames = synth.make_frames(2, 200, 150, seed=96)
+    monkeypatch.setenv("JDA_W_STREAM_MB", "1")            # 300 x 32 leaves x 640 B = 6.1 MB per stage > 1 MB
+    c = api.Cascador(p)
+    c.set_option("wide_max", 0)
+    o = Oracle(p)
+    got = c.detect_batch(frames)
+    for i in range(len(frames)):
+        _compare_detect(o.detect(frames[i]), got[i])
+    assert sum(len(g["scores"]) for g in got) > 0
+    c.close()
+
+
 # ---------------------------------------------------------------- submit / wait
 
 def test_submit_wait_gives_the_synchronous_results(built, gpu, model_file):
