@@ -78,6 +78,10 @@ int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
     d_frames = (const uint8_t*)lanes.v[0]->frames.p;
     host.ptrs = host_frames; host.fbytes = (size_t)width * height;
   }
+  // per-frame sort, NMS and relocation on the device for batches (k_post; the host form stays for single frames, for
+  // what the kernel declines, and is what it is tested against)
+  host.device_post = c->kn.device_post >= 1 && n >= c->kn.device_post_min_frames;
+  host.nms = !opt || opt->nms; host.nms_overlap = opt ? opt->nms_overlap : 0.3f;
   RawDets<float> dets;
   RunStats rs;
   rs.timed = opt && opt->stats;

@@ -117,6 +117,8 @@ inline long long env_ll(const char* name, long long dflt) {
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
+  X(device_post, "JDA_DEVICE_POST", 1)      /* per-frame sort, NMS and relocation of a dialect-C batch on the device (k_post) instead of on the host (0): synchronous batch calls and tickets */ \
+  X(device_post_min_frames, "JDA_DEVICE_POST_MIN_FRAMES", 16) /* ... for batches of at least this many frames */ \
   X(w_pad, "JDA_W_PAD", 1)                  /* k_finish gathers its weight rows from a copy whose rows start on 128-byte lines (0: from the tight table) */ \
   X(lm_deep, "JDA_LM_DEEP", 1)              /* trees of five or more node levels: k_finish reads the levels from the fourth on as whole records grouped per path (0: every level from the level-major split copy) */ \
   X(w_stream_mb, "JDA_W_STREAM_MB", 8)      /* ... with non-temporal loads when one stage's rows exceed this many MB (they would only push the stage's nodes out of L2); 0: never */ \
@@ -305,6 +307,7 @@ struct Lane {
   hipEvent_t ev_h2d[2] = {};                 // staging buffer free / frames uploaded (Cascador::h2d)
   unsigned long long* h_cnt = nullptr;       // pinned copy of the work counters
   HostPinned h_gid, h_score, h_shape;        // detections of the lane's pass
+  HostPinned h_pn, h_pbb, h_psc, h_psh;      // ... post-processed on the device (k_post): per-frame count / first row (+ flag), boxes, scores, shapes
   DevBuf ws;                                 // per-window arrays, carved for one dialect at a time
   size_t cap = 0; bool trace = false; int dim = 0, real_bytes = 0;
   WorkT<float> wf{};
@@ -334,6 +337,7 @@ struct Lane {
   void trim() {
     ws.release(); frames.release(); pyr.release(); rag_frames.release(); rag_raw.release(); rag_tab.release();
     h_gid.release(); h_score.release(); h_shape.release(); h_tab.release(); h_raw.release();
+    h_pn.release(); h_pbb.release(); h_psc.release(); h_psh.release();
     cap = 0; trace = false; dim = 0; real_bytes = 0;
     wf = WorkT<float>{}; wd = WorkT<double>{};
   }
@@ -476,6 +480,11 @@ struct RawDets {               // survivors of a batch, sorted by gid (= frame, 
   std::vector<uint32_t> gid;
   std::vector<Real> score;
   std::vector<Real> shape;     // [n][dim]
+  // frames whose pass was post-processed on the device (k_post; dialect C only): p_n[f] >= 0 detections kept after NMS,
+  // already relocated, rows [p_first[f], p_first[f] + p_n[f]) of p_bb (x, y, size) / p_sc / p_sh; p_n[f] < 0: the frame's
+  // detections are in the raw lists above.  Empty unless the caller asked for it (HostFrames::device_post)
+  std::vector<int> p_n, p_first, p_bb;
+  std::vector<Real> p_sc, p_sh;
 };
 
 template <typename Real>

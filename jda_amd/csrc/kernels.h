@@ -190,7 +190,8 @@ enum Counter : int {
   kCntCartsScanGlb = kMaxStages + 6,  // carts evaluated inside k_scan's global-pixel launches
   kCntTotal = kMaxStages + 7,
   // spare words of a shard: [kCntTotal, kCntMidScan) deal k_scan_p's tiles (PScanCfg::dyn_slot, shards 0..7)
-  kCntMidScan = kCntStride - 1     // windows k_scan_p put into the mid queue itself (they count as handed off)
+  kCntMidScan = kCntStride - 1,    // windows k_scan_p put into the mid queue itself (they count as handed off)
+  kCntPostCursor = kCntTotal       // shard 8 only: rows k_post has allotted (shards 0..7 use this word to deal tiles)
 };
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
@@ -305,6 +306,19 @@ size_t stage_lds_bytes(int dim, int node_n, int leaf_n, int real_bytes);
 // Device -> mapped pinned host memory by a kernel on `stream` (instead of the copy engine): up to 4 segments, 16-byte
 // aligned.
 hipError_t launch_copy_out(const void* const* src, void* const* dst, const size_t* bytes, int n, hipStream_t stream);
+
+// Per-frame post-processing of a dialect-C pass on the device (k_post.hip): scan order, score order, NMS, relocation --
+// one workgroup per frame, results into mapped pinned host memory.  n[f] = detections kept for frame f of the pass
+// (-1: the kernel declined, flag[0] = 1: the host post-processes the pass from its raw detections), first[f] = their first
+// row in bb (x, y, size) / score / shape (dim floats, relocated); rows are allotted from *cursor (device, zeroed
+// with the counters).
+struct PostOut {
+  int* n; int* first; int* bb; float* score; float* shape; int* flag;
+  unsigned long long* cursor;
+  unsigned cap_rows;
+};
+hipError_t launch_post(const DevPlan* d_plan, const WorkT<float>& w, int dim, int n_frames, bool do_nms, float overlap,
+                       const PostOut& o, hipStream_t stream);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

@@ -38,6 +38,8 @@ struct Pass {
   bool predicted = false;          // the finishing launches were sized from PlanEntry::pred_tail, no host wait in between
   bool counters_issued = false, results_pending = false;
   int p_launches = 0;              // k_scan_p launches of this pass so far (each deals its tiles from its own counter words)
+  bool want_post = false, post_nms = true; float post_overlap = 0.3f;   // the caller takes device-post-processed frames (RawDets::p_*)
+  bool post_issued = false, posted = false; size_t post_cap = 0;         // k_post queued for this pass / its results are good
   bool mid_direct = false;         // a scan launch of this pass put stage-0 survivors into the mid queue itself (k_scan_p up to cart K)
   long long n_tail = -1;
   size_t n_out = 0, out_copied = 0;   // detections of the pass / how many of them are already on their way to the host
@@ -327,6 +329,11 @@ struct Pass {
       predicted = true;
       const double po = pred_out >= 0 ? pred_out : 0.0;
       const size_t to = std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64);
+      if constexpr (sizeof(Real) == 4) {
+        // dialect C, uniform batch: scan order, score order, NMS and relocation per frame on the device, results straight
+        // into pinned memory (k_post); a frame or a row count it declines sends the pass through the host path below
+        if (want_post && kn().kernel_d2h && dets && to > 0 && !rag && !want_trace() && !dense) return issue_post(to) && issue_counters();
+      }
       if (kn().kernel_d2h && dets && to > 0) return issue_results(0, to, true);      // counters + prefix in one launch
       return issue_counters() && issue_results(0, to);
     }
@@ -462,6 +469,28 @@ struct Pass {
     return true;
   }
 
+  // k_post for this pass: at most `rows` detections kept in all
+  bool issue_post(size_t rows) {
+    if constexpr (sizeof(Real) == 4) {
+      const int dim = hm().dim();
+      if (!ln->h_pn.reserve(((size_t)2 * nf + 4) * sizeof(int)) || !ln->h_pbb.reserve(rows * 3 * sizeof(int)) ||
+          !ln->h_psc.reserve(rows * sizeof(float)) || !ln->h_psh.reserve(rows * dim * sizeof(float))) return false;
+      int* pn = (int*)ln->h_pn.p;
+      pn[2 * nf] = 0;                         // the kernel's "declined" flag (the lane's last pass has been collected)
+      PostOut o;
+      o.n = pn; o.first = pn + nf; o.flag = pn + 2 * nf;
+      o.bb = (int*)ln->h_pbb.p; o.score = (float*)ln->h_psc.p; o.shape = (float*)ln->h_psh.p;
+      o.cursor = w.counters + (size_t)8 * kCntStride + kCntPostCursor;
+      o.cap_rows = (unsigned)std::min<size_t>(rows, 0x7fffffffu);
+      JDA_HIP(launch_post(pe->dp, w, dim, nf, post_nms, post_overlap, o, st));
+      post_issued = true; post_cap = rows;
+      return true;
+    } else {
+      (void)rows;
+      return false;
+    }
+  }
+
   // detections [from, to) of the device list -> the lane's pinned host arrays (asynchronous)
   bool issue_results(size_t from, size_t to, bool with_counters = false) {
     const int dim = hm().dim();
@@ -531,6 +560,10 @@ struct Pass {
       }
       c->last_dense = pe->dense_hint;
     }
+    if (post_issued) {
+      posted = ((const int*)ln->h_pn.p)[2 * nf] == 0;
+      if (posted) return true;                 // (nothing else to fetch: the frames' results are in pinned memory)
+    }
     if (n_out > out_copied && !issue_results(out_copied, n_out)) return false;   // the prediction fell short (or there was none)
     return true;
   }
@@ -540,7 +573,20 @@ struct Pass {
     const int dim = hm().dim();
     const long long wpf = rag ? 0 : pe->sp.windows;
     const double t_dbg = now_ms();
-    if (n_out && dets) {
+    if (posted && dets) {
+      // the frames of this pass as k_post left them: rows appended, first rows rebased
+      const int* pn = (const int*)ln->h_pn.p;
+      size_t rows = 0;
+      for (int f = 0; f < nf; f++) rows = std::max(rows, (size_t)pn[nf + f] + (size_t)std::max(0, pn[f]));
+      const size_t o0 = dets->p_sc.size();
+      dets->p_bb.resize((o0 + rows) * 3); dets->p_sc.resize(o0 + rows); dets->p_sh.resize((o0 + rows) * dim);
+      if (rows) {
+        std::memcpy(&dets->p_bb[o0 * 3], ln->h_pbb.p, rows * 3 * sizeof(int));
+        std::memcpy(&dets->p_sc[o0], ln->h_psc.p, rows * sizeof(Real));
+        std::memcpy(&dets->p_sh[o0 * dim], ln->h_psh.p, rows * dim * sizeof(Real));
+      }
+      for (int f = 0; f < nf; f++) { dets->p_n[(size_t)f0 + f] = pn[f]; dets->p_first[(size_t)f0 + f] = (int)o0 + pn[nf + f]; }
+    } else if (n_out && dets) {
       if (results_pending) JDA_HIP(hipStreamSynchronize(st));
       results_pending = false;
       if (kn().debug_times) fprintf(stderr, "[jda] lane %d: results D2H wait %.3f ms (%zu detections)\n", lane, now_ms() - t_dbg, n_out);

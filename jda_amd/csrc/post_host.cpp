@@ -180,7 +180,23 @@ double post_c(Cascador* c, const ScanPlan& sp, const RawDets<float>& dets, int n
     }
     first[n] = i;
   }
+  const bool some_posted = dets.p_n.size() == (size_t)n;
   parallel_for(n, [&](int f) {
+    if (some_posted && dets.p_n[f] >= 0) {
+      // this frame's pass was post-processed on the device (k_post): kept detections, relocated, in scan order
+      const size_t k = (size_t)dets.p_n[f], r0 = (size_t)dets.p_first[f];
+      jdaResult& r = out[f];
+      r.n = (int)k; r.landmark_n = L;
+      r.bboxes = (int*)std::malloc(std::max<size_t>(1, k * 3) * sizeof(int));
+      r.scores = (float*)std::malloc(std::max<size_t>(1, k) * sizeof(float));
+      r.shapes = (float*)std::malloc(std::max<size_t>(1, k * dim) * sizeof(float));
+      if (k) {
+        std::memcpy(r.bboxes, &dets.p_bb[r0 * 3], k * 3 * sizeof(int));
+        std::memcpy(r.scores, &dets.p_sc[r0], k * sizeof(float));
+        std::memcpy(r.shapes, &dets.p_sh[r0 * dim], k * dim * sizeof(float));
+      }
+      return;
+    }
     const size_t a = first[f], cnt = first[f + 1] - a;
     static thread_local std::vector<int> bb, keep;          // per-frame scratch, grown once per thread
     bb.resize(cnt * 3);

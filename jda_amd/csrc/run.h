@@ -16,6 +16,9 @@ inline bool jda_gid_overflow(const Knobs& kn, long long n, long long wpf) {
 struct HostFrames {
   const unsigned char* const* ptrs = nullptr;
   size_t fbytes = 0;
+  // dialect C: the passes may post-process their frames on the device (RawDets::p_*), with these NMS settings
+  bool device_post = false, nms = true;
+  float nms_overlap = 0.3f;
 };
 
 // Runs the device pipeline over n frames in device memory (d_frames; with host.ptrs set they are copied there first,
@@ -122,6 +125,7 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
     for (int l = 1; l < lanes; l++) JDA_HIP(hipStreamWaitEvent(lanes_held.v[l]->stream, lanes_held.v[0]->ev_user, 0));
   }
 
+  if (host.device_post && dets) { dets->p_n.assign((size_t)n, -1); dets->p_first.assign((size_t)n, 0); }
   std::vector<Pass<Real>> ps;
   for (int f0 = 0; f0 < n;) {
     // one round: up to `lanes` sub-batches in flight, their steps interleaved
@@ -130,6 +134,7 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
       Pass<Real> p;
       p.c = c; p.pe = pe; p.trace = trace; p.dets = dets; p.rs = rs; p.apply_th = apply_th; p.th = th; p.multi = multi;
       p.solo = lanes == 1;
+      p.want_post = host.device_post; p.post_nms = host.nms; p.post_overlap = host.nms_overlap;
       p.bind(lanes_held.v[l], l, l == 0 ? user_stream : nullptr);
       p.cap = cap;
       p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);

@@ -51,6 +51,10 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
   p = Pass<float>();
   p.c = c; p.pe = pb.pe; p.trace = nullptr; p.dets = &pb.dets; p.rs = &pb.rs; p.apply_th = true; p.th = th; p.multi = false;
   p.solo = true;
+  if (c->kn.device_post >= 1 && n >= c->kn.device_post_min_frames) {      // (k_post: even with the host work hidden behind the other tickets' kernels, +1 %)
+    p.want_post = true; p.post_nms = !opt || opt->nms; p.post_overlap = opt ? opt->nms_overlap : 0.3f;
+    pb.dets.p_n.assign((size_t)n, -1); pb.dets.p_first.assign((size_t)n, 0);
+  }
   p.bind(ln, 0, nullptr);
   p.f0 = 0; p.nf = n;
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
