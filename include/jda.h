@@ -138,6 +138,8 @@ JDA_API int jdaSetDevice(void *cascador, int device);
  *   "workspace_mb"  device workspace budget of a call in MiB; larger batches run in several passes (24576)
  *   "plan_cache"    scan plans (one per frame size and call parameters) kept per cascador (64)
  *   "predict"       size the finishing launches from the previous pass instead of a host round trip (1)
+ *   "scan_p"        the persistent form of the stage-0 scan for large uniform batches: 0 off, 1 where it suits, 2 wherever it fits (1)
+ *   "device_post"   per-frame sort, NMS and relocation of batches of 16 frames or more on the device instead of on the host (1)
  * (the other keys of DESIGN.md section 8 are accepted as well; they are experiment switches).
  * Returns 0, or -1 for an unknown key / a running call or pending batch.  jdaGetOption returns the value (-1: unknown key). */
 JDA_API int jdaSetOption(void *cascador, const char *key, long long value);
