@@ -520,7 +520,7 @@ struct RaggedChunk {
   struct Launch { int mode, block, pix_bytes, blk_base, blk_n; };
   std::vector<Launch> launches;
   int n_segs = 0, n_blk = 0;
-  size_t off_segs = 0, off_blk = 0, off_imgoff = 0, off_rimg = 0, table_bytes = 0;   // layout of the table buffer
+  size_t off_segs = 0, off_blk = 0, off_imgoff = 0, off_rimg = 0, off_gidbase = 0, table_bytes = 0;   // layout of the table buffer
   const unsigned char* const* host_imgs = nullptr;   // the chunk's images in host memory (tight), or
   const uint8_t* d_raw = nullptr;                    // the base their RagImg::src_off refer to on the device
   const int* widths = nullptr; const int* heights = nullptr;      // of the chunk's images

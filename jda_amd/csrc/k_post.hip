@@ -16,8 +16,10 @@ constexpr int kPostLiteralMax = 256;    // ... and of those, how many it orders 
 
 }  // namespace
 
+// rag_gid / rag_img (ragged pass, else null): first gid of every image of the pass (n + 1 entries; an image's gids are
+// consecutive: level, y, x) and the images' sizes -- its window grid per level is derived like post_ragged does.
 __global__ __launch_bounds__(256) void k_post(const DevPlan* __restrict__ plan, WorkT<float> w, int dim, int do_nms, float overlap,
-                                               PostOut o) {
+                                               PostOut o, const uint32_t* __restrict__ rag_gid, const RagImg* __restrict__ rag_img) {
   __shared__ unsigned long long key[kPostMaxDets];      // gid << 32 | position in the pass's detection list
   __shared__ float sc[kPostMaxDets];
   __shared__ int bx[kPostMaxDets], by[kPostMaxDets], bs[kPostMaxDets];
@@ -27,12 +29,13 @@ __global__ __launch_bounds__(256) void k_post(const DevPlan* __restrict__ plan, 
   const int frame = (int)blockIdx.x, tid = (int)threadIdx.x;
   const unsigned n_out = (unsigned)min(w.counters[kCntOut], (unsigned long long)w.cap);
   const unsigned wpf = (unsigned)plan->windows;
+  const unsigned g_lo = rag_gid ? rag_gid[frame] : 0u, g_hi = rag_gid ? rag_gid[frame + 1] : 0u;
   if (tid == 0) { s_n = 0; s_over = 0; s_lit = 0; s_kept = 0; s_base = 0; }
   __syncthreads();
   // ---- this frame's detections out of the pass's list (a few thousand entries, read by every workgroup from L2) ----
   for (unsigned i = (unsigned)tid; i < n_out; i += 256u) {
     const unsigned g = w.out_gid[i];
-    if (g / wpf == (unsigned)frame) {
+    if (rag_gid ? (g >= g_lo && g < g_hi) : (g / wpf == (unsigned)frame)) {
       const int p = atomicAdd(&s_n, 1);
       if (p < kPostMaxDets) key[p] = ((unsigned long long)g << 32) | (unsigned long long)i;
       else s_over = 1;
@@ -64,13 +67,30 @@ __global__ __launch_bounds__(256) void k_post(const DevPlan* __restrict__ plan, 
   // ---- window and score of every detection (post_host.cpp: locate) ----
   for (int i = tid; i < n; i += 256) {
     const unsigned g = (unsigned)(key[i] >> 32), idx = (unsigned)(key[i] & 0xffffffffu);
-    const int wid = (int)(g - (unsigned)frame * wpf);
-    int l = 0;
-    for (int q = 1; q < plan->n_levels; q++)
-      if (wid >= plan->lv[q].base) l = q;
-    const DevLevel lv = plan->lv[l];
-    const int rel = wid - lv.base;
-    by[i] = (rel / lv.nx) * lv.step; bx[i] = (rel % lv.nx) * lv.step; bs[i] = lv.win;
+    if (rag_gid) {
+      // the image's own grids, level after level (ragged.cpp: post_ragged)
+      const int W = rag_img[frame].w, H = rag_img[frame].h;
+      unsigned lbase = g_lo;
+      int l = 0, nx = 1;
+      for (;; l++) {
+        const DevLevel lv = plan->lv[l];
+        nx = (W - lv.win) / lv.step + 1;
+        const unsigned cntl = (unsigned)nx * (unsigned)((H - lv.win) / lv.step + 1);
+        if (g < lbase + cntl || l + 1 >= plan->n_levels) break;
+        lbase += cntl;
+      }
+      const DevLevel lv = plan->lv[l];
+      const unsigned rel = g - lbase;
+      bx[i] = (int)(rel % (unsigned)nx) * lv.step; by[i] = (int)(rel / (unsigned)nx) * lv.step; bs[i] = lv.win;
+    } else {
+      const int wid = (int)(g - (unsigned)frame * wpf);
+      int l = 0;
+      for (int q = 1; q < plan->n_levels; q++)
+        if (wid >= plan->lv[q].base) l = q;
+      const DevLevel lv = plan->lv[l];
+      const int rel = wid - lv.base;
+      by[i] = (rel / lv.nx) * lv.step; bx[i] = (rel % lv.nx) * lv.step; bs[i] = lv.win;
+    }
     sc[i] = w.out_score[idx];
     keep[i] = 1;
   }
@@ -160,9 +180,9 @@ __global__ __launch_bounds__(256) void k_post(const DevPlan* __restrict__ plan, 
 }
 
 hipError_t launch_post(const DevPlan* d_plan, const WorkT<float>& w, int dim, int n_frames, bool do_nms, float overlap,
-                       const PostOut& o, hipStream_t stream) {
+                       const PostOut& o, hipStream_t stream, const uint32_t* rag_gid, const RagImg* rag_img) {
   if (n_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_post, dim3((unsigned)n_frames), dim3(256), 0, stream, d_plan, w, dim, do_nms ? 1 : 0, overlap, o);
+  hipLaunchKernelGGL(k_post, dim3((unsigned)n_frames), dim3(256), 0, stream, d_plan, w, dim, do_nms ? 1 : 0, overlap, o, rag_gid, rag_img);
   return hipGetLastError();
 }
 

@@ -317,8 +317,9 @@ struct PostOut {
   unsigned long long* cursor;
   unsigned cap_rows;
 };
+// rag_gid / rag_img: a ragged pass (first gid of every image, n + 1 entries; the images' sizes), else null.
 hipError_t launch_post(const DevPlan* d_plan, const WorkT<float>& w, int dim, int n_frames, bool do_nms, float overlap,
-                       const PostOut& o, hipStream_t stream);
+                       const PostOut& o, hipStream_t stream, const uint32_t* rag_gid = nullptr, const RagImg* rag_img = nullptr);
 
 template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,

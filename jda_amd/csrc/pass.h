@@ -332,7 +332,7 @@ struct Pass {
       if constexpr (sizeof(Real) == 4) {
         // dialect C, uniform batch: scan order, score order, NMS and relocation per frame on the device, results straight
         // into pinned memory (k_post); a frame or a row count it declines sends the pass through the host path below
-        if (want_post && kn().kernel_d2h && dets && to > 0 && !rag && !want_trace() && !dense) return issue_post(to) && issue_counters();
+        if (want_post && kn().kernel_d2h && dets && to > 0 && !want_trace() && !dense) return issue_post(to) && issue_counters();
       }
       if (kn().kernel_d2h && dets && to > 0) return issue_results(0, to, true);      // counters + prefix in one launch
       return issue_counters() && issue_results(0, to);
@@ -482,7 +482,12 @@ struct Pass {
       o.bb = (int*)ln->h_pbb.p; o.score = (float*)ln->h_psc.p; o.shape = (float*)ln->h_psh.p;
       o.cursor = w.counters + (size_t)8 * kCntStride + kCntPostCursor;
       o.cap_rows = (unsigned)std::min<size_t>(rows, 0x7fffffffu);
-      JDA_HIP(launch_post(pe->dp, w, dim, nf, post_nms, post_overlap, o, st));
+      const uint32_t* rag_gid = nullptr; const RagImg* rag_img = nullptr;
+      if (rag) {                                       // (the chunk's tables are on the device: issue_scan_ragged)
+        const uint8_t* tab = (const uint8_t*)ln->rag_tab.p;
+        rag_gid = (const uint32_t*)(tab + rag->off_gidbase); rag_img = (const RagImg*)(tab + rag->off_rimg);
+      }
+      JDA_HIP(launch_post(pe->dp, w, dim, nf, post_nms, post_overlap, o, st, rag_gid, rag_img));
       post_issued = true; post_cap = rows;
       return true;
     } else {

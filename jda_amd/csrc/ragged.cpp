@@ -151,6 +151,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   ch->off_blk = o; o = align_up(o + (size_t)n_blk * sizeof(RagBlk), 256);
   ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
   ch->off_rimg = o; o = align_up(o + (size_t)n * sizeof(RagImg), 256);
+  ch->off_gidbase = o; o = align_up(o + ((size_t)n + 1) * sizeof(uint32_t), 256);      // (k_post: an image's gid range)
   ch->table_bytes = o;
   if (!ln->h_tab.reserve(o) || !ln->rag_tab.reserve(o)) return false;
   uint8_t* tab = (uint8_t*)ln->h_tab.p;
@@ -198,6 +199,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   }
   seg_first[n] = si;
   ch->gid_base[n] = (uint32_t)gid;
+  std::memcpy(tab + ch->off_gidbase, ch->gid_base.data(), ((size_t)n + 1) * sizeof(uint32_t));
   if (gid > 0x7fffffffLL) { fail("ragged chunk has too many windows"); return false; }
   ch->windows = gid; ch->frame_bytes = dst + 256; ch->max_h = max_h;
   ch->raw_bytes = job.host_imgs ? src : 0;
@@ -289,7 +291,22 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
     }
     first[ch.n] = i;
   }
+  const bool some_posted = dets.p_n.size() == (size_t)ch.n;
   parallel_for(ch.n, [&](int f) {
+    if (some_posted && dets.p_n[f] >= 0) {           // post-processed on the device (k_post)
+      const size_t k = (size_t)dets.p_n[f], r0 = (size_t)dets.p_first[f];
+      jdaResult& r = out[f];
+      r.n = (int)k; r.landmark_n = L;
+      r.bboxes = (int*)std::malloc(std::max<size_t>(1, k * 3) * sizeof(int));
+      r.scores = (float*)std::malloc(std::max<size_t>(1, k) * sizeof(float));
+      r.shapes = (float*)std::malloc(std::max<size_t>(1, k * dim) * sizeof(float));
+      if (k) {
+        std::memcpy(r.bboxes, &dets.p_bb[r0 * 3], k * 3 * sizeof(int));
+        std::memcpy(r.scores, &dets.p_sc[r0], k * sizeof(float));
+        std::memcpy(r.shapes, &dets.p_sh[r0 * dim], k * dim * sizeof(float));
+      }
+      return;
+    }
     const size_t a = first[f], cnt = first[f + 1] - a;
     static thread_local std::vector<int> bb, keep;
     bb.resize(cnt * 3);
@@ -563,6 +580,10 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
     p.solo = lanes == 1;
     p.bind(ln, lane, nullptr);
     p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
+    if (c->kn.device_post >= 1 && sl.ch.n >= c->kn.device_post_min_frames) {
+      p.want_post = true; p.post_nms = !opt || opt->nms; p.post_overlap = opt ? opt->nms_overlap : 0.3f;
+      sl.dets.p_n.assign((size_t)sl.ch.n, -1); sl.dets.p_first.assign((size_t)sl.ch.n, 0);
+    }
     p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
     p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
     if (job.d_job_raw) {
