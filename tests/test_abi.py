@@ -130,7 +130,9 @@ def test_options_round_trip_and_start_from_the_environment(built, model_file, mo
     documented = {"handoff": 128, "lanes": 2, "dense": 1, "plan_cache": 64, "predict": 1, "wide_max": 1024,
                   "wide_busy_max": 2, "ragged_chunk_windows": 4000000, "ragged_tile_grow_pct": 150, "filter0": 1,
                   "kernel_d2h": 1, "h2d_stream": 1, "h2d_min_bytes": 8 << 20, "ragged_uploader": 1,
-                  "ragged_stage_threads": 4}
+                  "ragged_stage_threads": 4, "ragged_chunk_min_windows": 1500000, "ragged_split": 3,
+                  "scan_p": 1, "scan_p_slots": 5, "scan_p_dyn": 1, "device_post": 1, "device_post_min_frames": 16,
+                  "w_pad": 1, "w_stream_mb": 8, "lm_deep": 1, "max_lanes": 16}
     for k in list(os.environ):
         if k.startswith("JDA_") and k not in ("JDA_LIB_PATH",):
             monkeypatch.delenv(k)
@@ -145,6 +147,9 @@ def test_options_round_trip_and_start_from_the_environment(built, model_file, mo
     assert c2.get_option("handoff") == 96
     c2.set_option("handoff", 112)
     assert c2.get_option("handoff") == 112 and c.get_option("handoff") == 128
+    for k in ("scan_p_tile_kb", "scan_p_grid", "ragged_chunk_min_windows", "workspace_mb"):      # sizes and counts: no negative values
+        with pytest.raises(api.JdaError):
+            c.set_option(k, -1)
     with pytest.raises(api.JdaError):
         c.set_option("no_such_option", 1)
     assert api.lib.jdaGetOption(c.h, b"no_such_option") == -1
