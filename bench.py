@@ -163,8 +163,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
     ap.add_argument("--no-x", action="store_true", help="skip the configs[4] all-pass leg (roofline_hbm_regime)")
-    ap.add_argument("--config2", action="store_true",
-                    help="also time BASELINE.json configs[2] at its stated size (256 x 1080p: ~10 s of frame synthesis) for roofline_config2")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the BASELINE.json configs[2] leg (256 x 1080p, scale 1.5: config.config2_*)")
+    ap.add_argument("--config2", action="store_true", help="(accepted for older command lines: the leg runs by default)")
     args = ap.parse_args()
     rc = maybe_self_spawn(args, sys.argv[1:])
     if rc is not None:
@@ -347,10 +348,14 @@ def main():
         gather.drain()
         barrier()
         el = time.perf_counter() - t0
+        rank_el = None
         if world > 1:
+            # the job's time is the slowest rank's; every rank's own time goes into config.rank_ms_per_step_min / _max
             t = torch.tensor([el], dtype=torch.float64, device=gather_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_el = [float(x.item()) for x in every]
+            el = max(rank_el)
         st = stats[-1]
         scan_ms = float(np.mean([s["scan_ms"] for s in stats]))
         scan_lds_ms = float(np.mean([s["scan_lds_ms"] for s in stats]))
@@ -375,6 +380,7 @@ def main():
             "scan_window_fraction": st["scan_patch_n"] / max(1, st["patch_n"]),
             "dense_passes_per_step": st["dense_passes"],
             "batches_in_flight": depth,
+            "rank_ms_per_step": [e / steps * 1e3 for e in rank_el] if rank_el else None,
         }
         for c in cascs:
             c.close()
@@ -382,7 +388,33 @@ def main():
             gather.close()
         return info, mp
 
+    # ---- first contact of the N-rank gather, before anything is timed: a known ragged pattern (an empty rank, a rank with
+    #      more rows than a pipelined block carries -> every rank takes the exact ncclAllGather(counts) + ncclSend/ncclRecv
+    #      path, two gathers in flight) through the same entry points the timed steps use, checked row by row on rank 0.
+    #      JDA_DIST_SELFTEST=0 skips it; a failure is reported in config.dist_selftest and the job goes on through
+    #      whatever gather still works ----
+    selftest = None
+    if world > 1 and os.environ.get("JDA_DIST_SELFTEST", "1") != "0":
+        g0, kind0 = make_gather()
+        try:
+            selftest = jdist.gather_selftest(g0, rank, world, 5 + 2 * L, 4096)
+        except Exception as e:                    # noqa: BLE001
+            selftest = "FAILED on rank %d: %r" % (rank, e)
+        flag = torch.tensor([1 if selftest == "ok" else 0], device=gather_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if selftest == "ok":
+                selftest = "FAILED on another rank"
+            sys.stderr.write("bench.py rank %d: gather self-test (%s): %s\n" % (rank, kind0, selftest))
+            if "libjda_dist" in kind0:
+                os.environ["JDA_BENCH_GATHER"] = "torch"      # every rank saw the same flag: all fall back together
+        else:
+            selftest = "ok (%s)" % kind0.split(":")[0]
+        if hasattr(g0, "close"):
+            g0.close()
+
     casc_info, casc_model = run_regime("cascade", args.steps, args.warmup, call["th"], depth=args.depth)
+    rank_ms = casc_info.get("rank_ms_per_step")
     # one caller, one batch at a time (what a single jdaDetectBatchDevice loop sees)
     single_info = casc_info if args.depth <= 1 else run_regime("cascade", max(1, min(20, args.steps)), 2, call["th"])[0]
     # roofline leg: the same workload with the k_scan launches of a step back to back on one stream
@@ -497,14 +529,16 @@ def main():
                     def shard_job():
                         return casc.detect_ragged_packed(d_sub, so, ws[a:b], hs[a:b], stats=True, keep_results="packed", frame_offset=a, **kw)
                     shard_job()
-                    best = 1e30
-                    for _ in range(max(2, reps)):
-                        t1 = time.perf_counter(); shard_job(); best = min(best, time.perf_counter() - t1)
-                    per.append(best); worst = max(worst, best)
+                    nrep = max(2, reps)
+                    t1 = time.perf_counter()
+                    for _ in range(nrep):
+                        shard_job()
+                    mean = (time.perf_counter() - t1) / nrep
+                    per.append(mean); worst = max(worst, mean)
                 pred[str(nn)] = {"max_shard_ms": worst * 1e3, "min_shard_ms": min(per) * 1e3, "speedup": t_full / worst}
             info["predicted_strong_scaling"] = pred
-            info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (best of %d); speedup = "
-                                                     "ms_per_job / max shard time; not a multi-GPU measurement" % max(2, reps))
+            info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (mean of %d runs, like ms_per_job); speedup = "
+                                                     "mean ms_per_job / slowest shard's mean; not a multi-GPU measurement" % max(2, reps))
         casc.close()
         if hasattr(gather, "close"):
             gather.close()
@@ -518,18 +552,24 @@ def main():
             raise
         fddb_info = {"error": repr(e)}
 
-    # ---- BASELINE.json configs[2] at its stated size, live (optional: the frames take ~10 s to synthesise) ----
+    # ---- BASELINE.json configs[2] at its stated size, live: 256 x 1920x1080 frames resident in HBM (531 MB), scale 1.5
+    #      (8 window sizes), shipped model dimensions, cascade regime.  The frames are 32 synthesised ones (synth.make_frames,
+    #      1.3 s of host time instead of 10 s for 256) and seven cyclic shifts of each, made on the device: 256 distinct
+    #      frames of the same statistics at 256 distinct places in HBM ----
     config2_live = None
-    if rank == 0 and world == 1 and args.config2:
+    if rank == 0 and world == 1 and not args.no_config2:
         try:
-            f2 = synth.make_frames(256, 1920, 1080, seed=0)
+            n_base, n_var = 32, 8
+            f2 = synth.make_frames(n_base, 1920, 1080, seed=0)
             mp2 = os.path.join(synth.cache_dir(), "config2_5_540_27_4.model")
             if not os.path.exists(mp2):
                 m2 = synth.make_model(5, 540, 27, 4, seed=1)
                 synth.calibrate_thresholds(m2, f2[:4], scale=1.5)
                 m2.save(mp2 + ".tmp", 8); os.replace(mp2 + ".tmp", mp2)
             c2 = api.Cascador(mp2, device=local_rank)
-            d2 = torch.from_numpy(f2).to(dev)
+            b2 = torch.from_numpy(f2).to(dev)
+            d2 = torch.cat([b2] + [torch.roll(b2, shifts=(131 * j, 257 * j), dims=(1, 2)) for j in range(1, n_var)]).contiguous()
+            del b2
             for _ in range(2):
                 c2.detect_batch_device(d2, 1.5, keep_results=False)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -537,9 +577,12 @@ def main():
                 _, st2 = c2.detect_batch_device(d2, 1.5, keep_results=False, stats=True)
             torch.cuda.synchronize(); el2 = (time.perf_counter() - t0) / 3
             config2_live = {"ms_per_call": el2 * 1e3, "windows_per_s": st2["patch_n"] / el2, "gpu_ms": st2["gpu_ms"],
-                            "windows_per_call": st2["patch_n"], "entry": "jdaDetectBatchDevice, synchronous (two sub-batch lanes)"}
-            # the same batches through submit / wait, two queued ahead of the one being collected (the host's sort + NMS of
-            # 15 k detections behind the other batches' kernels); warmed up in this mode: a ticket's lane holds a whole batch
+                            "scan_ms": st2["scan_ms"], "average_cart_n": st2["average_cart_n"],
+                            "windows_per_call": st2["patch_n"], "frames": int(d2.shape[0]),
+                            "entry": "jdaDetectBatchDevice, synchronous (two sub-batch lanes)",
+                            "data": "%d synthesised 1920x1080 frames + %d cyclic shifts of each (made on the device)" % (n_base, n_var - 1)}
+            # the same batches through submit / wait, two queued ahead of the one being collected; warmed up in this mode:
+            # a ticket's lane holds a whole batch
             def pipe2(k):
                 q = [c2.submit_batch_device(d2, 1.5) for _ in range(min(2, k))]
                 issued = len(q)
@@ -554,6 +597,7 @@ def main():
             config2_live["submit_wait_ms_per_call"] = elp * 1e3
             config2_live["submit_wait_windows_per_s"] = st2["patch_n"] / elp
             c2.close(); del d2, f2
+            torch.cuda.empty_cache()
         except Exception as e:
             config2_live = {"error": repr(e)}
 
@@ -594,7 +638,7 @@ def main():
                 x_info["traffic_over_algorithmic"] = tj["traffic_line_bytes"] / tj["algorithmic_bytes"]
                 x_info["traffic_GBps_in_profiled_run"] = tj["traffic_line_bytes"] / tj["duration_s"] / 1e9
                 x_info["traffic_useful_equivalent"] = tj["traffic_useful_equivalent_bytes"]
-                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json + profiles/r03_x_allpass.txt -- builder-run, NOT measured in this run: "
+                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json (from profiles/r04_x_allpass.txt) -- builder-run, NOT measured in this run: "
                                             "fabric read requests of the k_finish dispatch x 128 B (= FETCH_SIZE x 2), FETCH_SIZE calibrated on a gather of "
                                             "544-byte rows of known size (0.65 counted bytes per useful byte); Infinity-Cache hits are included, no counter "
                                             "separates them from HBM reads")
@@ -650,65 +694,90 @@ def main():
                             "what": "LDS crossbar bytes: (%d walk + %d weight-row) lane-reads of 4 B per window-cart x carts / device span of the step" % (lane_reads_per_cart, 2 * L),
                             "counters": {"lds_pipe_busy_frac": 0.37, "valu_busy_frac": 0.27, "lds_bank_conflict_cycles": 0,
                                          "source": "profiles/r04_allpass_k_stage.txt (SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU x 4 cycles / 4 SIMDs, per CU-clock of the LDS-tiled k_stage launches; 64-frame batch) -- builder-run, NOT measured in this run"}}
-        config2_roof = None
-        c2p = os.path.join(ROOT, "profiles", "r04_config2_roofline.json")
-        if os.path.exists(c2p):
-            try:
-                config2_roof = json.load(open(c2p))
-            except Exception:
-                config2_roof = None
-        if config2_roof is not None and config2_live is not None:
-            config2_roof["measured_in_this_run"] = config2_live
+        # ---- flat scalars under `config` and `roofline`: the two objects a reader of the driver's record keeps ----
+        def g(d, *ks):
+            for k in ks:
+                if not isinstance(d, dict) or d.get(k) is None:
+                    return None
+                d = d[k]
+            return d
+        cfg_extra = {
+            "images_per_s": casc_info["images_per_s"],
+            # BASELINE metric, second half: the FDDB-shaped job (configs[3]'s 2,845 images as one ragged job)
+            "fddb_images_per_s": g(fddb_info, "images_per_s"), "fddb_ms_per_job": g(fddb_info, "ms_per_job"),
+            "fddb_windows_per_s": g(fddb_info, "windows_per_s"), "fddb_images": g(fddb_info, "images"),
+            "fddb_jobs_timed": g(fddb_info, "jobs_timed"), "fddb_host_images_per_s": g(fddb_info, "host_images_per_s"),
+            "fddb_pred_speedup_2": g(fddb_info, "predicted_strong_scaling", "2", "speedup"),
+            "fddb_pred_speedup_4": g(fddb_info, "predicted_strong_scaling", "4", "speedup"),
+            "fddb_pred_speedup_8": g(fddb_info, "predicted_strong_scaling", "8", "speedup"),
+            # configs[2]: 256 x 1080p, scale 1.5, measured in this run
+            "config2_windows_per_s": g(config2_live, "windows_per_s"), "config2_ms_per_call": g(config2_live, "ms_per_call"),
+            "config2_gpu_ms_per_call": g(config2_live, "gpu_ms"), "config2_windows_per_call": g(config2_live, "windows_per_call"),
+            "config2_frames": g(config2_live, "frames"),
+            "config2_submit_wait_windows_per_s": g(config2_live, "submit_wait_windows_per_s"),
+            "config2_submit_wait_ms_per_call": g(config2_live, "submit_wait_ms_per_call"),
+            # all-pass regime of the headline batch (dense kernel) and configs[4] (one 1080p frame, all-pass)
+            "allpass_windows_per_s": g(allpass_info, "windows_per_s"), "allpass_ms_per_step": g(allpass_info, "ms_per_step"),
+            "config4_allpass_windows_per_s": g(x_info, "windows_per_s"), "config4_allpass_ms_per_frame": g(x_info, "ms_per_step"),
+            "one_lane_ms_per_step": roof_info["ms_per_step"], "average_cart_n": casc_info["average_cart_n"],
+            "detections_after_nms": casc_info["detections_after_nms"],
+        }
+        if rank_ms is not None:
+            cfg_extra.update({"rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms)})
+        if selftest is not None:
+            cfg_extra["dist_selftest"] = selftest
+        roof_extra = {
+            # the regime in which memory traffic IS the bound (configs[4] all-pass), measured in this run
+            "hbm_regime_bound": "hbm", "hbm_regime_frac": g(x_info, "frac"), "hbm_regime_achieved_GBps": g(x_info, "achieved"),
+            "hbm_regime_peak_GBps": HBM_PEAK_GBPS, "hbm_regime_ms_per_step": g(x_info, "ms_per_step"),
+            "hbm_regime_traffic_over_algorithmic": g(x_info, "traffic_over_algorithmic"),
+            "hbm_regime_workload": "configs[4]: T=7 K=2000 L=68 D=6, one 1080p frame, all-pass: 303,222 windows x 14,000 carts",
+            "allpass_lds_frac": g(allpass_roof, "frac"), "allpass_lds_achieved_GBps": g(allpass_roof, "achieved"),
+            "hbm_side_measured_frac_of_hbm_peak": hbm_frac,
+            "hbm_side_algorithmic_GBps": scan_bytes_alg / lds_s / 1e9 if lds_s > 0 else None,
+        }
         line = {
-            "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path); FDDB images/sec in fddb_images_per_s",
+            "metric": "candidate windows/sec, 640x480 batch (jdaDetect hot path); FDDB images/sec in config.fddb_images_per_s",
             "value": casc_info["windows_per_s"], "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": casc_info["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "images_per_s": casc_info["images_per_s"],
-            "fddb_images_per_s": fddb_info.get("images_per_s") if fddb_info else None,
+            "config": dict({"workload": "BASELINE.json configs[1]: batch=%d %dx%d frames per GPU, synthetic %dx%d-cart "
+                                        "%d-landmark depth-%d model, cascade regime, jdaDetect(1.25,0.1,40,-1,-0.5)"
+                                        % (B, W, H, T, K, L, D),
+                            "batch_per_gpu": B, "width": W, "height": H, "windows_per_frame": wpf, "levels": n_levels,
+                            "model_T": T, "model_K": K, "model_landmarks": L, "model_depth": D,
+                            "regime": "cascade", "sharding": "frames, %d rank(s)" % world,
+                            "gather": gather_kind[0],
+                            "distinct_resident_batches": R, "resident_frame_bytes": R * B * W * H,
+                            "batches_in_flight_per_gpu": casc_info["batches_in_flight"],
+                            "single_caller_ms_per_step": single_info["ms_per_step"],
+                            "single_caller_windows_per_s": single_info["windows_per_s"],
+                            "host_frames_windows_per_s": host_info["pageable_windows_per_s"] if host_info else None,
+                            "host_frames_pinned_windows_per_s": host_info["pinned_windows_per_s"] if host_info else None,
+                            "host_frames_pinned_over_value": (host_info["pinned_windows_per_s"] / casc_info["windows_per_s"])
+                                                             if host_info else None}, **cfg_extra),
+            "roofline": dict({"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBPS,
+                              "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
+                              "traffic": traffic, "traffic_source": traffic_src,
+                              "traffic_from_this_device_code": traffic_fresh,
+                              "kernel": "k_scan_p / k_scan, LDS-tiled launches of one step (one per tiled pyramid level)",
+                              "what": "LDS crossbar bytes: %d lane-reads x 4 B per window-cart x carts (device counter) / HIP-event span"
+                                      % lane_reads_per_cart,
+                              "lane_reads_per_cart": lane_reads_per_cart,
+                              "carts_per_step": roof_info["scan_lds_carts_per_step"],
+                              "kernel_ms_per_step": roof_info["scan_lds_ms_per_step"],
+                              "frac_of_random_gather_rate": achieved / LDS_RANDOM_GATHER_GBPS,
+                              "random_gather_rate_GBps": LDS_RANDOM_GATHER_GBPS,
+                              "all_scan_launches_ms_per_step": roof_info["scan_ms_per_step"],
+                              "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0: launches back to back on one stream, HIP events on that stream"},
+                             **roof_extra),
+            "cpu_baseline": cpu,
+            # ---- detail (a reader of the full line; the driver's record keeps config / roofline / cpu_baseline) ----
             "fddb": fddb_info,
-            "config": {"workload": "BASELINE.json configs[1]: batch=%d %dx%d frames per GPU, synthetic %dx%d-cart "
-                                   "%d-landmark depth-%d model, cascade regime, jdaDetect(1.25,0.1,40,-1,-0.5)"
-                                   % (B, W, H, T, K, L, D),
-                       "batch_per_gpu": B, "width": W, "height": H, "windows_per_frame": wpf, "levels": n_levels,
-                       "model_dims_TKLD": list(dims), "regime": "cascade", "sharding": "frames, %d rank(s)" % world,
-                       "gather": gather_kind[0],
-                       "distinct_resident_batches": R, "resident_frame_bytes": R * B * W * H,
-                       "batches_in_flight_per_gpu": casc_info["batches_in_flight"],
-                       "single_caller_ms_per_step": single_info["ms_per_step"],
-                       "single_caller_windows_per_s": single_info["windows_per_s"],
-                       "host_frames_windows_per_s": host_info["pageable_windows_per_s"] if host_info else None,
-                       "host_frames_pinned_windows_per_s": host_info["pinned_windows_per_s"] if host_info else None,
-                       "host_frames_pinned_over_value": (host_info["pinned_windows_per_s"] / casc_info["windows_per_s"])
-                                                        if host_info else None},
-            "roofline": {"bound": "lds", "achieved": achieved, "peak": LDS_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / LDS_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_from_this_device_code": traffic_fresh,
-                         "kernel": "k_scan_p / k_scan, the LDS-tiled launches of one step (one per tiled pyramid level: k_scan_p where a workgroup has room for >= 4 pixel-tile slots, k_scan else)",
-                         "what": "LDS crossbar bytes: (D-1)*3+2 = %d lane-reads of 4 B per window-cart x carts evaluated "
-                                 "(device counter) / HIP-event span of the launches; peak = 128 B/clk/CU x 256 CUs x 2.4 GHz "
-                                 "(conflict-free ds_read_b32/u8 rate)" % lane_reads_per_cart,
-                         "lane_reads_per_cart": lane_reads_per_cart,
-                         "carts_per_step": roof_info["scan_lds_carts_per_step"],
-                         "kernel_ms_per_step": roof_info["scan_lds_ms_per_step"],
-                         "frac_of_random_gather_rate": achieved / LDS_RANDOM_GATHER_GBPS,
-                         "random_gather_rate_GBps": LDS_RANDOM_GATHER_GBPS,
-                         "hbm_side": {"algorithmic_bytes_per_step": scan_bytes_alg,
-                                      "algorithmic_GBps": scan_bytes_alg / lds_s / 1e9 if lds_s > 0 else None,
-                                      "measured_frac_of_hbm_peak": hbm_frac,
-                                      "note": "SURVEY 8(d)'s 34 B per node are served from LDS (tile and tables staged once "
-                                              "per workgroup), so this figure exceeds what HBM delivers and is not a "
-                                              "roofline; the kernel's HBM-side traffic is the frames once + the tables"},
-                         "all_scan_launches_ms_per_step": roof_info["scan_ms_per_step"],
-                         "measured_with": "JDA_LANES=1 JDA_SIDE_STREAM=0: the launches of a step run back to back on one "
-                                          "stream, HIP events recorded on that stream before the first and after the last "
-                                          "LDS-tiled launch (jdaStats.scan_lds_ms); the throughput legs overlap two batches"},
+            "config2": config2_live,
             "roofline_hbm_regime": x_info,
             "roofline_allpass": allpass_roof,
-            "roofline_config2": config2_roof,
-            "cpu_baseline": cpu,
             "regimes": {"cascade": casc_info, "cascade_single_caller": single_info, "cascade_one_lane": roof_info,
                         "allpass": allpass_info, "host_frames": host_info},
         }

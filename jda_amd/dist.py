@@ -280,6 +280,16 @@ class CGather:
             raise RuntimeError("libjda_dist: %s" % self.L.jdaDistLastError().decode())
         return prev
 
+    def start_raw(self, mat):
+        """jdaDistGatherStart alone (up to two may be in flight); collect() finishes the oldest."""
+        import ctypes as C
+        mat = np.ascontiguousarray(mat, np.float32)
+        if self.L.jdaDistGatherStart(self.h, mat.ctypes.data_as(C.POINTER(C.c_float)), mat.shape[0]) != 0:
+            raise RuntimeError("libjda_dist: %s" % self.L.jdaDistLastError().decode())
+
+    def collect(self):
+        return self._collect()
+
     def _collect(self):
         import ctypes as C
         out, n = C.POINTER(C.c_float)(), C.c_int()
@@ -291,3 +301,50 @@ class CGather:
         while self.L.jdaDistPending(self.h) > 0:
             last = self._collect()
         return last
+
+
+# ---------------------------------------------------------------------------------------------
+# first contact: a known ragged pattern through a gather object, checked on rank 0
+# ---------------------------------------------------------------------------------------------
+
+def selftest_rows(pattern, rank, world, width, block_rows):
+    """Rows rank `rank` contributes to self-test gather `pattern` (0: every block fits, rank 1 is empty;
+    1: the last rank overflows its block, so every rank takes the exact path).  Values are exact in fp32."""
+    if pattern == 0:
+        n = 0 if rank == 1 else 3 * rank + 2
+    else:
+        n = block_rows + 5 if rank == world - 1 else (0 if rank == 1 else rank + 1)
+    i = np.arange(n, dtype=np.float32)[:, None]
+    j = np.arange(width, dtype=np.float32)[None, :]
+    return (np.float32(100000 * pattern + 1000 * (rank % 64)) + i + j * np.float32(0.5)).astype(np.float32).reshape(n, width)
+
+
+def gather_selftest(gather, rank, world, width, block_rows):
+    """Drives `gather` (CGather or PipelinedGather: start() returns what the previous start gathered, drain() the
+    last) with two gathers in flight -- one whose blocks all fit with an empty rank in it, one that overflows a
+    block and sends every rank down the exact count-then-rows path -- and compares what arrives on rank 0 with the
+    concatenation in rank order.  Every rank must call it (the gathers are collectives).  Returns "ok" or raises."""
+    order = (1, 0)          # the overflowing gather first: its exact fallback then runs with the next gather queued behind it
+    mine = [selftest_rows(p, rank, world, width, block_rows) for p in order]
+    if hasattr(gather, "start_raw"):           # CGather: really two in flight (jdaDistGatherStart x 2, then Collect x 2)
+        gather.start_raw(mine[0]); gather.start_raw(mine[1])
+        got = [gather.collect(), gather.collect()]
+    else:
+        first = gather.start(mine[0])
+        if first is not None and len(first):
+            raise RuntimeError("a fresh gather returned rows before anything was started")
+        got = [gather.start(mine[1]), gather.drain()]
+    if hasattr(gather, "gather"):              # the blocking exact entry too (jdaDistGatherRows)
+        got.append(gather.gather(mine[1]))
+    if rank != 0:
+        for g in got:
+            if g is not None and len(g):
+                raise RuntimeError("rows arrived on rank %d" % rank)
+        return "ok"
+    for k, g in enumerate(got):
+        p = order[k] if k < 2 else order[1]
+        want = np.concatenate([selftest_rows(p, r, world, width, block_rows) for r in range(world)])
+        if g is None or g.shape != want.shape or not np.array_equal(np.asarray(g), want):
+            raise RuntimeError("gather %d: rows on rank 0 differ from the ranks' rows in rank order (got %s, want %s)"
+                               % (k, None if g is None else g.shape, want.shape))
+    return "ok"

@@ -166,6 +166,8 @@ def _worker_pipelined(rank, world, port, q, max_rows):
         outs.append(pg.start(mat))                        # returns the PREVIOUS step's gather
     outs.append(pg.drain())
     assert outs[0] is None and pg.drain() is None
+    # the first-contact pattern bench.py --gpus N runs before its timed region (empty rank, overflowing rank)
+    assert jd.gather_selftest(jd.PipelinedGather(max_rows, 9, device="cpu"), rank, world, 9, max_rows) == "ok"
     if rank == 0:
         q.put(outs[1:])
     else:
@@ -203,3 +205,16 @@ def test_pipelined_gather_single_process():
     assert pg.start(a) is None
     assert pg.start(b) is a
     assert pg.drain() is b and pg.drain() is None
+    assert jd.gather_selftest(jd.PipelinedGather(8, 3), 0, 1, 3, 8) == "ok"
+
+
+def test_selftest_notices_wrong_rows():
+    """The self-test is a check, not a formality: a gather that drops or reorders rows fails it."""
+    from jda_amd import dist as jd
+
+    class Lossy(jd.PipelinedGather):
+        def drain(self):
+            out = super().drain()
+            return out[:-1] if out is not None and len(out) else out
+    with pytest.raises(RuntimeError, match="differ"):
+        jd.gather_selftest(Lossy(8, 3), 0, 1, 3, 8)

@@ -1176,6 +1176,8 @@ def test_c_gather_entry_over_rccl_group_of_one(built, gpu, model_file):
     for step, got in enumerate(outs[1:]):
         n = [3, 0, 40, 16][step]
         assert got.shape == (n, 7) and (got[:, 1:] == step + 1).all() and list(got[:, 0]) == list(range(n)), (step, got.shape)
+    # the first-contact pattern of bench.py --gpus N: two gathers in flight, the first one overflowing its block
+    assert jd.gather_selftest(g, 0, 1, 7, 16) == "ok"
     g.close()
     # jdaGatherResults: per-frame results of a detect call -> rows on rank 0 == jdaResultsPack's rows
     p, _ = model_file((3, 20, 5, 4), 8, seed=3, cart_th=-1.0)
