@@ -306,3 +306,43 @@ def cache_dir():
     d = os.environ.get("JDA_SYNTH_CACHE", "/tmp/jda_synth_cache")
     os.makedirs(d, exist_ok=True)
     return d
+
+
+def make_dyadic_model(T, K, L, D, win, seed=1, reject=0.0, norm_every=7):
+    """A model on which the two numeric dialects MUST walk the same path (tests/test_dialect_differential.py).
+
+    Every real is a small dyadic rational, chosen so that for windows of side `win` (a power of two):
+      * (shape + offset) * win is an integer + 0.25 in every stage -- truncation (c/jda.c:373-381) and round()
+        (src/jda/data.cpp:37-51) pick the same pixel, and fp32 and fp64 compute it without rounding;
+      * every score and every regressed shape coordinate is a sum of multiples of 2^-10 far below 2^14, exact in
+        fp32 and in fp64 alike, in any order of accumulation (the sum-from-zero of btcart.cpp:407-424 included);
+      * normalising carts divide by a power of two.
+    What the dialects still do differently on such a model is nothing: equal leaf paths, equal reject positions,
+    scores and shapes equal after fp64 -> fp32 conversion.  reject > 0: cart thresholds on the same grid, so that
+    about that fraction of the still-alive windows dies per cart.
+    """
+    assert win & (win - 1) == 0 and win >= 16
+    rng = np.random.default_rng(seed)
+    m = Model(T, K, L, D)
+    g, bias = 1.0 / win, 0.25 / win
+    m.mean_shape = rng.integers(int(0.25 * win), int(0.75 * win) + 1, m.dim) * g + bias
+    shp = (T, K, m.node_n)
+    m.lm1 = rng.integers(0, L, shp).astype(np.int32)
+    m.lm2 = rng.integers(0, L, shp).astype(np.int32)
+    r = max(1, int(0.3 * win))
+    m.off = rng.integers(-r, r + 1, shp + (4,)) * g
+    m.nth = rng.integers(-40, 41, shp).astype(np.int32)
+    m.leaf = rng.integers(-256, 257, (T, K, m.leaf_n)) / 256.0
+    kk = np.arange(1, K + 1)
+    normed = (kk % norm_every) == 0
+    m.cmean = np.where(normed[None, :], rng.integers(-64, 65, (T, K)) / 256.0, 0.0)
+    m.cstd = np.where(normed[None, :], np.where((kk // norm_every) % 2 == 1, 2.0, 0.5)[None, :], 1.0) * np.ones((T, K))
+    m.w = rng.choice(np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, g, -g]), (T, K * m.leaf_n, m.dim))
+    if reject > 0:
+        # a threshold that climbs with the running score's spread (~0.29 * sqrt(c)): roughly `reject` of the live
+        # windows fall below it at every cart; on the 2^-8 grid
+        c = np.arange(1, T * K + 1, dtype=np.float64).reshape(T, K)
+        m.cth = np.round((-1.6 + 3.2 * reject) * 0.29 * np.sqrt(c) * 256.0) / 256.0
+    else:
+        m.cth = np.full((T, K), NEG_BIG)
+    return m

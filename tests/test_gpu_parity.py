@@ -464,16 +464,58 @@ def test_dialect_cpp_shipped_config(built, gpu, model_file):
         assert same(dets[0][k], want[k]), k
 
 
-def test_dialects_agree_where_they_must(built, gpu, model_file):
-    """Same model, same windows: wherever fp32/trunc and fp64/round pick the same pixels the
-    leaf paths coincide; with thresholds off both dialects evaluate every cart of every window."""
+DIFF_KERNELS = {  # which finishing kernel a traced pass runs (options of DESIGN.md section 8; none changes results)
+    "k_finish": dict(dense=0, wide_max=0),
+    "k_finish_wide": dict(dense=0, wide_max=10_000_000, wide_busy_max=64),
+    "k_stage": dict(dense=2),
+}
+
+
+@pytest.mark.parametrize("kernel", sorted(DIFF_KERNELS))
+@pytest.mark.parametrize("dims,win,scale,n_frames,w,h", [((3, 70, 9, 5), 32, 4.0 / 3.0, 4, 640, 480),
+                                                         ((2, 64, 68, 6), 64, 8.0 / 3.0, 2, 400, 300)])
+@pytest.mark.parametrize("reject", [0.0, 0.12])
+def test_dialects_agree_where_they_must(built, gpu, tmp_path, kernel, dims, win, scale, n_frames, w, h, reject):
+    """The fp64 instantiation of the kernels (dialect CPP, parity UNPINNED: src/jda needs OpenCV) against their fp32
+    instantiation (dialect C, pinned by the compiled c/jda.c) on a model where the two MUST agree
+    (synth.make_dyadic_model: truncation and round() pick the same pixels, every sum is exact in fp32 and fp64) and on
+    the same window grid (one window size; C: min = max = win, CPP: minimum_size = win, step = (int)(0.1f * win)).
+    Per window: reject position (carts evaluated), leaf-path hash, score and shape after fp64 -> fp32 conversion --
+    121,800 windows in the large case, through each of the three finishing kernels.  The CPU half (the oracle's two
+    dialects, and this model through the compiled reference) is tests/test_dialect_differential.py.  What stays
+    unpinned in dialect CPP: round() where it differs from truncation, fp64 accumulation where fp32 rounds, the patch
+    sizes of scale != 0 nodes, cv::resize, the multimap NMS (cart.cpp:392-404, data.cpp:37-51)."""
     from jda_amd import api, synth
-    p, _ = model_file((2, 8, 5, 3), 8, seed=23)
-    frames = synth.make_frames(1, 100, 80, seed=33)
+    from oracle.pyoracle import Oracle
+    m = synth.make_dyadic_model(*dims, win=win, seed=11 + win, reject=reject)
+    p = str(tmp_path / "dyadic.model")
+    m.save(p, 8)
+    frames = synth.make_frames(n_frames, w, h, seed=33)
+    step = int(np.float32(win) * np.float32(0.1))
     c = api.Cascador(p)
-    a = c.trace(frames, scale=1.25, min_size=24)
-    b = c.trace_cpp(frames, minimum_size=24, step=5, factor=1.25)
-    assert (a["carts_n"] == 16).all() and (b["carts_n"] == 16).all()
+    for k, v in DIFF_KERNELS[kernel].items():
+        c.set_option(k, v)
+    a = c.trace(frames, scale=np.float32(scale), min_size=win, max_size=win)
+    b = c.trace_cpp(frames, minimum_size=win, step=step, factor=100.0)
+    n = n_frames * ((w - win) // step + 1) * ((h - win) // step + 1)
+    assert len(a["carts_n"]) == len(b["carts_n"]) == n
+    if dims == (3, 70, 9, 5):
+        assert n >= 100_000
+    assert np.array_equal(a["carts_n"], b["carts_n"])
+    assert np.array_equal(a["path_hash"], b["path_hash"])
+    assert same(a["score"], b["score"].astype(np.float32))
+    assert same(a["shapes"], b["shapes"].astype(np.float32))
+    assert np.array_equal(b["shapes"].astype(np.float32).astype(np.float64), b["shapes"])
+    T, K = dims[0], dims[1]
+    if reject == 0.0:
+        assert (a["carts_n"] == T * K).all()
+    else:
+        assert 0.2 < (a["carts_n"] < T * K).mean() and (a["carts_n"] > K).any() and len(np.unique(a["carts_n"])) > 10
+    assert len(np.unique(a["path_hash"])) > n // 8
+    # ... and the pinned side is the oracle's on the first frame (which the CPU half ties to the compiled reference)
+    r = Oracle(p).trace(frames[0], scale=np.float32(scale), min_size=win, max_size=win)
+    for key in ("carts_n", "score", "path_hash", "shapes"):
+        assert same(r[key], a[key][:len(r[key])]), key
 
 
 @pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 452, 339), (640, 480, 320, 240), (131, 97, 92, 68), (100, 80, 100, 80),
