@@ -96,6 +96,29 @@ def build_variant(name, defines):
     return _build(os.path.join(HERE, "libjda_%s.so" % name), OBJDIR + "_" + name, ["-D" + d for d in defines])
 
 
+WD_LIB = os.path.join(HERE, "libjda_wd.so")
+
+
+def build_watchdog(force=False):
+    """libjda_wd.so: the product's objects with ONE translation unit rebuilt -- k_scan_p.hip with its idle watchdog at
+    zero (-DJDA_SCAN_P_IDLE_MAX=0), so that every launch of the persistent scan trips it.  Never the product: the GPU
+    suite loads it through JDA_LIB_PATH to see that a tripped launch is noticed and the pass rerun with k_scan
+    (tests/test_scan_persistent.py).  Built here, in-tree, so that it travels to the GPU box with libjda.so."""
+    build()
+    src = os.path.join(CSRC, "k_scan_p.hip")
+    objdir = OBJDIR + "_wd"
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, "k_scan_p_hip.o")
+    main_objs = [os.path.join(OBJDIR, s.replace(".", "_") + ".o") for s in SOURCES]
+    newest = max([os.path.getmtime(o) for o in main_objs] + [os.path.getmtime(src), _deps_mtime()])
+    if not force and os.path.exists(WD_LIB) and os.path.getmtime(WD_LIB) >= newest:
+        return WD_LIB
+    subprocess.check_call([hipcc()] + CFLAGS + ["-DJDA_SCAN_P_IDLE_MAX=0", "-c", src, "-o", obj])
+    objs = [obj if o.endswith("k_scan_p_hip.o") else o for o in main_objs]
+    subprocess.check_call([hipcc()] + LDFLAGS + ["-o", WD_LIB] + objs)
+    return WD_LIB
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -110,3 +133,4 @@ if __name__ == "__main__":
         print(build_timing()); sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_dist(force="--force" in sys.argv))
+    print(build_watchdog(force="--force" in sys.argv))

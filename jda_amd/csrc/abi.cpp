@@ -8,34 +8,70 @@
 
 using namespace jda;
 
+// ---- exception barrier -------------------------------------------------------------------------------------------
+// No C++ exception may cross `extern "C"`: the host side allocates (std::vector growth in the post-processing, the
+// 512 MB of a big model's tables, std::string in the error channel, std::thread) and a std::bad_alloc that left
+// jdaDetect* would end the caller's process in std::terminate.  The reference answers an allocation failure with NULL
+// (c/jda.c:487-493); every entry below is a function-try-block whose handler reports through jdaGetLastError() and
+// returns the entry's error value (NULL / -1 / an empty jdaResult).  Stack unwinding has already given back what the
+// call held (LaneSet, PlanPin); the detect entries also wait for whatever the call had queued on the device, because
+// the caller is free to release its frames as soon as the entry returns.
+namespace {
+void abi_exception(const char* fn, bool sync_device) noexcept {
+  const char* what = "unknown C++ exception";
+  char buf[200];
+  try { throw; }
+  catch (const std::bad_alloc&) { what = "out of host memory (std::bad_alloc)"; }
+  catch (const std::exception& e) { std::snprintf(buf, sizeof buf, "%s", e.what()); what = buf; }
+  catch (...) {}
+  try { fail(std::string(fn) + ": " + what); }
+  catch (...) { std::fprintf(stderr, "libjda: %s: %s\n", fn, what); }       // (not even the message could be allocated)
+  if (sync_device) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+}
+// test hook (option test_throw; tests/test_abi.py): 1 = std::bad_alloc, 2 = std::runtime_error inside the entry
+void maybe_throw(const Cascador* c) {
+  if (c->kn.test_throw == 1) throw std::bad_alloc();
+  if (c->kn.test_throw == 2) throw std::runtime_error("injected by test_throw");
+}
+}  // namespace
+#define JDA_ABI_CATCH(ret) catch (...) { abi_exception(__func__, false); return ret; }
+#define JDA_ABI_CATCH_SYNC(ret) catch (...) { abi_exception(__func__, true); return ret; }
+#define JDA_ABI_CATCH_VOID catch (...) { abi_exception(__func__, false); }
+
 extern "C" {
 
 const char* jdaGetLastError(void) { return g_err.c_str(); }
 
 static void* create_impl(const char* path, int real_bytes) {
-  g_err.clear();
-  Cascador* c = new (std::nothrow) Cascador();
-  if (!c) return nullptr;
-  c->kn.load();
-  std::string err;
-  if (!load_model(path, real_bytes, &c->hm, &err)) {
-    g_err = err;   // reference returns NULL silently (c/jda.c:487-488); keep the reason retrievable
+  Cascador* c = nullptr;
+  try {
+    g_err.clear();
+    c = new Cascador();
+    c->kn.load();
+    std::string err;
+    if (!load_model(path, real_bytes, &c->hm, &err)) {
+      g_err = err;   // reference returns NULL silently (c/jda.c:487-488); keep the reason retrievable
+      delete c;
+      return nullptr;
+    }
+    return c;
+  } catch (...) {      // malloc failure: NULL like the reference (c/jda.c:489-493)
+    abi_exception("jdaCascadorCreate", false);
     delete c;
     return nullptr;
   }
-  return c;
 }
 
 void* jdaCascadorCreateDouble(const char* model) { return create_impl(model, 8); }
 void* jdaCascadorCreateFloat(const char* model) { return create_impl(model, 4); }
 void* jdaCascadorCreate(const char* model) { return create_impl(model, 0); }
 
-void jdaCascadorSerializeTo(void* cascador, const char* model) {
+void jdaCascadorSerializeTo(void* cascador, const char* model) try {
   if (!cascador) return;
   (void)save_model_f32(((Cascador*)cascador)->hm, model);
-}
+} JDA_ABI_CATCH_VOID
 
-void jdaCascadorRelease(void* cascador) {
+void jdaCascadorRelease(void* cascador) try {
   Cascador* c = (Cascador*)cascador;
   if (!c) return;
   // Submitted batches nobody waited for are drained here (their helper threads joined, their streams synchronised by
@@ -63,17 +99,17 @@ void jdaCascadorRelease(void* cascador) {
   }
   delete[] c->pending;
   delete c;
-}
+} JDA_ABI_CATCH_VOID
 
-int jdaCascadorInfo(void* cascador, jdaModelInfo* info) {
+int jdaCascadorInfo(void* cascador, jdaModelInfo* info) try {
   if (!cascador || !info) return -1;
   const HostModel& h = ((Cascador*)cascador)->hm;
   info->T = h.T; info->K = h.K; info->landmark_n = h.L; info->tree_depth = h.D;
   info->multi_scale = h.multi_scale() ? 1 : 0; info->source_real_bytes = h.real_bytes;
   return 0;
-}
+} JDA_ABI_CATCH(-1)
 
-int jdaSetSimilarityTransform(void* cascador, int on) {
+int jdaSetSimilarityTransform(void* cascador, int on) try {
   Cascador* c = (Cascador*)cascador;
   if (!c) return -1;
   std::lock_guard<std::mutex> lock(c->mu);
@@ -85,18 +121,18 @@ int jdaSetSimilarityTransform(void* cascador, int on) {
     c->md.ready = false;          // the fp64 node table depends on it (stage-0 offsets carry the transform)
   }
   return 0;
-}
+} JDA_ABI_CATCH(-1)
 
-int jdaSetDevice(void* cascador, int device) {
+int jdaSetDevice(void* cascador, int device) try {
   Cascador* c = (Cascador*)cascador;
   if (!c) return -1;
   std::lock_guard<std::mutex> lock(c->mu);
   if (c->dev_init && c->device != device) { fail("jdaSetDevice after first use"); return -1; }
   c->device = device;
   return 0;
-}
+} JDA_ABI_CATCH(-1)
 
-int jdaSetOption(void* cascador, const char* key, long long value) {
+int jdaSetOption(void* cascador, const char* key, long long value) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !key) { fail("jdaSetOption: null cascador or key"); return -1; }
@@ -111,54 +147,54 @@ int jdaSetOption(void* cascador, const char* key, long long value) {
   for (auto& kv : c->plans) c->plan_pool.push_back({kv.second.dp, kv.second.table, kv.second.table_cap});
   c->plans.clear();
   return 0;
-}
+} JDA_ABI_CATCH(-1)
 
-long long jdaGetOption(void* cascador, const char* key) {
+long long jdaGetOption(void* cascador, const char* key) try {
   Cascador* c = (Cascador*)cascador;
   long long v = 0;
   if (!c || !key || !c->kn.get(key, &v)) { fail("jdaGetOption: unknown option"); return -1; }
   return v;
-}
+} JDA_ABI_CATCH(-1)
 
 int jdaCountWindows(int width, int height, float scale, int min_size, int max_size,
-                    long long* n_windows, int* n_levels) {
+                    long long* n_windows, int* n_levels) try {
   ScanPlan sp; std::string err;
   if (!plan_dialect_c(width, height, scale, min_size, max_size, &sp, &err)) { g_err = err; return -1; }
   if (n_windows) *n_windows = sp.windows;
   if (n_levels) *n_levels = (int)sp.levels.size();
   return 0;
-}
+} JDA_ABI_CATCH(-1)
 
-void jdaDetectOptionsInit(jdaDetectOptions* opt) {
+void jdaDetectOptionsInit(jdaDetectOptions* opt) try {
   if (!opt) return;
   std::memset(opt, 0, sizeof(*opt));
   opt->dialect = JDA_DIALECT_C; opt->nms = 1; opt->nms_overlap = 0.3f; opt->cpp_step = 5;
-}
+} JDA_ABI_CATCH_VOID
 
 int jdaDetectBatchDevice(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
                          int width, int height, float scale, float step, int min_size, int max_size,
-                         float th, const jdaDetectOptions* opt, jdaResult* out) {
+                         float th, const jdaDetectOptions* opt, jdaResult* out) try {
   (void)step;  // ignored like the reference (c/jda.c:333)
   g_err.clear();
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchDevice runs dialect C; use jdaDetectBatchCpp"); return -1; }
   if (!cascador) { fail("null cascador"); return -1; }
   return detect_c_device((Cascador*)cascador, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt, out);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatchSubmit(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n,
                          int width, int height, float scale, float step, int min_size, int max_size,
-                         float th, const jdaDetectOptions* opt) {
+                         float th, const jdaDetectOptions* opt) try {
   (void)step;
   g_err.clear();
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmit runs dialect C"); return -1; }
   if (!cascador) { fail("null cascador"); return -1; }
   Cascador* c = (Cascador*)cascador;
   return submit_c_device(c, d_frames, frame_stride, n, width, height, scale, min_size, max_size, th, opt);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatchSubmitHost(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                              float scale, float step, int min_size, int max_size, float th,
-                             const jdaDetectOptions* opt) {
+                             const jdaDetectOptions* opt) try {
   (void)step;
   g_err.clear();
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchSubmitHost runs dialect C"); return -1; }
@@ -166,61 +202,68 @@ int jdaDetectBatchSubmitHost(void* cascador, const unsigned char* const* frames,
   if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
   Cascador* c = (Cascador*)cascador;
   return submit_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, frames);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
-int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* out) {
+int jdaDetectBatchWait(void* cascador, int ticket, jdaStats* stats, jdaResult* out) try {
   g_err.clear();
   if (!cascador) { fail("null cascador"); return -1; }
   Cascador* c = (Cascador*)cascador;
   return wait_c_device(c, ticket, stats, out);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                    float scale, float step, int min_size, int max_size, float th,
-                   const jdaDetectOptions* opt, jdaResult* out) {
+                   const jdaDetectOptions* opt, jdaResult* out) try {
   (void)step;
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
   if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
   for (int i = 0; i < n; i++) if (!frames[i]) { fail("null frame pointer"); return -1; }
+  maybe_throw(c);
   return detect_c_device(c, nullptr, 0, n, width, height, scale, min_size, max_size, th, opt, out, frames);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatchRagged(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
                          float scale, float step, int min_size, int max_size, float th,
-                         const jdaDetectOptions* opt, jdaResult* out) {
+                         const jdaDetectOptions* opt, jdaResult* out) try {
   (void)step;
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !images || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRagged runs dialect C"); return -1; }
   return detect_ragged(c, images, nullptr, nullptr, widths, heights, n, scale, min_size, max_size, th, opt, out);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatchRaggedDevice(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
                                const int* heights, int n, float scale, float step, int min_size, int max_size, float th,
-                               const jdaDetectOptions* opt, jdaResult* out) {
+                               const jdaDetectOptions* opt, jdaResult* out) try {
   (void)step;
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
   if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedDevice runs dialect C"); return -1; }
   return detect_ragged(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, out);
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 jdaResult jdaDetect(void* cascador, unsigned char* data, int width, int height,
                     float scale, float step, int min_size, int max_size, float th) {
   Cascador* c = (Cascador*)cascador;
   jdaResult r;
   r.n = 0; r.landmark_n = c ? c->hm.L : 0; r.bboxes = nullptr; r.shapes = nullptr; r.scores = nullptr;
-  if (!c || !data) { fail("jdaDetect: null cascador or image"); return empty_result(r.landmark_n); }
-  const unsigned char* frames[1] = {data};
-  if (jdaDetectBatch(cascador, frames, 1, width, height, scale, step, min_size, max_size, th, nullptr, &r) != 0) {
-    jdaResultRelease(r);
-    return empty_result(c->hm.L);
+  try {
+    if (!c || !data) { fail("jdaDetect: null cascador or image"); return empty_result(r.landmark_n); }
+    const unsigned char* frames[1] = {data};
+    if (jdaDetectBatch(cascador, frames, 1, width, height, scale, step, min_size, max_size, th, nullptr, &r) != 0) {
+      jdaResultRelease(r);
+      return empty_result(c->hm.L);
+    }
+    return r;
+  } catch (...) {      // (jdaDetectBatch has its own barrier; what is left is the error string of the first branch)
+    abi_exception("jdaDetect", false);
+    r.n = 0; r.bboxes = nullptr; r.shapes = nullptr; r.scores = nullptr;
+    return r;
   }
-  return r;
 }
 
 void jdaResultRelease(jdaResult result) {
@@ -231,7 +274,7 @@ void jdaResultRelease(jdaResult result) {
 
 int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                   float scale, int min_size, int max_size, int* carts_n, float* score,
-                  unsigned int* path_hash, float* shapes) {
+                  unsigned int* path_hash, float* shapes) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
@@ -250,10 +293,10 @@ int jdaTraceBatch(void* cascador, const unsigned char* const* frames, int n, int
   if (!run_device<float>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.f, nullptr, nullptr, &tr, &rs,
                          HostFrames{frames, (size_t)width * height})) return -1;
   return 0;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int height,
-                    unsigned char* half, int* hw, int* hh, unsigned char* quarter, int* qw, int* qh) {
+                    unsigned char* half, int* hw, int* hh, unsigned char* quarter, int* qw, int* qh) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !data || width <= 0 || height <= 0) { fail("bad arguments"); return -1; }
@@ -279,11 +322,11 @@ int jdaBuildPyramid(void* cascador, const unsigned char* data, int width, int he
   };
   if (!one(half, w1, h1) || !one(quarter, w2, h2)) return -1;
   return 0;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                      int minimum_size, int step, double factor, int* carts_n, double* score,
-                     unsigned int* path_hash, double* shapes) {
+                     unsigned int* path_hash, double* shapes) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || n < 0) { fail("bad arguments"); return -1; }
@@ -303,9 +346,9 @@ int jdaTraceBatchCpp(void* cascador, const unsigned char* const* frames, int n, 
   if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, nullptr, &tr, &rs,
                           HostFrames{frames, (size_t)width * height})) return -1;
   return 0;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
-int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height, unsigned char* out, int ow, int oh) {
+int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height, unsigned char* out, int ow, int oh) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !data || !out || width <= 0 || height <= 0 || ow <= 0 || oh <= 0) { fail("bad arguments"); return -1; }
@@ -325,11 +368,11 @@ int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height
     return true;
   };
   return run() ? 0 : -1;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                              int origin_size, int step, double factor, double overlap, int nms,
-                             jdaStats* stats, jdaResultD* out) {
+                             jdaStats* stats, jdaResultD* out) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
@@ -428,24 +471,24 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
   }, total < 6000);
   fill_stats(stats, rs_total, patch_total, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
-int jdaNmsC(const int* bboxes, const float* scores, int n, float overlap, unsigned char* keep) {
+int jdaNmsC(const int* bboxes, const float* scores, int n, float overlap, unsigned char* keep) try {
   if (n < 0 || (n > 0 && (!bboxes || !scores || !keep))) return -1;
   std::vector<int> k = nms_dialect_c(bboxes, scores, n, overlap);
   std::memset(keep, 0, (size_t)n);
   for (int i : k) keep[i] = 1;
   return (int)k.size();
-}
+} JDA_ABI_CATCH(-1)
 
-int jdaNmsCpp(const int* rects, const double* scores, int n, double overlap, int* picked) {
+int jdaNmsCpp(const int* rects, const double* scores, int n, double overlap, int* picked) try {
   if (n < 0 || (n > 0 && (!rects || !scores || !picked))) return -1;
   std::vector<int> k = nms_dialect_cpp(rects, scores, n, overlap);
   std::copy(k.begin(), k.end(), picked);
   return (int)k.size();
-}
+} JDA_ABI_CATCH(-1)
 
-int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* rows, int capacity_rows) {
+int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* rows, int capacity_rows) try {
   if (!results || n < 0) return -1;
   long long total = 0;
   for (int i = 0; i < n; i++) total += results[i].n;
@@ -464,7 +507,7 @@ int jdaResultsPack(const jdaResult* results, int n, int frame_offset, float* row
     }
   }
   return (int)total;
-}
+} JDA_ABI_CATCH(-1)
 
 void jdaResultsRelease(jdaResult* results, int n) {
   if (!results) return;
@@ -476,7 +519,7 @@ void jdaResultsRelease(jdaResult* results, int n) {
 
 // Tile plan of a dialect-C call without touching a device (tests, tools): per level 10 ints
 // {win, step, nx, ny, mode, tw, th, pitch, tiles_x, tiles_y}.  Returns the number of levels.
-int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int min_size, int max_size, int* out, int cap_levels) {
+int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int min_size, int max_size, int* out, int cap_levels) try {
   Cascador* c = (Cascador*)cascador;
   if (!c) return -1;
   ScanPlan sp; std::string err;
@@ -493,7 +536,7 @@ int jdaDebugPlanTiles(void* cascador, int width, int height, float scale, int mi
     std::memcpy(out + 10 * i, v, sizeof v);
   }
   return pe.hp.n_levels;
-}
+} JDA_ABI_CATCH(-1)
 
 long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int real_bytes) {
   return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
@@ -516,7 +559,7 @@ void jdaResultDRelease(jdaResultD result) {
 
 int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n, int width, int height,
                       int minimum_size, int step, double factor, double overlap, int nms,
-                      jdaStats* stats, jdaResultD* out) {
+                      jdaStats* stats, jdaResultD* out) try {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
@@ -573,6 +616,6 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
   }, dets.gid.size() < 6000);
   fill_stats(stats, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
-}
+} JDA_ABI_CATCH_SYNC(-1)
 
 }  // extern "C"

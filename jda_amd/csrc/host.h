@@ -21,6 +21,8 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -106,6 +108,7 @@ inline long long env_ll(const char* name, long long dflt) {
   X(predict, "JDA_PREDICT", 1)              /* size the finishing launches from the previous pass (no host round trip) */ \
   X(debug_times, "JDA_DEBUG_TIMES", 0)                                                                 \
   X(test_wpf_scale, "JDA_TEST_WPF_SCALE", 1) /* test hook of the 32-bit window-id guard */             \
+  X(test_throw, "JDA_TEST_THROW", 0)        /* test hook of the C ABI's exception barrier (abi.cpp): 1 = std::bad_alloc, 2 = std::runtime_error inside jdaDetectBatch */ \
   X(lanes, "JDA_LANES", 2)                  /* sub-batch lanes of one synchronous call */               \
   X(lanes_min_windows, "JDA_LANES_MIN_WINDOWS", 2000000)                                               \
   X(host_chunk, "JDA_HOST_CHUNK", 128)      /* frames per sub-batch when the frames come from host memory */ \
@@ -334,10 +337,21 @@ struct Lane {
   // The memory of a lane nobody has used for a while (a burst of concurrent callers leaves lanes behind, each with a
   // workspace of up to workspace_mb): everything that is re-created on demand.  The lane is free and its holder has
   // collected what ran on it, so nothing is in flight.
-  void trim() {
-    ws.release(); frames.release(); pyr.release(); rag_frames.release(); rag_raw.release(); rag_tab.release();
-    h_gid.release(); h_score.release(); h_shape.release(); h_tab.release(); h_raw.release();
-    h_pn.release(); h_pbb.release(); h_psc.release(); h_psh.release();
+  // With a bag, the buffers are only MOVED out (pointer swaps: the caller holds Cascador::mu) and released when the
+  // bag goes out of scope, after the mutex -- hipFree / hipHostFree of gigabytes synchronise the device and take
+  // milliseconds, in which every other caller would stand in front of the plan cache and the lane pool.
+  struct Bag {
+    std::vector<void*> dev, host;
+    Bag() = default;
+    Bag(const Bag&) = delete;
+    Bag& operator=(const Bag&) = delete;
+    ~Bag() { for (void* p : dev) (void)hipFree(p); for (void* p : host) (void)hipHostFree(p); }
+  };
+  void trim(Bag* bag = nullptr) {
+    DevBuf* db[] = {&ws, &frames, &pyr, &rag_frames, &rag_raw, &rag_tab};
+    HostPinned* hb[] = {&h_gid, &h_score, &h_shape, &h_tab, &h_raw, &h_pn, &h_pbb, &h_psc, &h_psh};
+    for (DevBuf* b : db) { if (bag && b->p) { bag->dev.push_back(b->p); b->p = nullptr; b->bytes = 0; } else b->release(); }
+    for (HostPinned* b : hb) { if (bag && b->p) { bag->host.push_back(b->p); b->p = nullptr; b->bytes = 0; } else b->release(); }
     cap = 0; trace = false; dim = 0; real_bytes = 0;
     wf = WorkT<float>{}; wd = WorkT<double>{};
   }
@@ -404,7 +418,7 @@ template <> struct Sel<double> {
 // Makes the cascador's device current for the calling thread; first use picks the device (caller holds c->mu then).
 bool ensure_device(Cascador* c);
 // A free lane (caller holds c->mu), see lanes.cpp.
-Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted = nullptr);
+Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted, Lane::Bag* trimmed);
 
 // The lanes a call holds; given back when it leaves.
 struct LaneSet {
@@ -418,6 +432,7 @@ struct LaneSet {
   // two callers can never wait for each other's lanes.  all = true (a caller that holds none and needs all n, at most
   // max_lanes of them): waits until it can have them all at once.
   bool take(int n, size_t want_cap = 0, bool all = false) {
+    Lane::Bag trimmed;                     // (declared before the lock: released after it, see Lane::trim)
     std::unique_lock<std::mutex> lk(c->mu);
     const int cap_lanes = (int)std::max<long long>(1, c->kn.max_lanes);
     if (all && v.empty()) {
@@ -431,7 +446,7 @@ struct LaneSet {
     }
     while ((int)v.size() < n) {
       bool exhausted = false;
-      Lane* l = acquire_lane_locked(c, want_cap, &exhausted);
+      Lane* l = acquire_lane_locked(c, want_cap, &exhausted, &trimmed);
       if (!l) {
         if (!exhausted) return false;
         if (!v.empty()) return true;

@@ -31,7 +31,18 @@ namespace {
 constexpr int kPSlotsMax = 8;          // slot index: 3 bits of an item
 constexpr int kPWidxBits = 11;         // window index inside the tile: up to 2048 windows per tile
 constexpr int kPBaseBits = 18;         // LDS byte offset of the window's first pixel
-constexpr int kPSpinMax = 1 << 20;     // watchdog of every wait loop (a wait is microseconds; this is a large fraction of a second)
+// Watchdogs of the two wait loops (a wait is microseconds; these are a large fraction of a second).  Neither loop can
+// hang the device, and neither ends quietly: a trip sets a bit of the counters' error word (kCntScanErr) and the host,
+// which also compares the windows covered with the plan's, runs the pass again with k_scan (pass.h: recover_scan).
+// A wave that trips never publishes anything half done: an idle wave just leaves; a ring commit that times out is NOT
+// committed out of order (its items are lost to the launch, later reservations time out behind it, the slots they
+// reference never drain and the remaining waves leave through the idle watchdog) -- so a tripped launch loses
+// windows, it never hands a corrupt item to the finishing kernels.
+constexpr int kPSpinMax = 1 << 20;     // ring commit
+#ifndef JDA_SCAN_P_IDLE_MAX
+#define JDA_SCAN_P_IDLE_MAX (1 << 20)  // (tests build a variant with 0: every wave that idles once leaves -> the fallback runs)
+#endif
+constexpr int kPIdleMax = JDA_SCAN_P_IDLE_MAX;
 
 struct ThNormF { float th, norm; };
 
@@ -43,8 +54,10 @@ struct ThNormF { float th, norm; };
 typedef int v4i __attribute__((ext_vector_type(4)));
 struct PCtl {
   v4i rec[24];
-  //   rec[s], s < 8        slot:  x state (0 free, 1 being loaded, 2 published), y generation << 12 | next fresh batch,
-  //                               z batches, w references (fresh batches not finished + items alive)
+  //   rec[s], s < 8        slot:  x claim generation << 2 | state (0 free, 1 being loaded, 2 published), y generation << 12 | next
+  //                               fresh batch, z batches, w references (fresh batches not finished + items alive).  The state
+  //                               word carries a generation so that a claim's compare-and-swap, made on a snapshot that has
+  //                               gone stale, cannot succeed on a slot another wave has claimed AND republished meanwhile
   //   rec[8 + b], b < 6    ring:  x committed, y popped, z reserved
   //   rec[14]              x next tile (sequence number inside this workgroup's share) to bring in
   //   rec[16 + s]          slot geometry: x twe | the << 16, y xshift, z frame, w wx0 | wy0 << 16
@@ -355,6 +368,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
 
   unsigned my_carts = 0, handed = 0, win_cov = 0, mids = 0;
   int idle_spins = 0;
+  unsigned long long* const scan_err = w.counters + (size_t)kCntScanErrShard * kCntStride + kCntScanErr;
 
   const int C = CF(kCfCap);                            // items per ring (a power of two)
   // survivors -> ring b, if it has room (reserved by compare-and-swap against the pop counter); false: no room
@@ -378,8 +392,13 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
       rings[b * C + ((start + rank) & (C - 1))] = make_uint2(packed, __float_as_uint(score));
     }
     lds_drain();
-    for (int spin = 0; ld_relaxed(rw) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
+    int spin = 0;
+    for (; ld_relaxed(rw) != start && spin < kPSpinMax; spin++) __builtin_amdgcn_s_sleep(1);   // commit in reservation order
     compiler_fence();
+    if (spin >= kPSpinMax) {               // (never seen; see kPSpinMax above: reported, not committed)
+      if (lane == 0) atomicOr(scan_err, 2ull);
+      return true;
+    }
     if (lane == 0) st_relaxed(rw, start + n);
     JDA_PSUB_END(8);
     return true;
@@ -432,19 +451,20 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
         const bool is_slot = lane < S, is_ring = (unsigned)(lane - kRecRing) < (unsigned)NB;
         const int bidx = r.y & 0xfff;
         const int avail_v = r.x - r.y;
-        const unsigned m_dr = (unsigned)__ballot(is_slot && (r.x == 0 || (r.x == 2 && bidx >= r.z && r.w == 0)));
-        const unsigned m_fr = (unsigned)__ballot(is_slot && r.x == 2 && bidx < r.z);
+        const int sx = r.x & 3;            // (slot lanes: the state; r.x >> 2 is the claim generation)
+        const unsigned m_dr = (unsigned)__ballot(is_slot && (sx == 0 || (sx == 2 && bidx >= r.z && r.w == 0)));
+        const unsigned m_fr = (unsigned)__ballot(is_slot && sx == 2 && bidx < r.z);
         const unsigned m_full = (unsigned)__ballot(is_ring && avail_v >= need_v);
         const int next_j = __builtin_amdgcn_readlane(r.x, kRecMisc);
         int task = -1;                     // 0 fresh, 1 ring, 2 tile load
-        int t_b = 0, t_n = 0, t_s = 0, t_j = 0, t_gen = 0;
+        int t_b = 0, t_n = 0, t_s = 0, t_j = 0, t_gen = 0, t_xg = 0;
         uint2 t_it = make_uint2(0u, 0u);
         bool lost = false;                 // a compare-and-swap went to another wave: look again
         unsigned m_ring = m_full;
         if (!(next_j < n_my && m_dr != 0u) && m_full == 0u && m_fr == 0u) {
           // nothing fresh, no full ring task.  While a tile is on its way: wait.  Else every slot waits for its last
           // windows (or the launch is ending): whatever the deepest ring holds.
-          const unsigned m_ld = (unsigned)__ballot(is_slot && r.x == 1);
+          const unsigned m_ld = (unsigned)__ballot(is_slot && sx == 1);
           if (m_ld == 0u) m_ring = (unsigned)__ballot(is_ring && avail_v > 0);
         }
         if (next_j < n_my && m_dr != 0u) {
@@ -452,8 +472,8 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           const int s = __builtin_ctz(m_dr);
           const int stt = __builtin_amdgcn_readlane(r.x, s);
           int got = 0;
-          if (lane == 0) got = (atomicCAS(recw + 4 * s, stt, 1) == stt) ? 1 : 0;
-          if (uni(got)) { task = 2; t_s = s; t_gen = (__builtin_amdgcn_readlane(r.y, s) >> 12) + 1; }
+          if (lane == 0) got = (atomicCAS(recw + 4 * s, stt, (stt & ~3) | 1) == stt) ? 1 : 0;
+          if (uni(got)) { task = 2; t_s = s; t_gen = (__builtin_amdgcn_readlane(r.y, s) >> 12) + 1; t_xg = (int)((((unsigned)stt >> 2) + 1u) & 0x1fffffffu) << 2; }
           else lost = true;
         } else if (m_ring != 0u) {
           // ---- the deepest ring that holds a full task (or, draining, anything).  The items are read BEFORE the
@@ -496,7 +516,10 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           if (lost) { __builtin_amdgcn_s_sleep(2); JDA_PCAT(6); continue; }
           // ---- nothing to do: finished when every tile has been brought in and every slot has drained ----
           if (next_j >= n_my && (m_dr & slot_bits) == slot_bits) break;
-          if (++idle_spins > kPSpinMax) break;           // (watchdog: a scheduling bug must not hang the device)
+          if (++idle_spins > kPIdleMax) {                // (watchdog: a scheduling bug must not hang the device -- nor pass unseen)
+            if (lane == 0) atomicOr(scan_err, 1ull);
+            break;
+          }
           __builtin_amdgcn_s_sleep(16);
           JDA_PCAT(4);
           continue;
@@ -532,7 +555,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           if (!have) {
             if (lane == 0) { recw[4 * s + 2] = 0; recw[4 * s + 3] = 0; }
             lds_drain();
-            st_relaxed(recw + 4 * s, 0);
+            st_relaxed(recw + 4 * s, t_xg | 0);
           } else {
             const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
             const int wx0 = tx * lv.tw, wy0 = ty * TH;
@@ -551,7 +574,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
             win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile has landed, the slot record too
             st_relaxed(recw + 4 * s + 1, (t_gen & 0x7ffff) << 12);
-            st_relaxed(recw + 4 * s, 2);
+            st_relaxed(recw + 4 * s, t_xg | 2);
           }
           JDA_PCAT(3);
           continue;

@@ -191,8 +191,11 @@ enum Counter : int {
   kCntTotal = kMaxStages + 7,
   // spare words of a shard: [kCntTotal, kCntMidScan) deal k_scan_p's tiles (PScanCfg::dyn_slot, shards 0..7)
   kCntMidScan = kCntStride - 1,    // windows k_scan_p put into the mid queue itself (they count as handed off)
-  kCntPostCursor = kCntTotal       // shard 8 only: rows k_post has allotted (shards 0..7 use this word to deal tiles)
+  kCntPostCursor = kCntTotal,      // shard 8 only: rows k_post has allotted (shards 0..7 use this word to deal tiles)
+  kCntScanErr = kCntTotal          // shard 9 only: k_scan_p's watchdog word (bit 0: a wave gave up waiting for work that never came,
+                                   // bit 1: a ring commit timed out) -- nonzero: the host runs the pass again with k_scan
 };
+constexpr int kCntScanErrShard = 9;
 static_assert(kCntTotal <= kCntStride, "counter shard too small");
 
 // ---- launchers (k_misc.hip, k_scan.hip, k_finish.hip, k_stage.hip) ------------------------------------------------

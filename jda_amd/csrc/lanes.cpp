@@ -34,8 +34,9 @@ bool ensure_device(Cascador* c) {
 // A free lane (caller holds c->mu): the one whose workspace fits `want_cap` windows most tightly, else the largest,
 // else a new one -- unless the pool has reached max_lanes: then nullptr with *exhausted set (the caller waits for a
 // lane to come back, or goes on with the lanes it holds).  Free lanes that were passed over `lane_idle_calls` times
-// give their buffers back.
-Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted) {
+// give their buffers back: into `trimmed`, which the caller lets go out of scope AFTER it has released c->mu (the
+// frees synchronise the device; no device work runs under the mutex).
+Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted, Lane::Bag* trimmed) {
   Lane* best = nullptr;
   for (auto& up : c->lanes) {
     Lane* l = up.get();
@@ -55,7 +56,7 @@ Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted) {
   for (auto& up : c->lanes) {
     Lane* l = up.get();
     if (l->busy || l == best) continue;
-    if (idle_max > 0 && ++l->idle > (unsigned long long)idle_max && (l->ws.p || l->frames.p || l->rag_frames.p)) l->trim();
+    if (idle_max > 0 && ++l->idle > (unsigned long long)idle_max && (l->ws.p || l->frames.p || l->rag_frames.p)) l->trim(trimmed);
   }
   best->busy = true;
   best->idle = 0;

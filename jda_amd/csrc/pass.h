@@ -41,6 +41,9 @@ struct Pass {
   bool want_post = false, post_nms = true; float post_overlap = 0.3f;   // the caller takes device-post-processed frames (RawDets::p_*)
   bool post_issued = false, posted = false; size_t post_cap = 0;         // k_post queued for this pass / its results are good
   bool mid_direct = false;         // a scan launch of this pass put stage-0 survivors into the mid queue itself (k_scan_p up to cart K)
+  bool no_scan_p = false;          // this pass has been started over without k_scan_p (recover_scan): its watchdog tripped or it covered too few windows
+  int my_scan_launches = 0;        // scan launches of this pass counted into rs so far
+  uint8_t* a_hbuf = nullptr; size_t a_hs = 0; uint8_t* a_qbuf = nullptr; size_t a_qs = 0;   // issue_scan's arguments (recover_scan issues it again)
   long long n_tail = -1;
   size_t n_out = 0, out_copied = 0;   // detections of the pass / how many of them are already on their way to the host
 
@@ -129,7 +132,7 @@ struct Pass {
   bool scan_persistent(int level, hipStream_t s) {
     if constexpr (sizeof(Real) != 4) { (void)level; (void)s; return false; }
     else {
-      if (!kn().scan_p || want_trace()) return false;
+      if (!kn().scan_p || want_trace() || no_scan_p) return false;
       const DevModelT<Real>& m = model();
       const DevLevel& lv = pe->hp.lv[level];
       if (lv.win > kn().scan_p_win_max) return false;
@@ -210,6 +213,7 @@ struct Pass {
   bool issue_scan(uint8_t* hbuf, size_t hs, uint8_t* qbuf, size_t qs, hipEvent_t scan_after) {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
+    a_hbuf = hbuf; a_hs = hs; a_qbuf = qbuf; a_qs = qs;
     if (timed) JDA_HIP(hipEventRecord(ev[0], st));
     if (rag) return issue_scan_ragged();
     if (host_frames && !upload_frames(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes)) return false;
@@ -261,9 +265,9 @@ struct Pass {
         // (opts bit 0, 8 trees in flight per lane in the LDS-tiled modes, was measured neutral to slower: off)
         const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
                          (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
-        if (mode == 1 && level >= 0 && scan_persistent(level, s)) { rs->scan_launches++; return true; }
+        if (mode == 1 && level >= 0 && scan_persistent(level, s)) { rs->scan_launches++; my_scan_launches++; return true; }
         JDA_HIP(launch_scan<Real>(mode, level, want_trace(), handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, s));
-        rs->scan_launches++;
+        rs->scan_launches++; my_scan_launches++;
         return true;
       };
       // the global-pixel launch of a lone lane goes to a side stream, forked here and joined before the
@@ -531,6 +535,15 @@ struct Pass {
       for (int i = 0; i < kCntTotal; i++) h_cnt[i] += h_cnt[shd * kCntStride + i];
       h_cnt[kCntMidScan] += h_cnt[shd * kCntStride + kCntMidScan];
     }
+    if (p_launches > 0 && !dense && !no_scan_p) {
+      // The persistent scan ran in this pass: did its watchdogs stay quiet, and did it cover every window it was given?
+      // (k_scan_p.hip: a tripped launch loses windows, it never corrupts one -- so the check is a count)
+      const unsigned long long err = h_cnt[(size_t)kCntScanErrShard * kCntStride + kCntScanErr];
+      long long expect = 0;
+      for (int l = 0; l < pe->hp.n_levels; l++)
+        if (pe->hp.lv[l].tiled != 0) expect += (long long)pe->hp.lv[l].nx * pe->hp.lv[l].ny * nf;
+      if (err != 0 || (long long)h_cnt[kCntWinScan] != expect) return recover_scan(err, (long long)h_cnt[kCntWinScan], expect);
+    }
     rs->carts += (long long)h_cnt[kCntCarts];
     rs->carts_scan += (long long)h_cnt[kCntCartsScan];
     rs->carts_scan_glb += (long long)h_cnt[kCntCartsScanGlb];
@@ -570,6 +583,24 @@ struct Pass {
       if (posted) return true;                 // (nothing else to fetch: the frames' results are in pinned memory)
     }
     if (n_out > out_copied && !issue_results(out_copied, n_out)) return false;   // the prediction fell short (or there was none)
+    return true;
+  }
+
+  // The persistent scan of this pass gave up (watchdog) or came back short: nothing of the pass has been counted or
+  // collected yet, so the whole pass is issued again on the same lane with k_scan's closed tiles, and the caller gets
+  // correct results plus a note in jdaGetLastError() / on stderr (the call itself succeeds).
+  bool recover_scan(unsigned long long err, long long got, long long expect) {
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "k_scan_p: watchdog word %llu, %lld of %lld windows covered -- pass of %d frame(s) run again with k_scan",
+                  err, got, expect, nf);
+    std::fprintf(stderr, "libjda: %s\n", msg);
+    no_scan_p = true;
+    rs->scan_launches -= my_scan_launches; my_scan_launches = 0;
+    dense = false; finished = false; lds_span = false; predicted = false; counters_issued = false; results_pending = false;
+    p_launches = 0; post_issued = false; posted = false; post_cap = 0; mid_direct = false; n_tail = -1; n_out = 0; out_copied = 0;
+    host_frames = nullptr;                 // (already in the staging buffer)
+    if (!issue_scan(a_hbuf, a_hs, a_qbuf, a_qs, nullptr) || !after_tail() || !issue_counters() || !after_counters()) return false;
+    g_err = msg;
     return true;
   }
 

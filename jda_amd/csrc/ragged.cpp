@@ -475,8 +475,19 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
     int ready = 0;                 // chunks [0, ready) are on the device
     bool failed = false, stop = false;
     std::string err;
-    ~Uploader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } if (th.joinable()) th.join(); }
+    Cascador* c = nullptr;
+    // Leaving the job (also on its error paths, before the lanes go back to the pool and the caller frees its images):
+    // the helper is stopped and joined, and whatever it had queued on the cascador's upload stream -- a copy out of the
+    // caller's memory or a lane's pinned buffer into a lane's device buffer -- is waited for.
+    ~Uploader() {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      if (!th.joinable()) return;
+      th.join();
+      std::lock_guard<std::mutex> lk(c->h2d_mu);
+      if (c->h2d) (void)hipStreamSynchronize(c->h2d);
+    }
   } up;
+  up.c = c;
   if (helper && n_chunks > 1 && lanes > 1 && held.v[0]->rag_raw.reserve(tight[n] + 16)) {
     size_t most = 0;
     job.raw_off.assign(n_chunks + 1, 0);

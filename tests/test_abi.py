@@ -154,3 +154,32 @@ def test_options_round_trip_and_start_from_the_environment(built, model_file, mo
         c.set_option("no_such_option", 1)
     assert api.lib.jdaGetOption(c.h, b"no_such_option") == -1
     c.close(); c2.close()
+
+
+def test_no_exception_crosses_the_c_abi(built, tmp_path):
+    """Reference behaviour on an allocation failure: NULL / nothing, never a crash (c/jda.c:487-493).  Every extern "C"
+    entry of abi.cpp is a function-try-block; the `test_throw` option makes jdaDetectBatch throw inside it -- the call
+    returns -1 (jdaDetect: an empty result), jdaGetLastError says why, and the process lives."""
+    import numpy as np
+    from jda_amd import api, synth
+    p = str(tmp_path / "m.model")
+    synth.make_model(2, 8, 5, 3, seed=1).save(p, 8)
+    c = api.Cascador(p)
+    frames = synth.make_frames(2, 64, 48, seed=1)
+    for code, text in ((1, "out of host memory"), (2, "injected by test_throw")):
+        c.set_option("test_throw", code)
+        with pytest.raises(api.JdaError, match=text):
+            c.detect_batch(frames)
+        assert "jdaDetectBatch" in api.last_error()
+        img = np.ascontiguousarray(frames[0])
+        r = api.lib.jdaDetect(c.h, img.ctypes.data_as(C.POINTER(C.c_ubyte)), 64, 48, 1.25, 0.1, 24, -1, -0.5)
+        assert r.n == 0 and r.landmark_n == 5 and text in api.last_error()
+        api.lib.jdaResultRelease(r)
+    c.set_option("test_throw", 0)
+    # the cascador is still usable: nothing was left locked or pinned by the unwinding
+    assert c.get_option("test_throw") == 0
+    c.set_option("handoff", 64)
+    c.close()
+    # a model file that cannot be read is NULL + a reason, as before
+    with pytest.raises(api.JdaError):
+        api.Cascador(str(tmp_path / "missing.model"))

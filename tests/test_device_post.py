@@ -97,3 +97,52 @@ def test_submit_wait_tickets_use_it_too(built, gpu, model_file):
                 assert same(a[key], b[key]), (k, key)
     assert sum(len(w["scores"]) for w in want) > 48
     c.close()
+
+
+def test_ragged_chunks_posted_and_declined(built, gpu, model_file):
+    """The ragged branch of k_post (an image's gids are one range of the chunk, its window grids are re-derived on the
+    device from its size) against the host form, bit for bit: images of mixed sizes in several chunks, one too small
+    for any window (n_lv == 0), a flat image whose 1,998 windows all pass with ONE score (crowded and tied: its chunk
+    is declined and goes through the host form while the other chunks are posted), a small flat image (ties replayed
+    literally on the device), from host memory and from one packed device buffer."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 20, 5, 4), 8, seed=2, cart_th=-0.5, norm_every=5)
+    base = synth.make_frames(8, 200, 150, seed=22)
+    rng = np.random.default_rng(4)
+    imgs = []
+    for i in range(64):
+        w, h = int(rng.integers(120, 201)), int(rng.integers(100, 151))
+        imgs.append(np.ascontiguousarray(base[i % 8][:h, :w]))
+    imgs[5] = np.ascontiguousarray(base[0][:20, :20])                 # no window fits
+    imgs[9] = np.full((150, 200), 128, np.uint8)                      # every window passes, every score equal
+    imgs[44] = np.full((60, 70), 90, np.uint8)                        # a handful of tied detections
+    c = api.Cascador(p)
+    c.set_option("ragged_chunk_windows", 25000); c.set_option("ragged_chunk_min_windows", 1000)
+    c.set_option("device_post_min_frames", 4)
+    offs, tot = [], 0
+    for im in imgs:
+        offs.append(tot); tot += im.size
+    buf = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).cuda()
+    ws, hs = [im.shape[1] for im in imgs], [im.shape[0] for im in imgs]
+    for nms in (True, False):
+        c.set_option("device_post", 0)
+        host = [c.detect_ragged(imgs, th=-0.5, nms=nms) for _ in range(2)][-1]
+        c.set_option("device_post", 1)
+        for rep in range(3):                                          # (the first job on a plan has no prediction: host form)
+            for got in (c.detect_ragged(imgs, th=-0.5, nms=nms), c.detect_ragged_packed(buf, offs, ws, hs, th=-0.5, nms=nms)):
+                assert len(got) == len(host) == 64
+                for i, (a, b) in enumerate(zip(host, got)):
+                    for k in ("bboxes", "scores", "shapes"):
+                        assert same(a[k], b[k]), (nms, rep, i, k, len(a["scores"]), len(b["scores"]))
+        assert len(host[5]["scores"]) == 0
+        if not nms:
+            assert len(host[9]["scores"]) == 1998 and len(np.unique(host[9]["scores"])) == 1
+            assert 0 < len(host[44]["scores"]) <= 256 and len(np.unique(host[44]["scores"])) == 1
+    # per image the ragged job is jdaDetect on that image
+    full = c.detect_ragged(imgs, th=-0.5)
+    for i in (0, 9, 44, 63):
+        one = c.detect(imgs[i], th=-0.5)
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(one[k], full[i][k]), (i, k)
+    c.close()

@@ -121,3 +121,67 @@ def test_persistent_scan_is_what_a_large_batch_runs_by_default(built, gpu, model
     assert _same_dets(ref, got) and _same_dets(ref, got2)
     for k in STAT_KEYS:
         assert st[k] == s1[k] == s2[k], (k, st[k], s1[k], s2[k])
+
+
+WD_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from jda_amd import api, synth
+assert api.LIB_PATH.endswith("libjda_wd.so"), api.LIB_PATH
+frames = torch.from_numpy(synth.make_frames(%(n)d, 640, 480, seed=77)).cuda()
+c = api.Cascador(%(model)r)
+out = {}
+for name, call in (("sync", lambda: c.detect_batch_device(frames, stats=True)),
+                   ("ticket", lambda: c.wait_batch(c.submit_batch_device(frames), stats=True))):
+    dets, st = call()
+    err = api.last_error()
+    out[name] = {"err": err, "scan_patch_n": st["scan_patch_n"], "patch_n": st["patch_n"], "cart_total_n": st["cart_total_n"],
+                 "n": [len(d["scores"]) for d in dets],
+                 "digest": [__import__("hashlib").sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in dets]}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_a_tripped_watchdog_is_noticed_and_the_pass_rerun(gpu, tmp_path):
+    """k_scan_p's wait loops have watchdogs (a scheduling bug must not hang the device).  A launch that trips one loses
+    windows; it used to return them short with rc 0.  Now the kernel sets an error word, the host also compares the
+    windows covered with the plan's, and either way runs the pass again with k_scan's closed tiles: correct results,
+    a note on stderr and in jdaGetLastError().  libjda_wd.so (jda_amd/build.py:build_watchdog) is the product with the
+    idle watchdog of k_scan_p.hip at zero -- every persistent launch trips it."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    import torch
+    from jda_amd import api, synth, build as lib_build
+    wd = lib_build.build_watchdog()
+    n = 64
+    path = os.path.join(synth.cache_dir(), "wd_%d_%d_%d_%d.model" % S_DIMS)
+    if not os.path.exists(path):
+        m = synth.make_model(*S_DIMS, seed=5)
+        synth.calibrate_thresholds(m, synth.make_frames(2, 640, 480, seed=78))
+        m.save(path + ".tmp", 8); os.replace(path + ".tmp", path)
+    frames = torch.from_numpy(synth.make_frames(n, 640, 480, seed=77)).to(gpu)
+    old = dict(os.environ); os.environ["JDA_SCAN_P"] = "0"
+    try:
+        c = api.Cascador(path)
+    finally:
+        os.environ.clear(); os.environ.update(old)
+    want, st = c.detect_batch_device(frames, stats=True)
+    c.close()
+    assert sum(len(d["scores"]) for d in want) > 0
+    env = dict(os.environ, JDA_LIB_PATH=wd, JDA_SCAN_P="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", WD_SCRIPT % dict(root=root, n=n, model=path)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert "run again with k_scan" in r.stderr, r.stderr[-2000:]
+    digest = [hashlib.sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in want]
+    for name in ("sync", "ticket"):
+        g = got[name]
+        assert "k_scan_p: watchdog word" in g["err"], (name, g["err"])
+        assert g["n"] == [len(d["scores"]) for d in want] and g["digest"] == digest, name
+        assert g["scan_patch_n"] == st["scan_patch_n"] == g["patch_n"] and g["cart_total_n"] == st["cart_total_n"], name
