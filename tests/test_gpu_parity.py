@@ -899,7 +899,11 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu(built, gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["achieved"] > 0 and d["regimes"]["cascade"]["detections_after_nms"] > 0
-    assert "gather" in d["config"] and d["fddb_images_per_s"] > 0
+    cfg = d["config"]
+    assert "gather" in cfg and cfg["fddb_images_per_s"] > 0
+    # the first-contact self-test of the gather ran before the timed region (an empty rank, an overflowing rank)
+    assert cfg["dist_selftest"].startswith("ok"), cfg["dist_selftest"]
+    assert 0 < cfg["rank_ms_per_step_min"] <= cfg["rank_ms_per_step_max"] and cfg["rank_ms_per_step_max"] == pytest.approx(d["ms_per_step"])
 
 
 def test_bench_plain_invocation_one_gpu(built, gpu):
@@ -922,7 +926,14 @@ def test_bench_plain_invocation_one_gpu(built, gpu):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert 0 < d["roofline"]["frac"] <= 1
-    assert d["fddb_images_per_s"] > 0 and d["fddb"]["images"] == 2845                 # BASELINE metric: "FDDB images/sec"
+    # the whole BASELINE metric sits in the two objects the driver's record keeps: FDDB images/sec, configs[2] measured
+    # in this run, the regime in which memory traffic is the bound -- as flat scalars
+    cfg, roof = d["config"], d["roofline"]
+    assert cfg["fddb_images_per_s"] > 0 and cfg["fddb_images"] == 2845 and d["fddb"]["images"] == 2845
+    assert cfg["config2_windows_per_s"] > 1e9 and cfg["config2_windows_per_call"] == 32089600 and cfg["config2_frames"] == 256
+    assert cfg["config2_submit_wait_windows_per_s"] > 1e9
+    for k, v in list(cfg.items()) + list(roof.items()):
+        assert v is None or isinstance(v, (int, float, str, bool)), (k, type(v))
 
 
 def test_pipelined_gather_device_path_over_rccl_group_of_one(built, gpu):
