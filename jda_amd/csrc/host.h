@@ -93,6 +93,7 @@ inline long long env_ll(const char* name, long long dflt) {
   X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
   X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
   X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
+  X(wide_conc, "JDA_WIDE_CONC", 1)          /* ... in which a stage's score replay (wave 0) and its regression (waves 1..) run side by side (0: one after the other, rows through LDS) */ \
   X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
   X(h2d_min_bytes, "JDA_H2D_MIN_BYTES", 8 << 20) /* ... for uploads of at least this many bytes */ \
   X(ragged_uploader, "JDA_RAGGED_UPLOADER", 1) /* ragged job from one packed host buffer: a helper thread uploads chunk after chunk */ \

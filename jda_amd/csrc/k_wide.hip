@@ -45,7 +45,7 @@ template <typename DL, bool TRACE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
                                                        WorkT<typename DL::Real> w, int apply_th, typename DL::Real final_th,
                                                        const S0Node* __restrict__ s0_table, int tile_win, int tile_bytes,
-                                                       int lds_budget) {
+                                                       int lds_budget, int conc) {
   using Real = typename DL::Real;
   constexpr bool kCpp = sizeof(Real) == 8;
   constexpr int NW = BLOCK / 64;
@@ -140,6 +140,83 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
       if (tid == 0) misc[0] = -1;
       __syncthreads();
       if (t <= 1) JDA_WSTAMP();
+      // ---- the two dependent chains of a stage side by side (conc; r05): wave 0 replays the score recurrence
+      //      (c/jda.c:395-399; ~23 k clocks for 540 carts) WHILE waves 1.. add the stage's K weight rows to the shape in
+      //      cart order (c/jda.c:404-411; lane = coordinate, rows straight from L2 into registers, one chunk of loads in
+      //      flight behind the chunk being added).  Neither needs the other: both follow from the leaves of the walks.
+      //      A window the replay rejects just drops the sums.  (Before: replay, then row fetch into LDS by all threads,
+      //      then the adds by wave 0 -- 23 k + 11 k + 15 k clocks per stage in sequence, profiles/r03_single_frame_*.) ----
+      if (conc) {
+        const int n_add = (dim + 63) >> 6;
+        const Real* wt = m.w + (size_t)t * K * leaf_n * dim;
+        Real a = 0;
+        const int d = (wv - 1) * 64 + lane;
+        const bool adder = wv >= 1 && wv <= n_add;
+        const bool act = adder && d < dim;
+        if (wv == 0) {
+          int rej = -1;
+          for (int kg = kbeg & ~63; kg < K && rej < 0; kg += 64) {
+            const int k = kg + lane;
+            Real ls = 0, thk = 0, mk = 0, sk = 1;
+            int nrm = 0, lf = 0;
+            if (k < K) {
+              ls = lsc[k]; thk = lth[k]; lf = lfi[k]; nrm = lf >> 7; lf &= 0x7f;
+              if (nrm) { mk = cmean[k]; sk = cstd[k]; }             // (rare: every 10*L-th cart, btcart.cpp:173-181)
+            }
+            const unsigned long long normmask = __ballot(nrm != 0);
+            const int jr = replay_scores<Real, TRACE>(score, hash, ls, thk, mk, sk, normmask, lf, max(0, kbeg - kg), min(64, K - kg));
+            if (jr >= 0) rej = kg + jr;
+          }
+          if (lane == 0) { misc[0] = rej; *(Real*)(misc + 2) = score; if (TRACE) misc[4] = (int)hash; }
+        } else if (adder) {
+          const int dc = act ? d : dim - 1;                      // (idle lanes of the last adding wave repeat a coordinate)
+          a = kCpp ? (Real)0 : sh[dc];
+          const Real* col = wt + dc;
+          constexpr int CH = 24;
+          int k = 0;
+          if (K >= CH) {
+            Real x[CH], y[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) x[q] = col[lbf[q]];
+            for (k = CH; k + CH <= K; k += CH) {
+#pragma unroll
+              for (int q = 0; q < CH; q++) y[q] = col[lbf[k + q]];
+#pragma unroll
+              for (int q = 0; q < CH; q++) a = a + x[q];          // c/jda.c:404-411, in cart order
+#pragma unroll
+              for (int q = 0; q < CH; q++) x[q] = y[q];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; q++) a = a + x[q];
+          }
+          for (; k < K; k++) a = a + col[lbf[k]];
+        }
+        __syncthreads();
+        const int rej = misc[0];
+        score = *(const Real*)(misc + 2);
+        if (TRACE) hash = (unsigned)misc[4];
+        if (t <= 1) JDA_WSTAMP();
+        if (rej >= 0) { alive = false; carts_n = t * K + rej + 1; break; }
+        if (adder) {
+          if (kCpp) {
+            // stp_mc.Apply(delta, delta) with the identity parameter, literally (btcart.cpp:422, data.hpp:42-45), on the
+            // (dx, dy) pair held by lanes d, d^1 (same wave: dim is even)
+            const Real other = __shfl_xor(a, 1);
+            if (act) {
+              a = (d & 1) ? stp.scale * (stp.r10 * other + stp.r11 * a) : stp.scale * (stp.r00 * a + stp.r01 * other);
+              a = sh[d] + a;
+            }
+          }
+          if (act) sh[d] = a;
+        }
+        if (tid == 0) stage_cnt[t] += 1;
+        __syncthreads();
+        JDA_WSTAMP();
+#ifdef JDA_SCAN_TIMING
+        dbg_stages = t + 1;
+#endif
+        continue;
+      }
       // ---- score recurrence, strictly in cart order, by wave 0 (64 carts per block: per-lane values, v_readlane) ----
       if (wv == 0) {
         int rej = -1;
@@ -306,7 +383,7 @@ namespace {
 template <typename DL>
 hipError_t launch_finish_wide_impl(bool trace, bool apply_th, typename DL::Real th, const DevPlan* d_plan,
                                    const DevModelT<typename DL::Real>& m, const WorkT<typename DL::Real>& w,
-                                   long long n_hint, const S0Node* s0_table, hipStream_t stream) {
+                                   long long n_hint, const S0Node* s0_table, hipStream_t stream, bool conc) {
   using Real = typename DL::Real;
   const int budget = 160 * 1024;
   // window tile: as large as leaves room for at least 64 weight rows
@@ -320,10 +397,12 @@ hipError_t launch_finish_wide_impl(bool trace, bool apply_th, typename DL::Real 
   if (L.row_cap < 1 || L.total > budget) return hipErrorInvalidValue;
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>(n_hint, 1 << 16));
   const int block = m.K > 512 ? 1024 : (m.K > 256 ? 512 : 256);
+  // replay and regression side by side: a wave for the replay + one per 64 shape coordinates
+  const bool conc_ok = conc && 1 + (m.dim + 63) / 64 <= block / 64;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(block), L.total, stream, d_plan, m, w, apply_th ? 1 : 0, th, s0_table,
-                       tile_win, tile_bytes, budget);
+                       tile_win, tile_bytes, budget, conc_ok ? 1 : 0);
   };
   auto pick = [&](auto trace_tag) {
     constexpr bool TR = decltype(trace_tag)::value;
@@ -345,14 +424,14 @@ bool finish_wide_ok(int dim, int K, int leaf_n, int real_bytes, bool multi, bool
 template <>
 hipError_t launch_finish_wide<float>(bool trace, bool apply_final_th, float final_th, const DevPlan* d_plan,
                                      const DevModelT<float>& m, const WorkT<float>& w, long long n_hint,
-                                     const S0Node* s0_table, hipStream_t stream) {
-  return launch_finish_wide_impl<DialectC>(trace, apply_final_th, final_th, d_plan, m, w, n_hint, s0_table, stream);
+                                     const S0Node* s0_table, hipStream_t stream, bool conc) {
+  return launch_finish_wide_impl<DialectC>(trace, apply_final_th, final_th, d_plan, m, w, n_hint, s0_table, stream, conc);
 }
 template <>
 hipError_t launch_finish_wide<double>(bool trace, bool apply_final_th, double final_th, const DevPlan* d_plan,
                                       const DevModelT<double>& m, const WorkT<double>& w, long long n_hint,
-                                      const S0Node* s0_table, hipStream_t stream) {
-  return launch_finish_wide_impl<DialectCPP>(trace, apply_final_th, final_th, d_plan, m, w, n_hint, s0_table, stream);
+                                      const S0Node* s0_table, hipStream_t stream, bool conc) {
+  return launch_finish_wide_impl<DialectCPP>(trace, apply_final_th, final_th, d_plan, m, w, n_hint, s0_table, stream, conc);
 }
 
 }  // namespace jda

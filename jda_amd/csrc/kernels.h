@@ -296,7 +296,8 @@ bool finish_wide_ok(int dim, int K, int leaf_n, int real_bytes, bool multi, bool
 template <typename Real>
 hipError_t launch_finish_wide(bool trace, bool apply_final_th, Real final_th, const DevPlan* d_plan,
                               const DevModelT<Real>& m, const WorkT<Real>& w, long long n_hint, const S0Node* s0_table,
-                              hipStream_t stream);
+                              hipStream_t stream, bool conc = true);
+// conc: the stage's score replay (one wave) and its regression (a wave per 64 shape coordinates) run side by side
 
 // Dense mode: stage t for every window of one level, a 16 x 8 tile of windows per workgroup.
 // pix_cap = largest pixel tile that may live in LDS (larger windows read the frame through L1/L2).

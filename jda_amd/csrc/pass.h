@@ -403,7 +403,7 @@ struct Pass {
     if (n_grid <= kn().wide_max && busy_lanes <= kn().wide_busy_max && finish_wide_ok(hm().dim(), hm().K, hm().leaf_n(), (int)sizeof(Real), multi, Sel<Real>::dialect == JDA_DIALECT_CPP && c->similarity)) {
       // a small job (a frame or a few): the call's time is the latency of one window's chain through the stages --
       // every queued window gets a whole workgroup (k_wide.hip)
-      JDA_HIP(launch_finish_wide<Real>(want_trace(), apply_th, th, pe->dp, model(), w, n_grid, s0_tbl(), st));
+      JDA_HIP(launch_finish_wide<Real>(want_trace(), apply_th, th, pe->dp, model(), w, n_grid, s0_tbl(), st, kn().wide_conc != 0));
       finished = true;
       return true;
     }

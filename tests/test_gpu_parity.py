@@ -992,6 +992,15 @@ def test_wide_finish_equals_wave_finish_and_the_oracle(built, gpu, model_file, d
     tw, tv = wide.trace(frames), wave.trace(frames)
     for k in tw:
         assert same(tw[k], tv[k]), k
+    # the wide kernel's two forms: replay and regression side by side (wide_conc = 1, the default) or one after the other
+    seq = api.Cascador(p)
+    seq.set_option("wide_conc", 0)
+    assert wide.get_option("wide_conc") == 1
+    ts, tsc = seq.trace(frames), seq.trace_cpp(frames, 20, 5, 1.2)
+    for k in tw:
+        assert same(tw[k], ts[k]), ("wide_conc", k)
+    for a, b in zip(wide.detect_batch(frames), seq.detect_batch(frames)):
+        _compare_detect(a, b)
     (dw, sw), (dv, sv) = wide.detect_batch(frames, stats=True), wave.detect_batch(frames, stats=True)
     for a, b in zip(dw, dv):
         _compare_detect(a, b)
@@ -1003,6 +1012,7 @@ def test_wide_finish_equals_wave_finish_and_the_oracle(built, gpu, model_file, d
     cw, cv = wide.trace_cpp(frames, 20, 5, 1.2), wave.trace_cpp(frames, 20, 5, 1.2)
     for k in cw:
         assert same(cw[k], cv[k]), ("cpp", k)
+        assert same(cw[k], tsc[k]), ("cpp wide_conc", k)
     r = o.trace_cpp(frames[0], 20, 5, 1.2)
     for k in ("carts_n", "score", "path_hash", "shapes"):
         assert same(r[k], cw[k][:len(r[k])]), ("cpp oracle", k)
