@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 measurement set on the GPU box (outputs under gpurun_out/<tag>/, summaries copied to profiles/ by hand):
-#   gpurun --timeout 1500 -- 'tools/profile_r02.sh r02_p'
+#   gpurun --timeout 1500 -- 'tools/sessions/profile_r02.sh r02_p'
 TAG=${1:-r02_p}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG

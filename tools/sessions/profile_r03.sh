@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement set on the GPU box (outputs under gpurun_out/<tag>/, summaries copied to profiles/ by hand):
-#   gpurun --timeout 2400 -- 'tools/profile_r03.sh r03_p'
+#   gpurun --timeout 2400 -- 'tools/sessions/profile_r03.sh r03_p'
 TAG=${1:-r03_p}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 measurement set on the GPU box (outputs under gpurun_out/<tag>/, summaries copied to profiles/ by hand):
-#   gpurun --timeout 2400 -- 'tools/profile_r04.sh r04_p'
+#   gpurun --timeout 2400 -- 'tools/sessions/profile_r04.sh r04_p'
 TAG=${1:-r04_p}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
@@ -33,7 +33,7 @@ python tools/rocpd_pmc.py $(db sq1) > $O/pmc_sq.txt; python tools/rocpd_pmc.py $
 python tools/pmc_traffic.py $(db cal_f) $(db cal_w) $(db pmc_f) $(db pmc_w) 13 "$TAG: JDA_LANES=1 JDA_SIDE_STREAM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python tools/variants.py ''" > $O/hbm_traffic.json
 find $O -name "*.db" -delete; rm -rf $O/kt1 $O/kt2 $O/pmc_f $O/pmc_w $O/cal_f $O/cal_w $O/sq1 $O/sq2
 # configs[4] all-pass regime: traffic of the weight-row gather (writes gpurun_out/r03_x/{r03_x_allpass.txt, x_allpass_traffic.json})
-bash tools/r03_x.sh > /dev/null 2>&1; cp gpurun_out/r03_x/r03_x_allpass.txt $O/x_allpass.txt; cp gpurun_out/r03_x/x_allpass_traffic.json $O/
+bash tools/sessions/r03_x.sh > /dev/null 2>&1; cp gpurun_out/r03_x/r03_x_allpass.txt $O/x_allpass.txt; cp gpurun_out/r03_x/x_allpass_traffic.json $O/
 # single-frame latency, ragged job
 timeout 300 python tools/latency.py > $O/latency.txt 2>&1
 timeout 600 python tools/ragged_bench.py > $O/ragged.jsonl 2>/dev/null

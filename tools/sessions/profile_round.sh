@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round measurements on the GPU box: bench line, kernel traces, PMC passes.
-#   gpurun --timeout 1500 -- 'tools/profile_round.sh r01_e'
+#   gpurun --timeout 1500 -- 'tools/sessions/profile_round.sh r01_e'
 # Outputs under gpurun_out/<tag>/ ; summaries are made from the rocpd databases by
 # tools/rocpd_summary.py / rocpd_pmc.py / make_traffic_json.py (run them where the files are).
 TAG=${1:-r01_x}

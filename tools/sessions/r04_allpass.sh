@@ -1,6 +1,6 @@
 #!/bin/bash
 # all-pass regime with the shipped dimensions (k_stage, dense mode): kernel trace, SQ and FETCH_SIZE / WRITE_SIZE passes
-#   gpurun -- 'bash tools/r04_allpass.sh'  -> gpurun_out/r04_allpass/*
+#   gpurun -- 'bash tools/sessions/r04_allpass.sh'  -> gpurun_out/r04_allpass/*
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r04_allpass; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp

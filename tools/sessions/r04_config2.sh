@@ -1,6 +1,6 @@
 #!/bin/bash
 # BASELINE configs[2] at its stated size: rates (sync / submit-wait), kernel trace, SQ and FETCH_SIZE / WRITE_SIZE passes
-#   gpurun -- 'bash tools/r04_config2.sh'   -> gpurun_out/r04_config2/*
+#   gpurun -- 'bash tools/sessions/r04_config2.sh'   -> gpurun_out/r04_config2/*
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r04_config2; mkdir -p $O
 cd $R

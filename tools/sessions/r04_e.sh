@@ -19,5 +19,5 @@ cat gpurun_out/${TAG}_timing.log
 fi
 if [ -n "$BENCH" ]; then
 IFS=';' read -ra BS <<< "$BENCH"
-TAG=${TAG}_bench bash tools/r04_bench_ab.sh "${BS[@]}"
+TAG=${TAG}_bench bash tools/sessions/r04_bench_ab.sh "${BS[@]}"
 fi

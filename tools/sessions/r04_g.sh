@@ -5,4 +5,4 @@ for v in "$@"; do
   env $v JDA_LANES=1 JDA_SIDE_STREAM=0 timeout 300 python tools/variants.py "$v" 2>&1 | grep -v amdgpu.ids
 done > gpurun_out/$TAG.log 2>&1
 cat gpurun_out/$TAG.log
-TAG=${TAG}_bench bash tools/r04_bench_ab.sh "$@"
+TAG=${TAG}_bench bash tools/sessions/r04_bench_ab.sh "$@"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: SQ counters of the LDS-tiled scan, k_scan against k_scan_p (one synchronous 256-frame step x 8, serialised launches)
-#   gpurun -- 'TAG=r04_pmc bash tools/r04_pmc.sh "JDA_SCAN_P=0" "JDA_SCAN_P=1"'
+#   gpurun -- 'TAG=r04_pmc bash tools/sessions/r04_pmc.sh "JDA_SCAN_P=0" "JDA_SCAN_P=1"'
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${TAG:-r04_pmc}
 O=$R/gpurun_out/$TAG; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, first contact: the GPU suite, then the default bench line.   gpurun --timeout 1500 -- 'tools/r05_a.sh r05_a'
+# Round 5, first contact: the GPU suite, then the default bench line.   gpurun --timeout 1500 -- 'tools/sessions/r05_a.sh r05_a'
 TAG=${1:-r05_a}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG

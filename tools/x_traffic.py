@@ -61,7 +61,7 @@ rd = None
 if len(sys.argv) >= 6:
     b = per_dispatch(sys.argv[5], "TCC_EA0_RDREQ_sum", "k_finish")
     rd = max(b) if b else None
-rec = {"source": "tools/r03_x.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
+rec = {"source": "tools/sessions/r03_x.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
        "windows": win, "duration_s": xd[big], "algorithmic_bytes": alg, "weight_row_bytes": rows,
        "fetch_size_bytes_as_counted": xs[big] * 1024, "gather_calibration_counted_per_useful_byte": {"w_sized_table": f[0], "1GiB_table": f[1]},
        "traffic_useful_equivalent_bytes": xs[big] * 1024 / f[0],
