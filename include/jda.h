@@ -308,12 +308,23 @@ JDA_API int jdaSetSimilarityTransform(void *cascador, int on);
  * origin_size x origin_size window (config image_size.origin_size, 48 in the shipped
  * config) slides with a pixel step over an image that is shrunk by 1/factor per level
  * ON THE DEVICE with a restatement of cv::resize(INTER_LINEAR); rects are scaled back
- * with truncating int *= double.  scale==0 models only.  PARITY UNPINNED: cv::resize
+ * with truncating int *= double.  scale==0 models only (multi-scale models: jdaDetectBatchCppPyramidMS).  PARITY UNPINNED: cv::resize
  * itself cannot be compared here (no OpenCV), only its restatement in the oracle. */
 JDA_API int jdaDetectBatchCppPyramid(void *cascador, const unsigned char *const *frames, int n,
                                      int width, int height, int origin_size, int step,
                                      double factor, double overlap, int nms,
                                      jdaStats *stats, jdaResultD *out);
+
+/* The same for models with multi-scale split nodes: detectSingleScale resizes EVERY window's ROI to the config's
+ * three sizes (image_size.origin_size / half_size / quarter_size -- 48 / 36 / 24 in the shipped config,
+ * src/jda/cascador.cpp:243-245, common.cpp:129-131); a split node of scale 1 / 2 reads the window's own half / quarter
+ * patch with coordinates scaled by that patch's side (data.cpp:21-51).  The patches are built on the device by the
+ * cv::resize restatement, one per window and scale.  Serves scale==0 models too (the sizes are then unused).
+ * PARITY UNPINNED like the entry above. */
+JDA_API int jdaDetectBatchCppPyramidMS(void *cascador, const unsigned char *const *frames, int n,
+                                       int width, int height, int origin_size, int half_size, int quarter_size,
+                                       int step, double factor, double overlap, int nms,
+                                       jdaStats *stats, jdaResultD *out);
 
 /* The cv::resize(INTER_LINEAR, 8-bit gray) restatement by itself (device kernel), for tests. */
 JDA_API int jdaResizeCv(void *cascador, const unsigned char *data, int width, int height,

@@ -125,6 +125,9 @@ def _load():
                                       C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     lib.jdaDetectBatchCppPyramid.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    if hasattr(lib, "jdaDetectBatchCppPyramidMS"):
+        lib.jdaDetectBatchCppPyramidMS.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     lib.jdaResizeCv.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
     lib.jdaSetSimilarityTransform.argtypes = [C.c_void_p, C.c_int]
     lib.jdaNmsC.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_float, u8p]
@@ -510,8 +513,10 @@ class Cascador:
         out = [_take_d(res[i]) for i in range(n)]
         return (out, st.asdict()) if stats else out
 
-    def detect_batch_cpp_pyramid(self, frames, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, stats=False):
-        """Dialect CPP, detect method 0: the true image pyramid (reference cascador.cpp:216-308)."""
+    def detect_batch_cpp_pyramid(self, frames, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,
+                                 half_size=0, quarter_size=0):
+        """Dialect CPP, detect method 0: the true image pyramid (reference cascador.cpp:216-308).  half_size /
+        quarter_size > 0: jdaDetectBatchCppPyramidMS, the per-window patches of a multi-scale model."""
         frames = np.ascontiguousarray(frames, np.uint8)
         if frames.ndim == 2:
             frames = frames[None]
@@ -519,8 +524,12 @@ class Cascador:
         ptrs = _frame_ptrs(frames)
         res = (jdaResultD * max(n, 1))()
         st = jdaStats()
-        rc = lib.jdaDetectBatchCppPyramid(self.h, ptrs, n, w, h, origin_size, step, factor, overlap, 1 if nms else 0,
-                                          C.byref(st), res)
+        if half_size or quarter_size:
+            rc = lib.jdaDetectBatchCppPyramidMS(self.h, ptrs, n, w, h, origin_size, half_size, quarter_size, step, factor, overlap,
+                                                1 if nms else 0, C.byref(st), res)
+        else:
+            rc = lib.jdaDetectBatchCppPyramid(self.h, ptrs, n, w, h, origin_size, step, factor, overlap, 1 if nms else 0,
+                                              C.byref(st), res)
         if rc != 0:
             raise JdaError(last_error())
         out = [_take_d(res[i]) for i in range(n)]

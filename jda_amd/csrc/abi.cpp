@@ -370,16 +370,21 @@ int jdaResizeCv(void* cascador, const unsigned char* data, int width, int height
   return run() ? 0 : -1;
 } JDA_ABI_CATCH_SYNC(-1)
 
-int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames, int n, int width, int height,
-                             int origin_size, int step, double factor, double overlap, int nms,
-                             jdaStats* stats, jdaResultD* out) try {
+static int detect_cpp_pyramid_impl(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                                   int origin_size, int half_size, int quarter_size, int step, double factor, double overlap, int nms,
+                                   jdaStats* stats, jdaResultD* out) {
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
   const int L = c->hm.L, dim = c->hm.dim();
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   if (origin_size < 1 || step < 1 || !(factor > 1.0)) { fail("origin_size/step must be positive and factor > 1"); return -1; }
-  if (c->hm.multi_scale()) { fail("method 0 supports only scale==0 split nodes (its per-window half/quarter patches are not reproduced)"); return -1; }
+  const bool multi = c->hm.multi_scale();
+  if (multi && (half_size < 1 || quarter_size < 1 || half_size > 4096 || quarter_size > 4096)) {
+    fail("method 0 on a model with scale != 0 split nodes needs the config's half_size and quarter_size: jdaDetectBatchCppPyramidMS "
+         "(jdaDetectBatchCppPyramid serves scale==0 models)");
+    return -1;
+  }
   if (!cpp_model_complete(c)) return -1;
   if (!begin_device(c)) return -1;
   LaneSet lanes(c);
@@ -412,7 +417,9 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
       PlanPin pin{c, pe};
       RawDets<double> dets;
       RunStats rs;
-      if (!run_device<double>(c, lanes, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs)) return false;
+      HostFrames hf;
+      if (multi) { hf.patch_hs = half_size; hf.patch_qs = quarter_size; }
+      if (!run_device<double>(c, lanes, pe, cur, cur_stride, n, false, 0.0, nullptr, &dets, nullptr, &rs, hf)) return false;
       rs_total.carts += rs.carts; rs_total.out += rs.out; rs_total.gpu_ms += rs.gpu_ms; rs_total.scan_ms += rs.scan_ms;
       rs_total.carts_scan += rs.carts_scan; rs_total.win_scan += rs.win_scan; rs_total.scan_launches += rs.scan_launches;
       rs_total.tail += rs.tail;
@@ -471,6 +478,18 @@ int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames,
   }, total < 6000);
   fill_stats(stats, rs_total, patch_total, c->hm.T, c->hm.K, now_ms() - t0);
   return 0;
+}
+
+int jdaDetectBatchCppPyramid(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                             int origin_size, int step, double factor, double overlap, int nms,
+                             jdaStats* stats, jdaResultD* out) try {
+  return detect_cpp_pyramid_impl(cascador, frames, n, width, height, origin_size, 0, 0, step, factor, overlap, nms, stats, out);
+} JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppPyramidMS(void* cascador, const unsigned char* const* frames, int n, int width, int height,
+                               int origin_size, int half_size, int quarter_size, int step, double factor, double overlap, int nms,
+                               jdaStats* stats, jdaResultD* out) try {
+  return detect_cpp_pyramid_impl(cascador, frames, n, width, height, origin_size, half_size, quarter_size, step, factor, overlap, nms, stats, out);
 } JDA_ABI_CATCH_SYNC(-1)
 
 int jdaNmsC(const int* bboxes, const float* scores, int n, float overlap, unsigned char* keep) try {

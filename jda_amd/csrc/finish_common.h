@@ -118,7 +118,14 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   v0->img = w.img_off != nullptr ? w.frames + w.img_off[frame] : w.frames + (size_t)frame * w.frame_stride;   // ragged batch: per-image offset
   v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
   v0->pw = wn;
-  if (multi) {
+  if (multi && w.patch_hs > 0) {
+    // method 0 (cascador.cpp:243-245): the window's own half_size / quarter_size patches, resized from its ROI
+    const DevLevel& lv = plan->lv[0];
+    const size_t wi = (size_t)(y / lv.step) * (size_t)lv.nx + (size_t)(x / lv.step);
+    const int hs = w.patch_hs, qs = w.patch_qs;
+    v1->img = w.half + (size_t)frame * w.half_stride + wi * (size_t)(hs * hs); v1->w = hs; v1->h = hs; v1->ox = 0; v1->oy = 0; v1->pw = hs;
+    v2->img = w.quarter + (size_t)frame * w.quarter_stride + wi * (size_t)(qs * qs); v2->w = qs; v2->h = qs; v2->ox = 0; v2->oy = 0; v2->pw = qs;
+  } else if (multi) {
     v1->img = w.half + (size_t)frame * w.half_stride; v1->w = w.hw; v1->h = w.hh;
     v2->img = w.quarter + (size_t)frame * w.quarter_stride; v2->w = w.qw; v2->h = w.qh;
     if (sizeof(Real) == 4) {

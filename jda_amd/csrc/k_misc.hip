@@ -53,19 +53,12 @@ hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, i
 // 11-bit fixed-point bilinear of OpenCV's 2.4/3.x imgwarp.cpp, with its routing of an exact
 // 2x2 down-scale to the box average.  PARITY UNPINNED (no OpenCV here to compare with);
 // bit-exact against the oracle's restatement of the same algorithm.
-__global__ void k_resize_cv(const uint8_t* __restrict__ src, size_t src_stride, int sw, int sh,
-                            uint8_t* __restrict__ dst, size_t dst_stride, int dw, int dh,
-                            double scale_x, double scale_y, int area_fast) {
-  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int dy = blockIdx.y;
-  const int f = blockIdx.z;
-  if (dx >= dw || dy >= dh) return;
-  const uint8_t* s = src + (size_t)f * src_stride;
-  uint8_t* d = dst + (size_t)f * dst_stride;
+// One output pixel (dx, dy) of the resize of an sw x sh image whose rows are `pitch` bytes apart.
+__device__ __forceinline__ uint8_t resize_cv_pixel(const uint8_t* __restrict__ s, int pitch, int sw, int sh, int dx, int dy,
+                                                   double scale_x, double scale_y, int area_fast) {
   if (area_fast) {
-    const uint8_t* p = s + (size_t)(2 * dy) * sw + 2 * dx;
-    d[(size_t)dy * dw + dx] = (uint8_t)((p[0] + p[1] + p[sw] + p[sw + 1] + 2) >> 2);
-    return;
+    const uint8_t* p = s + (size_t)(2 * dy) * pitch + 2 * dx;
+    return (uint8_t)((p[0] + p[1] + p[pitch] + p[pitch + 1] + 2) >> 2);
   }
   float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
   int sx = (int)floorf(fx);
@@ -80,12 +73,39 @@ __global__ void k_resize_cv(const uint8_t* __restrict__ src, size_t src_stride, 
   const int a0 = sat_short((1.f - fx) * 2048.f), a1 = sat_short(fx * 2048.f);
   const int b0 = sat_short((1.f - fy) * 2048.f), b1 = sat_short(fy * 2048.f);
   const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-  const uint8_t* S0 = s + (size_t)y0 * sw;
-  const uint8_t* S1 = s + (size_t)y1 * sw;
+  const uint8_t* S0 = s + (size_t)y0 * pitch;
+  const uint8_t* S1 = s + (size_t)y1 * pitch;
   int r0, r1;
   if (!edge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
   else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }
-  d[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+  return (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+__global__ void k_resize_cv(const uint8_t* __restrict__ src, size_t src_stride, int sw, int sh,
+                            uint8_t* __restrict__ dst, size_t dst_stride, int dw, int dh,
+                            double scale_x, double scale_y, int area_fast) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y;
+  const int f = blockIdx.z;
+  if (dx >= dw || dy >= dh) return;
+  dst[(size_t)f * dst_stride + (size_t)dy * dw + dx] =
+      resize_cv_pixel(src + (size_t)f * src_stride, sw, sw, sh, dx, dy, scale_x, scale_y, area_fast);
+}
+
+// The same resize for the ROI of every window of a level (method 0 on a multi-scale model, cascador.cpp:243-245: the ROI
+// is an image of its own to cv::resize): a thread per output pixel of a window's ds x ds patch.
+__global__ void k_resize_cv_patches(const uint8_t* __restrict__ src, size_t src_stride, int lw, int nx, int step, int win,
+                                    uint8_t* __restrict__ dst, size_t dst_stride, int ds,
+                                    double scale, int area_fast) {
+  const int pb = (ds * ds + (int)blockDim.x - 1) / (int)blockDim.x;     // blocks per patch
+  const int wi = (int)(blockIdx.x / (unsigned)pb);
+  const int e = (int)(blockIdx.x - (unsigned)wi * (unsigned)pb) * (int)blockDim.x + (int)threadIdx.x;
+  const int f = blockIdx.y;
+  if (e >= ds * ds) return;
+  const int dy = e / ds, dx = e - dy * ds;
+  const int wy = wi / nx, wx = wi - wy * nx;
+  const uint8_t* roi = src + (size_t)f * src_stride + (size_t)(wy * step) * lw + wx * step;
+  dst[(size_t)f * dst_stride + (size_t)wi * ds * ds + e] = resize_cv_pixel(roi, lw, win, win, dx, dy, scale, scale, area_fast);
 }
 
 hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
@@ -97,6 +117,18 @@ hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw
   dim3 block(256), grid((dw + 255) / 256, dh, n);
   hipLaunchKernelGGL(k_resize_cv, grid, block, 0, stream, src, src_stride, sw, sh, dst, dst_stride, dw, dh,
                      scale_x, scale_y, area);
+  return hipGetLastError();
+}
+
+hipError_t launch_resize_cv_patches(const uint8_t* src, size_t src_stride, int n, int lw, int nx, int ny, int step, int win,
+                                    uint8_t* dst, size_t dst_stride, int ds, hipStream_t stream) {
+  if (ds <= 0 || n <= 0 || nx <= 0 || ny <= 0) return hipSuccess;
+  if (n > 65535 || (long long)nx * ny * ((ds * ds + 255) / 256) > 0x7fffffffLL) return hipErrorInvalidValue;
+  const double inv = (double)ds / win;
+  const double scale = 1. / inv;
+  const int area = fabs(scale - 2.) < 2.220446049250313e-16 ? 1 : 0;
+  dim3 block(256), grid((unsigned)((long long)nx * ny * ((ds * ds + 255) / 256)), (unsigned)n);
+  hipLaunchKernelGGL(k_resize_cv_patches, grid, block, 0, stream, src, src_stride, lw, nx, step, win, dst, dst_stride, ds, scale, area);
   return hipGetLastError();
 }
 

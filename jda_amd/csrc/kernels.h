@@ -152,6 +152,10 @@ struct WorkT {
   const uint8_t* frames; size_t frame_stride; int n_frames;
   const uint8_t* half; size_t half_stride; int hw, hh;        // pyramid images, only for multi-scale models
   const uint8_t* quarter; size_t quarter_stride; int qw, qh;
+  // dialect CPP, method 0 on a multi-scale model (cascador.cpp:243-245): no half / quarter IMAGE -- every window has its own
+  // half_size^2 and quarter_size^2 patches, resized from its ROI: window i of frame f at half + f * half_stride + i * patch_hs^2
+  // (quarter alike).  0: the images above
+  int patch_hs, patch_qs;
   // hand-off queue k_scan -> k_finish (plus the windows k_scan does not cover)
   uint32_t* q_gid; Real* q_score; uint32_t* q_hash; uint32_t* q_kstart;
   uint32_t* q_xy; uint32_t* q_wf;          // x | y << 16 and win | frame << 16 of the queued window
@@ -208,6 +212,12 @@ hipError_t launch_resize(const uint8_t* src, size_t src_stride, int n, int sw, i
 // cv::resize(INTER_LINEAR, 8UC1) restatement for dialect CPP (half/quarter images, method-0 pyramid).
 hipError_t launch_resize_cv(const uint8_t* src, size_t src_stride, int n, int sw, int sh,
                             uint8_t* dst, size_t dst_stride, int dw, int dh, hipStream_t stream);
+
+// The per-window patches of method 0 (cascador.cpp:243-245): cv::resize(INTER_LINEAR) of the win x win ROI of every window
+// of a one-level plan (nx x ny windows, `step` apart, in frames of row pitch lw) to ds x ds, window i of frame f at
+// dst + f * dst_stride + i * ds * ds.
+hipError_t launch_resize_cv_patches(const uint8_t* src, size_t src_stride, int n, int lw, int nx, int ny, int step, int win,
+                                    uint8_t* dst, size_t dst_stride, int ds, hipStream_t stream);
 
 // Resolves stage-0 node offsets for every tiled level (dialect 0 = C, 1 = CPP): cart-major into table (k_scan),
 // level-major (lm_index) into table_lm (k_finish).

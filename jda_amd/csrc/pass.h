@@ -217,7 +217,12 @@ struct Pass {
     if (timed) JDA_HIP(hipEventRecord(ev[0], st));
     if (rag) return issue_scan_ragged();
     if (host_frames && !upload_frames(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes)) return false;
-    if (multi) {
+    if (multi && w.patch_hs > 0) {             // method 0: every window's ROI -> its half_size / quarter_size patches (cascador.cpp:243-245)
+      const DevLevel& lv = pe->hp.lv[0];
+      JDA_HIP(launch_resize_cv_patches(w.frames, w.frame_stride, nf, pe->sp.width, lv.nx, lv.ny, lv.step, lv.win, hbuf, hs, w.patch_hs, st));
+      JDA_HIP(launch_resize_cv_patches(w.frames, w.frame_stride, nf, pe->sp.width, lv.nx, lv.ny, lv.step, lv.win, qbuf, qs, w.patch_qs, st));
+      w.half = hbuf; w.half_stride = hs; w.quarter = qbuf; w.quarter_stride = qs;
+    } else if (multi) {
       const int W = pe->sp.width, H = pe->sp.height;
       const size_t stride = w.frame_stride;
       if (dialect == JDA_DIALECT_C) {      // jdaImageResize, c/jda.c:203-230

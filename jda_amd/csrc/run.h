@@ -19,6 +19,8 @@ struct HostFrames {
   // dialect C: the passes may post-process their frames on the device (RawDets::p_*), with these NMS settings
   bool device_post = false, nms = true;
   float nms_overlap = 0.3f;
+  // dialect CPP, method 0 on a multi-scale model: per-window patches of these sides instead of half / quarter images
+  int patch_hs = 0, patch_qs = 0;
 };
 
 // Runs the device pipeline over n frames in device memory (d_frames; with host.ptrs set they are copied there first,
@@ -104,7 +106,13 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
 
   int hw = 0, hh = 0, qw = 0, qh = 0;
   size_t hs = 0, qs = 0;
-  if (multi) {
+  if (multi && host.patch_hs > 0) {
+    // (one level per plan; the patches of a pass: windows x (hs^2 + qs^2) bytes per frame)
+    hw = hh = host.patch_hs; qw = qh = host.patch_qs;
+    hs = (((size_t)wpf * hw * hh) + 255) & ~(size_t)255; qs = (((size_t)wpf * qw * qh) + 255) & ~(size_t)255;
+    for (int l = 0; l < lanes; l++)
+      if (!lanes_held.v[l]->pyr.reserve((hs + qs) * (size_t)fpp + 512)) return false;
+  } else if (multi) {
     if (dialect == JDA_DIALECT_C) {
       const float r = 1.f / sqrtf(2.f);                     // c/jda.c:450-456
       hw = (int)((float)pe->sp.width * r); hh = (int)((float)pe->sp.height * r);
@@ -142,6 +150,7 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
       if (host_frames) { p.host_frames = host_frames + f0; p.host_fbytes = host_fbytes; }
       p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
       p.w.hw = hw; p.w.hh = hh; p.w.qw = qw; p.w.qh = qh;
+      p.w.patch_hs = multi ? host.patch_hs : 0; p.w.patch_qs = multi ? host.patch_qs : 0;
       f0 += p.nf;
       ps.push_back(std::move(p));
     }

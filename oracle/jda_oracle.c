@@ -839,10 +839,15 @@ long long orc_count_windows_pyramid(int w, int h, int origin_size, int step, dou
   return tot;
 }
 
-int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, int h,
-                           int origin_size, int step, double factor, double overlap, int do_nms,
-                           int *rects, double *scores, double *shapes) {
-  if (orc_has_multiscale(m)) return -1;
+/* Method 0 with the config's three patch sizes (image_size.origin_size / half_size / quarter_size, common.cpp:129-131):
+ * detectSingleScale resizes EVERY window's ROI to each of them (cascador.cpp:243-245) -- the first is the identity
+ * (the window is origin_size wide), the other two feed the split nodes of scale 1 and 2 (data.cpp:21-34).
+ * half_size = quarter_size = 0: the call of a single-scale model (multi-scale models are refused). */
+int orc_detect_cpp_pyramid_ms(const orc_model *m, const unsigned char *img, int w, int h,
+                              int origin_size, int half_size, int quarter_size, int step, double factor, double overlap,
+                              int do_nms, int *rects, double *scores, double *shapes) {
+  const int multi = orc_has_multiscale(m);
+  if (multi && (half_size < 1 || quarter_size < 1)) return -1;
   int nl = 0;
   const long long tot = orc_count_windows_pyramid(w, h, origin_size, step, factor, &nl);
   if (tot < 0) return -1;
@@ -853,6 +858,9 @@ int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, 
   double *s0 = (double *)malloc(sizeof(double) * (tot > 0 ? tot : 1));
   double *h0 = (double *)malloc(sizeof(double) * m->dim * (tot > 0 ? tot : 1));
   unsigned char *cur = (unsigned char *)malloc((size_t)w * h);
+  unsigned char *roi = (unsigned char *)malloc((size_t)origin_size * origin_size);
+  unsigned char *ph = (unsigned char *)malloc((size_t)(half_size > 0 ? half_size * half_size : 1));
+  unsigned char *pq = (unsigned char *)malloc((size_t)(quarter_size > 0 ? quarter_size * quarter_size : 1));
   memcpy(cur, img, (size_t)w * h);
   int width = w, height = h, n = 0;
   double scale = 1.;
@@ -863,6 +871,14 @@ int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, 
         orc_patch pt[3];
         pt[0].data = cur; pt[0].iw = width; pt[0].ox = x; pt[0].oy = y; pt[0].pw = origin_size;
         pt[1] = pt[0]; pt[2] = pt[0];
+        if (multi) {
+          /* cv::resize(img(roi), patch_h / patch_q, ...): the ROI is an image of its own to cv::resize */
+          for (int r = 0; r < origin_size; r++) memcpy(roi + (size_t)r * origin_size, cur + (size_t)(y + r) * width + x, (size_t)origin_size);
+          orc_resize_cv(roi, origin_size, origin_size, ph, half_size, half_size);
+          orc_resize_cv(roi, origin_size, origin_size, pq, quarter_size, quarter_size);
+          pt[1].data = ph; pt[1].iw = half_size; pt[1].ox = 0; pt[1].oy = 0; pt[1].pw = half_size;
+          pt[2].data = pq; pt[2].iw = quarter_size; pt[2].ox = 0; pt[2].oy = 0; pt[2].pw = quarter_size;
+        }
         (void)orc_walk_cpp(m, pt, shape, delta, lbf, &s, &hsh, &alive);
         if (!alive) continue;
         int rx = x, ry = y, rw = origin_size, rh = origin_size;
@@ -880,6 +896,13 @@ int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, 
     free(cur); cur = nxt; width = nw; height = nh;
   }
   const int np = orc_finish_cpp(m, r0, s0, h0, n, overlap, do_nms, rects, scores, shapes);
-  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(cur);
+  free(shape); free(delta); free(lbf); free(r0); free(s0); free(h0); free(cur); free(roi); free(ph); free(pq);
   return np;
+}
+
+int orc_detect_cpp_pyramid(const orc_model *m, const unsigned char *img, int w, int h,
+                           int origin_size, int step, double factor, double overlap, int do_nms,
+                           int *rects, double *scores, double *shapes) {
+  if (orc_has_multiscale(m)) return -1;
+  return orc_detect_cpp_pyramid_ms(m, img, w, h, origin_size, 0, 0, step, factor, overlap, do_nms, rects, scores, shapes);
 }

@@ -52,6 +52,9 @@ class Oracle:
         L.orc_detect_cpp_pyramid.restype = C.c_int
         L.orc_detect_cpp_pyramid.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                              C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_detect_cpp_pyramid_ms.restype = C.c_int
+        L.orc_detect_cpp_pyramid_ms.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_pyramid_dims.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
         self.h = L.orc_load(os.fsencode(model_path))
         if not self.h:
@@ -160,7 +163,8 @@ class Oracle:
         self.lib.orc_resize_cv(_ptr(img, C.c_ubyte), w, h, _ptr(out, C.c_ubyte), dw, dh)
         return out
 
-    def detect_cpp_pyramid(self, img, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True):
+    def detect_cpp_pyramid(self, img, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, half_size=0, quarter_size=0):
+        """half_size / quarter_size > 0: the per-window patches of a multi-scale model (cascador.cpp:243-245)."""
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         nl = C.c_int()
@@ -170,8 +174,8 @@ class Oracle:
         rc = np.zeros((max(n, 1), 4), np.int32)
         sc = np.zeros(max(n, 1), np.float64)
         sh = np.zeros((max(n, 1), self.dim), np.float64)
-        k = self.lib.orc_detect_cpp_pyramid(self.h, _ptr(img, C.c_ubyte), w, h, origin_size, step, factor, overlap,
-                                            int(nms), _ptr(rc, C.c_int), _ptr(sc, C.c_double), _ptr(sh, C.c_double))
+        k = self.lib.orc_detect_cpp_pyramid_ms(self.h, _ptr(img, C.c_ubyte), w, h, origin_size, half_size, quarter_size, step,
+                                               factor, overlap, int(nms), _ptr(rc, C.c_int), _ptr(sc, C.c_double), _ptr(sh, C.c_double))
         if k < 0:
             raise RuntimeError("oracle pyramid detect failed (multi-scale model?)")
         return dict(rects=rc[:k].copy(), scores=sc[:k].copy(), shapes=sh[:k].copy(), windows=n, levels=nl.value)

@@ -573,12 +573,45 @@ def test_dialect_cpp_method0_true_pyramid(built, gpu, model_file, size, origin, 
     assert sum(len(g["scores"]) for g in got) > 0
 
 
-def test_method0_rejects_multiscale(built, gpu, model_file):
+def test_method0_multiscale_needs_the_patch_sizes(built, gpu, model_file):
     from jda_amd import api, synth
     p, _ = model_file((2, 8, 5, 3), 8, seed=24, multi_scale=True)
     c = api.Cascador(p)
-    with pytest.raises(api.JdaError, match="scale==0"):
+    with pytest.raises(api.JdaError, match="half_size and quarter_size"):
         c.detect_batch_cpp_pyramid(synth.make_frames(1, 64, 64, seed=1))
+
+
+@pytest.mark.parametrize("dims,sizes,frame", [((3, 20, 5, 4), (48, 36, 24), (160, 120)), ((2, 8, 5, 3), (40, 27, 20), (131, 97)),
+                                              ((3, 70, 9, 5), (48, 36, 24), (200, 150))])
+def test_method0_multiscale_per_window_patches(built, gpu, model_file, dims, sizes, frame):
+    """Method 0 on a model with scale != 0 split nodes: detectSingleScale resizes every window's ROI to the config's
+    half_size / quarter_size (cascador.cpp:243-245; 48 / 36 / 24 in the shipped config, the exact-2x quarter goes through
+    cv::resize's box average) and a split node reads the window's own patch with coordinates scaled by that patch's side
+    (data.cpp:21-51).  The patches are built on the device; detections == the oracle's (both UNPINNED: src/jda needs OpenCV)."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    p, _ = model_file(dims, 8, seed=24, cart_th=-0.9, multi_scale=True, f32_exact=False)
+    o_size, h_size, q_size = sizes
+    frames = synth.make_frames(2, frame[0], frame[1], seed=35)
+    c, o = api.Cascador(p), Oracle(p)
+    total = 0
+    for nms in (True, False):
+        got, st = c.detect_batch_cpp_pyramid(frames, o_size, 5, 1.2, 0.3, nms, stats=True, half_size=h_size, quarter_size=q_size)
+        for i in range(len(frames)):
+            want = o.detect_cpp_pyramid(frames[i], o_size, 5, 1.2, 0.3, nms, half_size=h_size, quarter_size=q_size)
+            assert st["patch_n"] == 2 * want["windows"]
+            for k in ("rects", "scores", "shapes"):
+                assert same(got[i][k], want[k]), (nms, i, k, len(got[i]["scores"]), len(want["scores"]))
+            total += len(want["scores"])
+    assert total > 0
+    # a single-scale model through the same entry: the sizes are unused, results those of jdaDetectBatchCppPyramid
+    p1, _ = model_file(dims, 8, seed=25, cart_th=-0.9)
+    c1 = api.Cascador(p1)
+    a = c1.detect_batch_cpp_pyramid(frames, o_size, 5, 1.2)
+    b = c1.detect_batch_cpp_pyramid(frames, o_size, 5, 1.2, half_size=h_size, quarter_size=q_size)
+    for x, y in zip(a, b):
+        for k in ("rects", "scores", "shapes"):
+            assert same(x[k], y[k]), k
 
 
 # ---------------------------------------------------------------- randomised sweep
