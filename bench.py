@@ -220,7 +220,25 @@ def main():
 
     gather_kind = ["none (one rank)"]
 
+    gather_cache = {}
+
     def make_gather():
+        """One gather object per process, made at first use and reused by every leg (at N ranks a libjda_dist communicator
+        is an ncclCommInitRank across the node: seconds, not something to repeat per leg)."""
+        key = os.environ.get("JDA_BENCH_GATHER", "c")
+        if key not in gather_cache:
+            gather_cache[key] = new_gather()
+        g, kind = gather_cache[key]
+        g.drain()
+        return g, kind
+
+    def close_gathers():
+        for g, _ in gather_cache.values():
+            if hasattr(g, "close"):
+                g.close()
+        gather_cache.clear()
+
+    def new_gather():
         """The gather of (bbox, score, landmarks) rows on rank 0, one collective per step, pipelined one step behind the
         detection.  N > 1 over RCCL: the C entry points of libjda_dist.so (include/jda_dist.h: jdaDistGatherStart /
         jdaDistGatherCollect on the library's own communicator); if that library cannot be set up on every rank, the
@@ -384,8 +402,6 @@ def main():
         }
         for c in cascs:
             c.close()
-        if hasattr(gather, "close"):
-            gather.close()
         return info, mp
 
     # ---- first contact of the N-rank gather, before anything is timed: a known ragged pattern (an empty rank, a rank with
@@ -410,8 +426,6 @@ def main():
                 os.environ["JDA_BENCH_GATHER"] = "torch"      # every rank saw the same flag: all fall back together
         else:
             selftest = "ok (%s)" % kind0.split(":")[0]
-        if hasattr(g0, "close"):
-            g0.close()
 
     casc_info, casc_model = run_regime("cascade", args.steps, args.warmup, call["th"], depth=args.depth)
     rank_ms = casc_info.get("rank_ms_per_step")
@@ -540,8 +554,6 @@ def main():
             info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (mean of %d runs, like ms_per_job); speedup = "
                                                      "mean ms_per_job / slowest shard's mean; not a multi-GPU measurement" % max(2, reps))
         casc.close()
-        if hasattr(gather, "close"):
-            gather.close()
         return info
 
     fddb_info = None
@@ -782,6 +794,7 @@ def main():
                         "allpass": allpass_info, "host_frames": host_info},
         }
         print(json.dumps(line))
+    close_gathers()
     if world > 1:
         dist.destroy_process_group()
 
