@@ -107,7 +107,14 @@ JDA_API void jdaResultRelease(jdaResult result);
  *                   src/jda/cascador.cpp:166-211,310-477 (method 1). */
 enum { JDA_DIALECT_C = 0, JDA_DIALECT_CPP = 1 };
 
-/* Thread-local message of the last failed call on this thread ("" if none). */
+/* Thread-local message of the last failed call on this thread ("" if none).
+ * No C++ exception leaves the library: an allocation failure inside any entry (std::bad_alloc from the host side's
+ * containers, the tables of a large model) is caught at the boundary and turned into the entry's error value -- NULL,
+ * -1 or an empty jdaResult, the reference's own answer to a failed malloc (c/jda.c:487-493) -- with the reason here.
+ * One SUCCESSFUL outcome also leaves a note here: when the persistent stage-0 scan kernel gives up waiting inside a
+ * launch (a watchdog; never observed on hardware) or covers fewer windows than the plan holds, the pass is run again
+ * with the closed-tile scan kernel and the call returns its (correct) results with "k_scan_p: watchdog word ..." as
+ * the message and on stderr. */
 JDA_API const char *jdaGetLastError(void);
 
 /* Opens a model of either layout; the layout is inferred from the file size
