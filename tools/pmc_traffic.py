@@ -37,7 +37,7 @@ def group(name):
     return None
 
 
-DEVICE_HEADERS = ("kernels.h", "kernels_common.h", "finish_common.h", "scan_walk.h")
+DEVICE_HEADERS = ("kernels.h", "kernels_common.h", "finish_common.h", "scan_walk.h", "k_scan_impl.h")
 
 
 def kernel_sources_sha256():
