@@ -188,3 +188,54 @@ def test_release_drains_a_ticket_nobody_waited_for(built, gpu, model_file):
         c.close()                                            # no Wait
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < (64 << 20)
+
+
+def test_idle_lanes_give_their_memory_back_while_others_call(built, gpu, model_file):
+    """A burst of concurrent callers leaves lanes behind, each with a workspace; a lane that sits out `lane_idle_calls`
+    hand-outs gives its buffers back.  The buffers are moved out under the cascador's mutex and freed AFTER it is
+    released (hipFree synchronises the device: r04 freed under the lock) -- here while two threads keep calling:
+    their results stay those of a quiet cascador and the device memory of the burst comes back."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 20, 5, 4), 8, seed=3, cart_th=-1.0, norm_every=5)
+    c = api.Cascador(p)
+    c.set_option("lane_idle_calls", 4)
+    frames = synth.make_frames(8, 200, 150, seed=5)
+    big = synth.make_frames(48, 320, 240, seed=6)            # a batch: its lane holds a workspace worth trimming
+    want = [c.detect(f) for f in frames]
+    want_big = c.detect_batch(big)
+    errors = []
+
+    def burst(t):
+        try:
+            for a, b in zip(c.detect_batch(big), want_big):
+                _eq(a, b, ("burst", t))
+        except Exception as e:           # noqa: BLE001
+            errors.append(repr(e))
+    ths = [threading.Thread(target=burst, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    free_burst = torch.cuda.mem_get_info()[0]
+
+    def steady(t):
+        try:
+            for r in range(60):
+                _eq(c.detect(frames[(t + r) % 8]), want[(t + r) % 8], (t, r))
+        except Exception as e:           # noqa: BLE001
+            errors.append(repr(e))
+    ths = [threading.Thread(target=steady, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after > free_burst + (32 << 20), (free_burst, free_after)      # the idle lanes' workspaces are gone
+    for a, b in zip(c.detect_batch(big), want_big):                             # ... and come back on demand
+        _eq(a, b, "after the trim")
+    c.close()
