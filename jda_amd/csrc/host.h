@@ -128,6 +128,7 @@ inline long long env_ll(const char* name, long long dflt) {
   X(w_stream_mb, "JDA_W_STREAM_MB", 8)      /* ... with non-temporal loads when one stage's rows exceed this many MB (they would only push the stage's nodes out of L2); 0: never */ \
   X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
+  X(scan_p_ragged, "JDA_SCAN_P_RAGGED", 1)  /* ... also for the single-level launches of a ragged chunk (tiles from the chunk's block map, re-cut per image) */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
   X(scan_p_min_slots, "JDA_SCAN_P_MIN_SLOTS", 4) /* ... pixel-tile slots a level's workgroup must have room for (scan_p = 1) */ \
   X(scan_p_wgs, "JDA_SCAN_P_WGS", 1)        /* ... workgroups per CU */                                 \
@@ -533,7 +534,7 @@ struct RaggedChunk {
   size_t raw_bytes = 0;                 // tight images (host staging; 0 when the images are already on the device)
   int max_h = 0, pitch = 0;
   std::vector<uint32_t> gid_base;       // [n + 1] first gid of every image inside the pass
-  struct Launch { int mode, block, pix_bytes, blk_base, blk_n; };
+  struct Launch { int mode, block, pix_bytes, blk_base, blk_n; int level = -1; };   // level: the one level of the launch (-1: several, merged)
   std::vector<Launch> launches;
   int n_segs = 0, n_blk = 0;
   size_t off_segs = 0, off_blk = 0, off_imgoff = 0, off_rimg = 0, off_gidbase = 0, table_bytes = 0;   // layout of the table buffer

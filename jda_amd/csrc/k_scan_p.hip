@@ -53,7 +53,7 @@ struct ThNormF { float th, norm; };
 // clocks, although the LDS round trip itself is ~60 clocks: stamps in profiles/r04_scan_p_stamps.txt.)
 typedef int v4i __attribute__((ext_vector_type(4)));
 struct PCtl {
-  v4i rec[24];
+  v4i rec[32];
   //   rec[s], s < 8        slot:  x claim generation << 2 | state (0 free, 1 being loaded, 2 published), y generation << 12 | next
   //                               fresh batch, z batches, w references (fresh batches not finished + items alive).  The state
   //                               word carries a generation so that a claim's compare-and-swap, made on a snapshot that has
@@ -61,10 +61,12 @@ struct PCtl {
   //   rec[8 + b], b < 6    ring:  x committed, y popped, z reserved
   //   rec[14]              x next tile (sequence number inside this workgroup's share) to bring in
   //   rec[16 + s]          slot geometry: x twe | the << 16, y xshift, z frame, w wx0 | wy0 << 16
+  //   rec[24 + s]          ragged passes: the tile's image -- x gid of its level's first window, y windows per row (nx),
+  //                        z windows per tile row (tw: the level's tile re-cut for this image)
   int cfgw[64];                        // PScanCfg as words (see kCf*): a wave keeps word i in lane i and reads it with v_readlane
   unsigned long long dbg[20];
 };
-constexpr int kRecRing = 8, kRecMisc = 14, kRecGeo = 16;
+constexpr int kRecRing = 8, kRecMisc = 14, kRecGeo = 16, kRecGeo2 = 24;
 // (dynamic indexing of the by-value kernel argument is a scalar memory load per access, ~200 clocks each and serialised)
 constexpr int kCfNb = 0, kCfBound = 1, kCfLg = kCfBound + kPScanMaxBuckets + 1, kCfCap = kCfLg + kPScanMaxBuckets,
               kCfOff = kCfCap + kPScanMaxBuckets, kCfEnd = kCfOff + kPScanMaxBuckets;
@@ -273,7 +275,10 @@ size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, 
   return (size_t)PLds(carts, node_n, leaf_n, cfg.ring_items, waves, cfg.slots, cfg.slot_bytes).total;
 }
 
-template <int DEPTH>
+// RAGGED: the tiles of a ragged batch (images of different sizes in one pass, kernels.h: RagSeg / RagBlk): a tile is
+// named by the launch's block map, its geometry -- the level's tile re-cut for the image, the image's own window grid --
+// travels with its slot.  A template parameter like k_scan's (a run-time test in the hot prologue cost that kernel 13 %).
+template <int DEPTH, bool RAGGED>
 // Registers: launch_bounds(1024) alone lets the compiler take 128 (117 used); a workgroup of 768 threads is three waves
 // per SIMD, and what it leaves of the 512 registers decides which of the other batch's kernels can run next to it.
 #ifndef JDA_SCAN_P_WAVES_PER_EU
@@ -281,7 +286,7 @@ template <int DEPTH>
 #endif
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(JDA_SCAN_P_WAVES_PER_EU)))
 void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node* __restrict__ table, WorkT<float> w,
-              int level, PScanCfg cfg, int total_blocks) {
+              int level, PScanCfg cfg, int total_blocks, int blk_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -415,12 +420,16 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
       const int rank = __popcll(mask & lanes_below(lane));
       const int s = (int)(packed >> (kPBaseBits + kPWidxBits));
       const int widx = (int)((packed >> kPBaseBits) & ((1u << kPWidxBits) - 1u));
-      const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const v4i g = rec_l[kRecGeo + s];
+      v4i g2 = g;
+      if (RAGGED) g2 = rec_l[kRecGeo2 + s];
+      const int tw_s = RAGGED ? g2.z : lv.tw;
+      const int wy = widx / tw_s, wx = widx - wy * tw_s;
       const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
       const unsigned slot = gbase + (unsigned)rank;
       if (slot < w.cap) {
-        const uint32_t gid = (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
+        const uint32_t gid = RAGGED ? (uint32_t)(g2.x + (wy0 + wy) * g2.y + wx0 + wx)
+                                    : (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
         const uint32_t xy = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
         const uint32_t wf = (uint32_t)lv.win | ((uint32_t)frame << 16);
         if (cfg.to_mid) {                  // stage 0 passed: k_finish(survivors) takes it from the mid queue, as k_filter0 leaves it
@@ -546,6 +555,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
               if (j >= n_my) break;
               v = (int)blockIdx.x + j * G;
             }
+            if (RAGGED) { trel = v; have = true; break; }          // (trel: the block's index in the launch's map)
             const int group = v / (8 * tiles_per_frame);
             const int rr = v - group * (8 * tiles_per_frame);
             frame = group * 8 + (rr & 7);
@@ -557,18 +567,34 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
             lds_drain();
             st_relaxed(recw + 4 * s, t_xg | 0);
           } else {
-            const int ty = trel / lv.tiles_x, tx = trel - ty * lv.tiles_x;
-            const int wx0 = tx * lv.tw, wy0 = ty * TH;
-            const int twe = min(lv.tw, lv.nx - wx0), the = min(TH, lv.ny - wy0);
+            // the tile's grid: the level's (uniform batch) or its image's own with the level's tile re-cut for it (ragged:
+            // block map -> segment; wave-uniform values that arrive through vector loads, readfirstlane puts them in SGPRs)
+            int tiles_x = lv.tiles_x, tw_s = lv.tw, th_s = TH, nx_s = lv.nx, ny_s = lv.ny, gid_b = 0;
+            const uint8_t* img;
+            if (RAGGED) {
+              const RagBlk bs = w.blk[blk_base + trel];
+              const RagSeg sg = w.segs[(unsigned)uni((int)bs.seg)];
+              trel = uni((int)bs.tile);
+              tiles_x = uni((int)sg.tiles_x); tw_s = uni((int)sg.tw); th_s = uni((int)sg.th);
+              nx_s = uni((int)sg.nx); ny_s = uni((int)sg.ny); gid_b = uni((int)sg.gid_base); frame = uni((int)sg.image);
+              const unsigned long long io = (unsigned long long)(unsigned)uni((int)(unsigned)(sg.img_off & 0xffffffffu)) |
+                                            ((unsigned long long)(unsigned)uni((int)(unsigned)(sg.img_off >> 32)) << 32);
+              img = w.frames + io;
+            } else {
+              img = w.frames + (size_t)frame * w.frame_stride;
+            }
+            const int ty = trel / tiles_x, tx = trel - ty * tiles_x;
+            const int wx0 = tx * tw_s, wy0 = ty * th_s;
+            const int twe = min(tw_s, nx_s - wx0), the = min(th_s, ny_s - wy0);
             const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
             const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
-            const uint8_t* img = w.frames + (size_t)frame * w.frame_stride;
             const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
                                              lv.pitch, lane);
-            const int nbatch = (lv.tw * the + 63) >> 6;
+            const int nbatch = (tw_s * the + 63) >> 6;
             if (lane == 0) {
               int* g = recw + 4 * (kRecGeo + s);
               g[0] = twe | (the << 16); g[1] = xshift; g[2] = frame; g[3] = wx0 | (wy0 << 16);
+              if (RAGGED) { int* g2 = recw + 4 * (kRecGeo2 + s); g2[0] = gid_b; g2[1] = nx_s; g2[2] = tw_s; g2[3] = 0; }
               recw[4 * s + 2] = nbatch; recw[4 * s + 3] = nbatch;
             }
             win_cov += (lane == 0) ? (unsigned)(twe * the) : 0u;
@@ -584,8 +610,10 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
           const v4i g = rec_l[kRecGeo + s];
           const int twe = g.x & 0xffff, the = g.x >> 16, xshift = g.y;
           const int i = 64 * t_j + lane;
-          const int wy = cfg.tw_magic ? (int)(((unsigned)i * (unsigned)cfg.tw_magic) >> 20) : i / lv.tw;
-          const int wx = i - wy * lv.tw;
+          int tw_s = lv.tw;
+          if (RAGGED) tw_s = rec_l[kRecGeo2 + s].z;
+          const int wy = (!RAGGED && cfg.tw_magic) ? (int)(((unsigned)i * (unsigned)cfg.tw_magic) >> 20) : i / tw_s;
+          const int wx = i - wy * tw_s;
           r_ok = wx < twe && wy < the;
           const int base = L.slots + s * cfg.slot_bytes + (wy * lv.step) * lv.pitch + wx * lv.step + xshift;
           r_pk = (uint32_t)base | ((uint32_t)i << kPBaseBits) | ((uint32_t)s << (kPBaseBits + kPWidxBits));
@@ -682,30 +710,39 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
 
 hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int grid_max, const DevPlan* d_plan,
                                   const DevPlan& h_plan, const DevModelT<float>& m, const S0Node* table,
-                                  const WorkT<float>& w, hipStream_t stream) {
-  if (w.n_frames == 0) return hipSuccess;
+                                  const WorkT<float>& w, hipStream_t stream, int rag_blk_base, int rag_blk_n) {
+  const bool ragged = rag_blk_n >= 0;
+  if (!ragged && w.n_frames == 0) return hipSuccess;
+  if (ragged && rag_blk_n == 0) return hipSuccess;
   const DevLevel& lv = h_plan.lv[level];
   if (lv.tiled != 1 || cfg.nb < 0 || cfg.nb > kPScanMaxBuckets || cfg.slots < 1 || cfg.slots > kPSlotsMax) return hipErrorInvalidValue;
-  if (cfg.th < 1 || cfg.th > lv.th || cfg.tiles_y != (lv.ny + cfg.th - 1) / cfg.th) return hipErrorInvalidValue;
+  if (!ragged && (cfg.th < 1 || cfg.th > lv.th || cfg.tiles_y != (lv.ny + cfg.th - 1) / cfg.th)) return hipErrorInvalidValue;
+  if (ragged && (!w.segs || !w.blk)) return hipErrorInvalidValue;
   if (cfg.to_mid && cfg.bound_last != m.K) return hipErrorInvalidValue;
   if (cfg.dyn_slot >= kCntMidScan - kCntTotal) return hipErrorInvalidValue;
-  if (lv.tw * cfg.th > (1 << kPWidxBits) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
+  if ((!ragged && lv.tw * cfg.th > (1 << kPWidxBits)) || block < 64 || block > 1024 || (block & 63)) return hipErrorInvalidValue;
   const int K = cfg.bound_last;
   const PLds L(K, m.node_n, m.leaf_n, cfg.ring_items, block / 64, cfg.slots, cfg.slot_bytes);
   if (L.total > 160 * 1024 || L.total > (1 << kPBaseBits)) return hipErrorInvalidValue;
   const int groups = (w.n_frames + 7) / 8;
-  const int total_blocks = groups * 8 * lv.tiles_x * cfg.tiles_y;
+  const int total_blocks = ragged ? rag_blk_n : groups * 8 * lv.tiles_x * cfg.tiles_y;
   int grid = std::min(total_blocks, grid_max);
   if (grid >= 8) grid &= ~7;             // block b runs on XCD b % 8: a workgroup's tiles b + j * grid stay on its XCD's frames
   auto go = [&](auto kern) {
     if (L.total > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), L.total, stream, d_plan, m, table, w, level, cfg,
-                       total_blocks);
+                       total_blocks, ragged ? rag_blk_base : 0);
   };
-  if (m.D == 4) go(k_scan_p<4>);
-  else if (m.D == 6) go(k_scan_p<6>);
-  else go(k_scan_p<0>);
+  if (ragged) {
+    if (m.D == 4) go(k_scan_p<4, true>);
+    else if (m.D == 6) go(k_scan_p<6, true>);
+    else go(k_scan_p<0, true>);
+  } else {
+    if (m.D == 4) go(k_scan_p<4, false>);
+    else if (m.D == 6) go(k_scan_p<6, false>);
+    else go(k_scan_p<0, false>);
+  }
   return hipGetLastError();
 }
 

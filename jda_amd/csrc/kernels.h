@@ -270,9 +270,11 @@ struct PScanCfg {
 };
 void scan_p_ring_caps(PScanCfg* cfg, int waves);
 size_t scan_p_lds_bytes(const PScanCfg& cfg, int carts, int node_n, int leaf_n, int waves);
+// rag_blk_n >= 0: a ragged pass -- the launch covers blocks [rag_blk_base, rag_blk_base + rag_blk_n) of WorkT::blk, all of
+// `level` (cfg.slot_bytes = the largest tile any image of the chunk cut from it; cfg.th / tiles_y / tw_magic unused).
 hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int grid_max, const DevPlan* d_plan,
                                   const DevPlan& h_plan, const DevModelT<float>& m, const S0Node* table,
-                                  const WorkT<float>& w, hipStream_t stream);
+                                  const WorkT<float>& w, hipStream_t stream, int rag_blk_base = 0, int rag_blk_n = -1);
 
 // Tight images (row stride = width) at raw + src_off -> rows of `pitch` bytes at dst + dst_off, n images of at most
 // max_h rows.

@@ -129,10 +129,12 @@ struct Pass {
 
   // The persistent form of an LDS-tiled level's scan (k_scan_p.hip): dialect C, no trace.  false = not applicable
   // (the caller launches k_scan).
-  bool scan_persistent(int level, hipStream_t s) {
-    if constexpr (sizeof(Real) != 4) { (void)level; (void)s; return false; }
+  // rl: a launch of a ragged chunk (all of ONE level): its tiles come from the chunk's block map, re-cut per image
+  bool scan_persistent(int level, hipStream_t s, const RaggedChunk::Launch* rl = nullptr) {
+    if constexpr (sizeof(Real) != 4) { (void)level; (void)s; (void)rl; return false; }
     else {
       if (!kn().scan_p || want_trace() || no_scan_p) return false;
+      if (rl && (!kn().scan_p_ragged || level < 0)) return false;
       const DevModelT<Real>& m = model();
       const DevLevel& lv = pe->hp.lv[level];
       if (lv.win > kn().scan_p_win_max) return false;
@@ -162,7 +164,7 @@ struct Pass {
       const int wgs = (int)std::max<long long>(1, std::min<long long>(8, kn().scan_p_wgs));
       cfg.ring_cap[0] = (int)std::max<long long>(64, std::min<long long>(4096, kn().scan_p_ring));
       scan_p_ring_caps(&cfg, block / 64);
-      { const unsigned mg = ((1u << 20) + (unsigned)lv.tw - 1u) / (unsigned)lv.tw; bool ok = true;
+      if (!rl) { const unsigned mg = ((1u << 20) + (unsigned)lv.tw - 1u) / (unsigned)lv.tw; bool ok = true;
         for (unsigned i = 0; i < (unsigned)(lv.tw * lv.th + 64) && ok; i++) ok = ((i * mg) >> 20) == i / (unsigned)lv.tw;
         cfg.tw_magic = ok ? (int)mg : 0; }
       cfg.opts = (int)kn().scan_p_opts;
@@ -171,7 +173,7 @@ struct Pass {
       // waves to 90 % (or the best filled one); the tallest that keeps the pixel tile within scan_p_tile_kb, else the
       // smallest
       cfg.th = lv.th;
-      if (kn().scan_p_tile_kb > 0) {
+      if (kn().scan_p_tile_kb > 0 && !rl) {
         double top = 0;
         auto fill_of = [&](int th) { const int n = lv.tw * th; return (double)n / (double)(((n + 63) / 64) * 64); };
         for (int th = 1; th <= lv.th; th++) top = std::max(top, fill_of(th));
@@ -185,7 +187,7 @@ struct Pass {
         cfg.th = fit ? fit : smallest;
       }
       cfg.tiles_y = (lv.ny + cfg.th - 1) / cfg.th;
-      cfg.slot_bytes = (lv.pitch * (lv.win + (cfg.th - 1) * lv.step) + 15) & ~15;
+      cfg.slot_bytes = rl ? ((rl->pix_bytes + 15) & ~15) : ((lv.pitch * (lv.win + (cfg.th - 1) * lv.step) + 15) & ~15);
       cfg.slots = 0;
       const long long fixed = (long long)scan_p_lds_bytes(cfg, K, m.node_n, m.leaf_n, block / 64);
       const long long budget = std::max<long long>(16, std::min<long long>(160, kn().scan_p_lds_kb)) * 1024 / wgs;
@@ -197,10 +199,12 @@ struct Pass {
       if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
       if (kn().scan_p == 1 && slots < kn().scan_p_min_slots) return false;     // few resident windows per wave: k_scan's closed tiles do better there
       cfg.slots = (int)slots;
-      if (kn().scan_p == 1 && (long long)lv.tiles_x * cfg.tiles_y * nf < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
+      const long long n_tiles = rl ? (long long)rl->blk_n : (long long)lv.tiles_x * cfg.tiles_y * nf;
+      if (kn().scan_p == 1 && n_tiles < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
       cfg.dyn_slot = (kn().scan_p_dyn && p_launches < kCntMidScan - kCntTotal) ? p_launches : -1;
       const int grid = kn().scan_p_grid > 0 ? (int)std::min<long long>(kn().scan_p_grid, 1 << 16) : c->n_cus * wgs;
-      const hipError_t e = launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s);
+      const hipError_t e = rl ? launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s, rl->blk_base, rl->blk_n)
+                              : launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s);
       if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return false; }
       if (e != hipSuccess) { fail(std::string("launch_scan_persistent failed: ") + hipGetErrorString(e)); return false; }
       if (cfg.to_mid) mid_direct = true;
@@ -378,9 +382,12 @@ struct Pass {
     const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
                      (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
     for (const RaggedChunk::Launch& l : ch.launches) {
+      // (the persistent form for the levels it suits, as in a uniform pass: one workgroup per CU walks the level's tiles
+      // of every image of the chunk through its slots)
+      if (l.mode == 1 && l.level >= 0 && scan_persistent(l.level, st, &l)) { rs->scan_launches++; my_scan_launches++; continue; }
       JDA_HIP(launch_scan_ragged<Real>(l.mode, l.block, false, handoff, cp_max, opts, pe->dp, m, pe->table, w, l.pix_bytes,
                                        l.blk_base, l.blk_n, st));
-      rs->scan_launches++;
+      rs->scan_launches++; my_scan_launches++;
     }
     if (timed) JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();
@@ -545,8 +552,10 @@ struct Pass {
       // (k_scan_p.hip: a tripped launch loses windows, it never corrupts one -- so the check is a count)
       const unsigned long long err = h_cnt[(size_t)kCntScanErrShard * kCntStride + kCntScanErr];
       long long expect = 0;
-      for (int l = 0; l < pe->hp.n_levels; l++)
-        if (pe->hp.lv[l].tiled != 0) expect += (long long)pe->hp.lv[l].nx * pe->hp.lv[l].ny * nf;
+      if (rag) expect = rag->windows;          // (a ragged job has no untiled level: ragged_prepare)
+      else
+        for (int l = 0; l < pe->hp.n_levels; l++)
+          if (pe->hp.lv[l].tiled != 0) expect += (long long)pe->hp.lv[l].nx * pe->hp.lv[l].ny * nf;
       if (err != 0 || (long long)h_cnt[kCntWinScan] != expect) return recover_scan(err, (long long)h_cnt[kCntWinScan], expect);
     }
     rs->carts += (long long)h_cnt[kCntCarts];

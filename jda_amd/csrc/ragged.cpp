@@ -264,6 +264,7 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     for (int l = 0; l < nl; l++)
       if (hp.lv[l].tiled == 1) {
         RaggedChunk::Launch L{1, win_max[l] > 256 ? 512 : 256, pix_of(l), bi, 0};
+        L.level = l;
         emit_level(l);
         L.blk_n = bi - L.blk_base;
         if (L.blk_n > 0) ch->launches.push_back(L);

@@ -168,3 +168,40 @@ def test_ragged_fddb_sized_job_shipped_dims(built, gpu, tmp_path):
             _eq(got[i], ref.detect(imgs[i]), i)
     assert sum(len(g["scores"]) for g in got) > 0
     print("ragged 300 FDDB-sized images: %.2f ms, %.0f images/s, %.3e windows/s" % (el * 1e3, 300 / el, st["patch_n"] / el))
+
+
+@pytest.mark.parametrize("dims,th", [((3, 20, 5, 4), -1.0), (S_DIMS, -2.0)])
+def test_ragged_chunks_through_the_persistent_scan(built, gpu, model_file, monkeypatch, dims, th):
+    """The single-level launches of a ragged chunk go through k_scan_p's RAGGED instantiation (tiles named by the chunk's
+    block map, the level's tile re-cut per image, the image's own window grid travelling with the slot): same results,
+    bit for bit, as with the closed-tile k_scan and as jdaDetect image by image -- 300 images of mixed sizes (some with
+    fewer levels than others, one too small for any window) in several chunks, scan_p = 2 so that every level it fits
+    takes the persistent form."""
+    from jda_amd import api, synth
+    p, _ = model_file(dims, 8, seed=3, cart_th=th, norm_every=5)
+    rng = np.random.default_rng(9)
+    base = synth.make_frames(8, 360, 300, seed=12)
+    imgs = []
+    for i in range(300):
+        w, h = int(rng.integers(60, 361)), int(rng.integers(50, 301))
+        imgs.append(np.ascontiguousarray(base[i % 8][:h, :w]))
+    imgs[17] = np.ascontiguousarray(base[0][:20, :30])
+    monkeypatch.setenv("JDA_SCAN_P", "2")
+    monkeypatch.setenv("JDA_RAGGED_CHUNK_WINDOWS", "700000"); monkeypatch.setenv("JDA_RAGGED_CHUNK_MIN_WINDOWS", "100000")
+    on = api.Cascador(p)
+    monkeypatch.setenv("JDA_SCAN_P_RAGGED", "0")
+    off = api.Cascador(p)
+    assert on.get_option("scan_p_ragged") == 1 and off.get_option("scan_p_ragged") == 0
+    (a, sa), (b, sb) = on.detect_ragged(imgs, stats=True), off.detect_ragged(imgs, stats=True)
+    assert len(a) == len(b) == 300
+    for i in range(300):
+        _eq(a[i], b[i], i)
+    for k in ("patch_n", "face_patch_n", "cart_gothrough_n", "cart_total_n", "handoff_n", "scan_cart_n", "scan_patch_n"):
+        assert sa[k] == sb[k], k
+    assert sa["scan_patch_n"] == sa["patch_n"] == sum(api.count_windows(im.shape[1], im.shape[0])[0] for im in imgs)
+    for i in (0, 17, 123, 299):
+        _eq(a[i], on.detect(imgs[i]), ("jdaDetect", i))
+    assert sum(len(r["scores"]) for r in a) > 0 and len(a[17]["scores"]) == 0
+    # second job (the finishing launches are sized by prediction now), NMS off
+    for x, y in zip(on.detect_ragged(imgs, nms=False), off.detect_ragged(imgs, nms=False)):
+        _eq(x, y, "second job")

@@ -140,6 +140,13 @@ for name, call in (("sync", lambda: c.detect_batch_device(frames, stats=True)),
     out[name] = {"err": err, "scan_patch_n": st["scan_patch_n"], "patch_n": st["patch_n"], "cart_total_n": st["cart_total_n"],
                  "n": [len(d["scores"]) for d in dets],
                  "digest": [__import__("hashlib").sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in dets]}
+# a ragged job too (the persistent kernel's RAGGED instantiation: tiles from the chunk's block map)
+rng = np.random.default_rng(3)
+base = synth.make_frames(8, 400, 300, seed=79)
+imgs = [np.ascontiguousarray(base[i %% 8][:int(rng.integers(200, 301)), :int(rng.integers(260, 401))]) for i in range(%(n_rag)d)]
+dets = c.detect_ragged(imgs)
+out["ragged"] = {"err": api.last_error(), "n": [len(d["scores"]) for d in dets],
+                 "digest": [__import__("hashlib").sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in dets]}
 print("RESULT " + json.dumps(out))
 """
 
@@ -170,11 +177,16 @@ def test_a_tripped_watchdog_is_noticed_and_the_pass_rerun(gpu, tmp_path):
     finally:
         os.environ.clear(); os.environ.update(old)
     want, st = c.detect_batch_device(frames, stats=True)
+    n_rag = 400
+    rng = np.random.default_rng(3)
+    base = synth.make_frames(8, 400, 300, seed=79)
+    imgs = [np.ascontiguousarray(base[i % 8][:int(rng.integers(200, 301)), :int(rng.integers(260, 401))]) for i in range(n_rag)]
+    want_rag = c.detect_ragged(imgs)
     c.close()
-    assert sum(len(d["scores"]) for d in want) > 0
+    assert sum(len(d["scores"]) for d in want) > 0 and sum(len(d["scores"]) for d in want_rag) > 0
     env = dict(os.environ, JDA_LIB_PATH=wd, JDA_SCAN_P="2")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", WD_SCRIPT % dict(root=root, n=n, model=path)], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, "-c", WD_SCRIPT % dict(root=root, n=n, model=path, n_rag=n_rag)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -185,3 +197,7 @@ def test_a_tripped_watchdog_is_noticed_and_the_pass_rerun(gpu, tmp_path):
         assert "k_scan_p: watchdog word" in g["err"], (name, g["err"])
         assert g["n"] == [len(d["scores"]) for d in want] and g["digest"] == digest, name
         assert g["scan_patch_n"] == st["scan_patch_n"] == g["patch_n"] and g["cart_total_n"] == st["cart_total_n"], name
+    g = got["ragged"]
+    assert "k_scan_p: watchdog word" in g["err"], g["err"]
+    assert g["n"] == [len(d["scores"]) for d in want_rag]
+    assert g["digest"] == [hashlib.sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in want_rag]
