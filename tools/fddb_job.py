@@ -8,7 +8,7 @@ import bench
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 calib = synth.make_frames(8, 640, 480, seed=0, first=10_000_000)
 mp = bench.model_path((5, 540, 27, 4), "cascade", 1, calib)
-n_img = 2845
+n_img = int(os.environ.get("FDDB_N", "2845"))
 rng = np.random.default_rng(0)
 sizes = []
 for _ in range(n_img):
