@@ -670,6 +670,11 @@ struct Pass {
   }
 };
 
+// The member functions of Pass are compiled ONCE, in pass.cpp (explicit instantiation); the other translation units that
+// include this header only see the declarations' bodies, they do not generate them again.
+extern template struct Pass<float>;
+extern template struct Pass<double>;
+
 struct PendingBatch {
   bool active = false;       // submitted, not yet collected
   bool reserved = false;     // a submit is filling this slot

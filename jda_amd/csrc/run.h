@@ -27,7 +27,7 @@ struct HostFrames {
 // sub-batch by sub-batch).  `lanes` holds the call's first lane; a large batch takes a second one from the pool and
 // is split into sub-batches that alternate between the two (streams with their own workspace), see Pass.
 template <typename Real>
-static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
                             bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
                             const TraceOut<Real>* trace, RunStats* rs, HostFrames host);
 
@@ -36,7 +36,7 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
 // the lanes' pinned buffers.  The lanes go back to the pool and the caller may free its frames as soon as this
 // returns, so everything queued is waited for first.
 template <typename Real>
-static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
                        bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
                        const TraceOut<Real>* trace, RunStats* rs, HostFrames host = HostFrames()) {
   if (run_device_impl<Real>(c, lanes_held, pe, d_frames, stride, n, apply_th, th, user_stream, dets, trace, rs, host)) return true;
@@ -51,7 +51,7 @@ static bool run_device(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const ui
 }
 
 template <typename Real>
-static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
+bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint8_t* d_frames, size_t stride, int n,
                             bool apply_th, Real th, hipStream_t user_stream, RawDets<Real>* dets,
                             const TraceOut<Real>* trace, RunStats* rs, HostFrames host) {
   constexpr int dialect = Sel<Real>::dialect;
@@ -196,6 +196,17 @@ static bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, con
   return true;
 }
 
+// (compiled once, in pass.cpp)
+#define JDA_RUN_INST(KW, Real)                                                                                                   \
+  KW template bool run_device_impl<Real>(Cascador*, LaneSet&, PlanEntry*, const uint8_t*, size_t, int, bool, Real, hipStream_t,   \
+                                         RawDets<Real>*, const TraceOut<Real>*, RunStats*, HostFrames);                          \
+  KW template bool run_device<Real>(Cascador*, LaneSet&, PlanEntry*, const uint8_t*, size_t, int, bool, Real, hipStream_t,        \
+                                    RawDets<Real>*, const TraceOut<Real>*, RunStats*, HostFrames);
+#ifndef JDA_PASS_CPP
+JDA_RUN_INST(extern, float)
+JDA_RUN_INST(extern, double)
+#endif
+
 struct PlanPin {           // unpins on scope exit
   Cascador* c; PlanEntry* pe;
   ~PlanPin() { unpin_plan(c, pe); }
@@ -203,11 +214,15 @@ struct PlanPin {           // unpins on scope exit
 
 // The shared part of an entry, under c->mu: device, the model of dialect Real on the device, the plan (pinned).
 template <typename Real>
-static bool begin_call(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** pe) {
+bool begin_call(Cascador* c, const PlanKey& key, const ScanPlan& sp, int dialect, PlanEntry** pe) {
   std::unique_lock<std::mutex> lk(c->mu);
   if (!ensure_device(c) || !upload_model<Real>(c)) return false;
   return get_plan(c, lk, key, sp, dialect, pe);
 }
+#ifndef JDA_PASS_CPP
+extern template bool begin_call<float>(Cascador*, const PlanKey&, const ScanPlan&, int, PlanEntry**);
+extern template bool begin_call<double>(Cascador*, const PlanKey&, const ScanPlan&, int, PlanEntry**);
+#endif
 
 
 }  // namespace jda
