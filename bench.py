@@ -244,7 +244,10 @@ def main():
         jdaDistGatherCollect on the library's own communicator); if that library cannot be set up on every rank, the
         same exchange through torch.distributed (jda_amd/dist.py:PipelinedGather)."""
         width = 5 + 2 * L
-        if world > 1 and backend == "nccl" and os.environ.get("JDA_BENCH_GATHER", "c") == "c":
+        # (JDA_BENCH_C_GATHER_ON_GLOO=1 is for tests/test_dist_stub.py: two ranks on ONE GPU, torch's group over gloo and
+        # the library's RCCL calls answered by the preloaded stand-in -- the bench's N>1 flow with the C gather in it)
+        c_backend = backend == "nccl" or os.environ.get("JDA_BENCH_C_GATHER_ON_GLOO") == "1"
+        if world > 1 and c_backend and os.environ.get("JDA_BENCH_GATHER", "c") == "c":
             ok = 1
             try:
                 jdist.dist_lib()
