@@ -617,7 +617,7 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
       rc[4 * i] = wr.x; rc[4 * i + 1] = wr.y; rc[4 * i + 2] = wr.win; rc[4 * i + 3] = wr.win;
     }
     std::vector<int> pick;
-    if (nms) pick = nms_dialect_cpp(rc.data(), &dets.score[a], (int)cnt, overlap);
+    if (nms) pick = nms_dialect_cpp(rc.data(), dets.score.data() + a, (int)cnt, overlap);
     else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
     jdaResultD& r = out[f];
     r.n = (int)pick.size(); r.landmark_n = L;

@@ -204,7 +204,7 @@ double post_c(Cascador* c, const ScanPlan& sp, const RawDets<float>& dets, int n
       const WinRef wr = locate(sp, dets.gid[a + i]);
       bb[3 * i] = wr.x; bb[3 * i + 1] = wr.y; bb[3 * i + 2] = wr.win;
     }
-    if (do_nms) nms_dialect_c_into(bb.data(), &dets.score[a], (int)cnt, overlap, &keep);
+    if (do_nms) nms_dialect_c_into(bb.data(), dets.score.data() + a, (int)cnt, overlap, &keep);
     else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
     jdaResult& r = out[f];
     r.n = (int)keep.size(); r.landmark_n = L;

@@ -328,7 +328,7 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
       const DevLevel& d = hp.lv[l];
       bb[3 * i] = (int)(rel % (uint32_t)nx) * d.step; bb[3 * i + 1] = (int)(rel / (uint32_t)nx) * d.step; bb[3 * i + 2] = d.win;
     }
-    if (do_nms) nms_dialect_c_into(bb.data(), &dets.score[a], (int)cnt, overlap, &keep);
+    if (do_nms) nms_dialect_c_into(bb.data(), dets.score.data() + a, (int)cnt, overlap, &keep);
     else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
     jdaResult& r = out[f];
     r.n = (int)keep.size(); r.landmark_n = L;
