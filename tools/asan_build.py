@@ -17,8 +17,13 @@ GXX_FLAGS = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-fvisibility=hi
 
 
 def main():
+    global SAN
+    name = "asan"
+    if "--tsan" in sys.argv:          # libjda_tsan.so: ThreadSanitizer instead (lanes, tickets, the uploader and post-processing threads)
+        SAN = ["-fsanitize=thread", "-fno-omit-frame-pointer", "-g"]
+        name = "tsan"
     B.build()
-    objdir = B.OBJDIR + "_asan"
+    objdir = B.OBJDIR + "_" + name
     os.makedirs(objdir, exist_ok=True)
     flags = GXX_FLAGS + SAN
     objs, jobs = [], []
@@ -36,9 +41,9 @@ def main():
             raise RuntimeError(" ".join(cmd) + "\n" + r.stderr[-4000:])
     with ThreadPoolExecutor(8) as ex:
         list(ex.map(run, jobs))
-    lib = os.path.join(B.HERE, "libjda_asan.so")
+    lib = os.path.join(B.HERE, "libjda_%s.so" % name)
     run(["g++", "-shared", "-fPIC"] + SAN + ["-o", lib] + objs + ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
-    rt = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    rt = subprocess.run(["g++", "-print-file-name=lib%s.so" % name], capture_output=True, text=True).stdout.strip()
     print(lib)
     print(rt)
 
