@@ -135,3 +135,15 @@ def test_partial_model_headers_are_refused_by_the_cpp_entries(built, tmp_path):
         with pytest.raises(api.JdaError, match="partial model"):
             call()
     assert api.Cascador(full).T == 3
+
+
+def test_mutated_streams_are_refused_or_loaded_never_a_crash(built):
+    """tools/fuzz_model.py: truncated, resized, bit-flipped, padded model files and files given to the other real size's
+    creator -- every create returns NULL with a reason or a handle that serialises; (the same script runs on the sanitizer
+    build: profiles/r05_host_asan.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_model.py"), "400"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no crash" in out.stdout and " 0 creates accepted" not in out.stdout, out.stdout[-500:]
