@@ -9,6 +9,6 @@ export UBSAN_OPTIONS=print_stacktrace=1
 export PYTHONUNBUFFERED=1
 # (the sanitizer's dlopen interceptor loses torch's RUNPATH: its lazily loaded libraries are found through this)
 export LD_LIBRARY_PATH=$(python -c "import torch,os;print(os.path.join(os.path.dirname(torch.__file__),\"lib\"))"):$LD_LIBRARY_PATH
-LD_PRELOAD=$RT timeout 2400 python -m pytest tests/test_abi.py tests/test_ragged.py tests/test_device_post.py tests/test_reentrant.py tests/test_scan_persistent.py tests/test_gpu_parity.py tests/test_layouts.py tests/test_fddb.py tests/test_fuzz_calls.py -s -q -m gpu -p no:cacheprovider > gpurun_out/r05_w/suite_full.txt 2>&1; echo "rc=$?" >> gpurun_out/r05_w/suite_full.txt
+LD_PRELOAD=$RT timeout 2400 python -m pytest ${FILES:-tests/test_abi.py tests/test_ragged.py tests/test_device_post.py tests/test_reentrant.py tests/test_scan_persistent.py tests/test_gpu_parity.py tests/test_layouts.py tests/test_fddb.py tests/test_fuzz_calls.py} -s -q -m gpu -p no:cacheprovider > gpurun_out/r05_w/suite_full.txt 2>&1; echo "rc=$?" >> gpurun_out/r05_w/suite_full.txt
 grep -v "python3.10\|libffi\|_ctypes" gpurun_out/r05_w/suite_full.txt | grep -n "runtime error\|AddressSanitizer\|passed\|failed\|rc=" -A 6 | head -150 > gpurun_out/r05_w/suite.txt
 cat gpurun_out/r05_w/suite.txt
