@@ -111,10 +111,10 @@ enum { JDA_DIALECT_C = 0, JDA_DIALECT_CPP = 1 };
  * No C++ exception leaves the library: an allocation failure inside any entry (std::bad_alloc from the host side's
  * containers, the tables of a large model) is caught at the boundary and turned into the entry's error value -- NULL,
  * -1 or an empty jdaResult, the reference's own answer to a failed malloc (c/jda.c:487-493) -- with the reason here.
- * One SUCCESSFUL outcome also leaves a note here: when the persistent stage-0 scan kernel gives up waiting inside a
- * launch (a watchdog; never observed on hardware) or covers fewer windows than the plan holds, the pass is run again
- * with the closed-tile scan kernel and the call returns its (correct) results with "k_scan_p: watchdog word ..." as
- * the message and on stderr. */
+ * A successful call leaves it empty.  (When the persistent stage-0 scan kernel gives up waiting inside a launch -- a
+ * watchdog; never observed on hardware -- or covers fewer windows than the plan holds, the pass is run again with the
+ * closed-tile scan kernel: the call succeeds with correct results, says so on stderr and counts it in
+ * jdaStats::scan_fallbacks; it is not an error and is not reported here.) */
 JDA_API const char *jdaGetLastError(void);
 
 /* Opens a model of either layout; the layout is inferred from the file size
@@ -183,6 +183,8 @@ typedef struct {
   double scan_lds_ms;         /* HIP-event span of the LDS-tiled k_scan launches alone; only meaningful when the launches of
                                  a call run back to back on one stream (JDA_LANES=1 JDA_SIDE_STREAM=0), 0 otherwise */
   long long scan_lds_cart_n;  /* carts evaluated by the LDS-tiled k_scan launches (scan_cart_n minus the global-pixel levels) */
+  int scan_fallbacks;         /* passes of this call that were run a second time with the closed-tile scan kernel because the
+                                 persistent one tripped a watchdog or covered too few windows (results are correct; see stderr) */
 } jdaStats;
 
 typedef struct {
@@ -301,6 +303,35 @@ JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames
                               int width, int height, int minimum_size, int step,
                               double factor, double overlap, int nms,
                               jdaStats *stats, jdaResultD *out);
+
+/* The same with the frames already resident in device memory (frame i at d_frames + i*frame_stride): the entry the
+ * dialect-CPP throughput figures of bench.py are timed on. */
+JDA_API int jdaDetectBatchCppDevice(void *cascador, const unsigned char *d_frames, size_t frame_stride, int n,
+                                    int width, int height, int minimum_size, int step,
+                                    double factor, double overlap, int nms,
+                                    jdaStats *stats, jdaResultD *out);
+
+/* Dialect CPP ragged batch: n images of DIFFERENT sizes as one job -- literally the loop of the reference's `jda fddb`
+ * command, one joincascador.Detect(gray, ...) per image with fddb.method = 1 (src/test.cpp:100-170, line 142;
+ * src/jda/cascador.cpp:310-376,431-477).  images[i] is widths[i]*heights[i] bytes in HOST memory, rows back to back;
+ * out must point at n jdaResultD slots.  Per image the result is identical to jdaDetectBatchCpp on that image alone.
+ * The window sizes minimum_size, int(win*factor), ... (cascador.cpp:314,369) are one series for every image, an image
+ * uses the prefix that fits both its sides (cascador.cpp:333): levels, tile shapes and stage-0 tables are shared and
+ * the job runs as a few large passes, like jdaDetectBatchRagged.  Models with multi-scale split nodes run image by
+ * image inside.  PARITY UNPINNED like every dialect-CPP entry.  Returns 0 on success. */
+JDA_API int jdaDetectBatchCppRagged(void *cascador, const unsigned char *const *images, const int *widths,
+                                    const int *heights, int n, int minimum_size, int step,
+                                    double factor, double overlap, int nms,
+                                    jdaStats *stats, jdaResultD *out);
+
+/* Same, images already resident in device memory: image i starts at d_base + offsets[i], rows back to back. */
+JDA_API int jdaDetectBatchCppRaggedDevice(void *cascador, const unsigned char *d_base, const size_t *offsets,
+                                          const int *widths, const int *heights, int n, int minimum_size, int step,
+                                          double factor, double overlap, int nms,
+                                          jdaStats *stats, jdaResultD *out);
+
+/* Releases n dialect-CPP results at once (same as n jdaResultDRelease calls). */
+JDA_API void jdaResultsDRelease(jdaResultD *results, int n);
 
 /* Dialect CPP only: the similarity-transform mode of Validate (reference
  * src/jda/data.cpp:64-126, config key face.similarity_transform, common.cpp:214; off in

@@ -47,7 +47,7 @@ class jdaStats(C.Structure):
                 ("host_ms", C.c_double), ("scan_cart_n", C.c_longlong), ("scan_patch_n", C.c_longlong),
                 ("scan_launches", C.c_int), ("handoff_n", C.c_longlong), ("cart_total_n", C.c_longlong),
                 ("call_ms", C.c_double), ("dense_passes", C.c_int), ("scan_lds_ms", C.c_double),
-                ("scan_lds_cart_n", C.c_longlong)]
+                ("scan_lds_cart_n", C.c_longlong), ("scan_fallbacks", C.c_int)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_done_n"}
@@ -123,6 +123,17 @@ def _load():
     lib.jdaResultDRelease.argtypes = [jdaResultD]
     lib.jdaDetectBatchCpp.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+    if hasattr(lib, "jdaDetectBatchCppDevice"):     # (r06; older builds loaded through JDA_LIB_PATH lack them)
+        lib.jdaDetectBatchCppDevice.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+        lib.jdaDetectBatchCppRagged.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats),
+                                                C.POINTER(jdaResultD)]
+        lib.jdaDetectBatchCppRaggedDevice.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                      C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                      C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
+        lib.jdaResultsDRelease.restype = None
+        lib.jdaResultsDRelease.argtypes = [C.POINTER(jdaResultD), C.c_int]
     lib.jdaDetectBatchCppPyramid.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     if hasattr(lib, "jdaDetectBatchCppPyramidMS"):
@@ -511,6 +522,70 @@ class Cascador:
         if rc != 0:
             raise JdaError(last_error())
         out = [_take_d(res[i]) for i in range(n)]
+        return (out, st.asdict()) if stats else out
+
+    def _collect_d(self, res, n, keep_results):
+        if keep_results:
+            return [_take_d(res[i]) for i in range(n)]
+        out = [res[i].n for i in range(n)]
+        lib.jdaResultsDRelease(res, n)
+        return out
+
+    def detect_batch_cpp_device(self, d_frames, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,
+                                keep_results=True):
+        """jdaDetectBatchCppDevice: a torch uint8 CUDA tensor [n, h, w] resident in HBM."""
+        assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
+        n, h, w = d_frames.shape
+        res = (jdaResultD * max(n, 1))()
+        st = jdaStats()
+        rc = lib.jdaDetectBatchCppDevice(self.h, C.c_void_p(d_frames.data_ptr()), h * w, n, w, h, minimum_size, step, factor,
+                                         overlap, 1 if nms else 0, C.byref(st) if stats else None, res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = self._collect_d(res, n, keep_results)
+        return (out, st.asdict()) if stats else out
+
+    def detect_ragged_cpp(self, images, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,
+                          keep_results=True):
+        """jdaDetectBatchCppRagged: a list of uint8 [h, w] arrays of different sizes in host memory -- the reference's
+        `jda fddb` loop (one joincascador.Detect per image, src/test.cpp:142) as one job."""
+        images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        n = len(images)
+        ptrs = _image_ptrs(images)
+        ws = (C.c_int * max(n, 1))(*[im.shape[1] for im in images])
+        hs = (C.c_int * max(n, 1))(*[im.shape[0] for im in images])
+        res = (jdaResultD * max(n, 1))()
+        st = jdaStats()
+        rc = lib.jdaDetectBatchCppRagged(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0,
+                                         C.byref(st) if stats else None, res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = self._collect_d(res, n, keep_results)
+        return (out, st.asdict()) if stats else out
+
+    def detect_ragged_cpp_packed(self, buf, offsets, widths, heights, minimum_size=20, step=5, factor=1.2, overlap=0.3,
+                                 nms=True, stats=False, keep_results=True):
+        """The same for images packed in ONE buffer (image i = buf[offsets[i] : offsets[i] + w*h]): a numpy uint8 array
+        (jdaDetectBatchCppRagged) or a torch uint8 CUDA tensor (jdaDetectBatchCppRaggedDevice)."""
+        n = len(offsets)
+        ws = (C.c_int * max(n, 1))(*[int(v) for v in widths])
+        hs = (C.c_int * max(n, 1))(*[int(v) for v in heights])
+        res = (jdaResultD * max(n, 1))()
+        st = jdaStats()
+        sp = C.byref(st) if stats else None
+        if isinstance(buf, np.ndarray):
+            assert buf.dtype == np.uint8 and buf.flags.c_contiguous
+            base = buf.ctypes.data
+            ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[C.cast(C.c_void_p(base + int(off)), C.POINTER(C.c_ubyte)) for off in offsets])
+            rc = lib.jdaDetectBatchCppRagged(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0, sp, res)
+        else:
+            assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
+            offs = (C.c_size_t * max(n, 1))(*[int(v) for v in offsets])
+            rc = lib.jdaDetectBatchCppRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, minimum_size, step,
+                                                   factor, overlap, 1 if nms else 0, sp, res)
+        if rc != 0:
+            raise JdaError(last_error())
+        out = self._collect_d(res, n, keep_results)
         return (out, st.asdict()) if stats else out
 
     def detect_batch_cpp_pyramid(self, frames, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,

@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjda.so")
-SOURCES = ["k_misc.hip", "k_scan.hip", "k_scan_d.hip", "k_scan_r.hip", "k_scan_p.hip", "k_finish.hip", "k_wide.hip", "k_stage.hip", "k_post.hip",
-           "abi.cpp", "pass.cpp", "detect.cpp", "tickets.cpp", "ragged.cpp", "post_host.cpp", "lanes.cpp", "plans.cpp", "model_dev.cpp",
+SOURCES = ["k_misc.hip", "k_scan.hip", "k_scan_d.hip", "k_scan_r.hip", "k_scan_dr.hip", "k_scan_p.hip", "k_finish.hip", "k_wide.hip", "k_stage.hip", "k_post.hip",
+           "abi.cpp", "pass.cpp", "detect.cpp", "detect_cpp.cpp", "tickets.cpp", "ragged.cpp", "post_host.cpp", "lanes.cpp", "plans.cpp", "model_dev.cpp",
            "model.cpp", "plan.cpp", "post.cpp"]
 HEADERS = ["kernels.h", "kernels_common.h", "finish_common.h", "scan_walk.h", "k_scan_impl.h", "model.h", "plan.h", "post.h", "host.h", "pass.h", "run.h", "detect.h", os.path.join("..", "..", "include", "jda.h")]
 OBJDIR = os.path.join(HERE, "build")

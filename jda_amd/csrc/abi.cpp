@@ -13,9 +13,11 @@ using namespace jda;
 // 512 MB of a big model's tables, std::string in the error channel, std::thread) and a std::bad_alloc that left
 // jdaDetect* would end the caller's process in std::terminate.  The reference answers an allocation failure with NULL
 // (c/jda.c:487-493); every entry below is a function-try-block whose handler reports through jdaGetLastError() and
-// returns the entry's error value (NULL / -1 / an empty jdaResult).  Stack unwinding has already given back what the
-// call held (LaneSet, PlanPin); the detect entries also wait for whatever the call had queued on the device, because
-// the caller is free to release its frames as soon as the entry returns.
+// returns the entry's error value (NULL / -1 / an empty jdaResult).  Stack unwinding has given back what the call held
+// (PlanPin; LaneSet, which waits for its lanes' streams BEFORE it returns them to the pool when it is destroyed by an
+// exception); the detect entries also wait for the device as a whole, because the caller is free to release its frames
+// as soon as the entry returns.  Helper threads (the ticket issuer, the ragged uploader, the post-processing workers)
+// catch inside their bodies and hand the failure to the thread that joins them.
 namespace {
 void abi_exception(const char* fn, bool sync_device) noexcept {
   const char* what = "unknown C++ exception";
@@ -400,7 +402,7 @@ static int detect_cpp_pyramid_impl(void* cascador, const unsigned char* const* f
   RunStats rs_total;
   long long patch_total = 0;
   // level images ping-pong inside one buffer; level 0 is the staged input
-  DevBuf levels;
+  struct LevelBuf : DevBuf { ~LevelBuf() { release(); } } levels;      // (freed on every way out, also an exception's)
   const size_t lvl_stride = ((size_t)width * height + 255) & ~(size_t)255;
   auto body = [&]() -> bool {
     if (!levels.reserve(2 * lvl_stride * (size_t)std::max(n, 1))) return false;
@@ -441,7 +443,12 @@ static int detect_cpp_pyramid_impl(void* cascador, const unsigned char* const* f
       if (nw < 1 || nh < 1) break;
       uint8_t* nxt = (uint8_t*)levels.p + (size_t)(li & 1) * lvl_stride * (size_t)n;
       JDA_HIP(launch_resize_cv(cur, cur_stride, n, w, h, nxt, lvl_stride, nw, nh, ln->stream));   // cascador.cpp:302
-      JDA_HIP(hipStreamSynchronize(ln->stream));
+      // (no host wait: the next level's pass is queued behind the resize on this lane's stream; a second lane the first
+      // level took -- the first level has the most windows, so no later level takes one more -- waits for it on the device)
+      if (lanes.v.size() > 1) {
+        JDA_HIP(hipEventRecord(ln->ev_user, ln->stream));
+        for (size_t l = 1; l < lanes.v.size(); l++) JDA_HIP(hipStreamWaitEvent(lanes.v[l]->stream, ln->ev_user, 0));
+      }
       cur = nxt; cur_stride = lvl_stride; w = nw; h = nh; li++;
     }
     return true;
@@ -582,59 +589,44 @@ int jdaDetectBatchCpp(void* cascador, const unsigned char* const* frames, int n,
   g_err.clear();
   Cascador* c = (Cascador*)cascador;
   if (!c || !frames || !out || n < 0) { fail("bad arguments"); return -1; }
-  const int L = c->hm.L, dim = c->hm.dim();
-  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
-  if (!cpp_model_complete(c)) return -1;
-  ScanPlan sp; std::string err;
-  if (!plan_dialect_cpp(width, height, minimum_size, step, factor, &sp, &err)) { fail(err); return -1; }
-  unsigned long long fb; std::memcpy(&fb, &factor, 8);
-  PlanKey key{width, height, JDA_DIALECT_CPP, minimum_size, step, c->similarity, fb};
-  PlanEntry* pe = nullptr;
-  if (!begin_call<double>(c, key, sp, JDA_DIALECT_CPP, &pe)) return -1;
-  PlanPin pin{c, pe};
-  LaneSet lanes(c);
-  size_t stride = 0;
-  if (!lanes.take(1) || !stage_frames(lanes.v[0], frames, n, (size_t)width * height, &stride, true)) return -1;
-  RawDets<double> dets;
-  RunStats rs;
-  if (!run_device<double>(c, lanes, pe, (const uint8_t*)lanes.v[0]->frames.p, stride, n, false, 0.0, nullptr, &dets, nullptr, &rs,
-                          HostFrames{frames, (size_t)width * height})) return -1;
-  const double t0 = now_ms();
-  std::vector<size_t> first(n + 1, dets.gid.size());
-  {
-    size_t i = 0;
-    for (int f = 0; f < n; f++) {
-      first[f] = i;
-      while (i < dets.gid.size() && dets.gid[i] / (uint32_t)sp.windows == (uint32_t)f) i++;
-    }
-    first[n] = i;
-  }
-  parallel_for(n, [&](int f) {
-    const size_t a = first[f], cnt = first[f + 1] - a;
-    std::vector<int> rc(cnt * 4);
-    for (size_t i = 0; i < cnt; i++) {
-      const WinRef wr = locate(sp, dets.gid[a + i]);
-      rc[4 * i] = wr.x; rc[4 * i + 1] = wr.y; rc[4 * i + 2] = wr.win; rc[4 * i + 3] = wr.win;
-    }
-    std::vector<int> pick;
-    if (nms) pick = nms_dialect_cpp(rc.data(), dets.score.data() + a, (int)cnt, overlap);
-    else { pick.resize(cnt); std::iota(pick.begin(), pick.end(), 0); }
-    jdaResultD& r = out[f];
-    r.n = (int)pick.size(); r.landmark_n = L;
-    r.rects = (int*)std::malloc(std::max<size_t>(1, pick.size() * 4) * sizeof(int));
-    r.scores = (double*)std::malloc(std::max<size_t>(1, pick.size()) * sizeof(double));
-    r.shapes = (double*)std::malloc(std::max<size_t>(1, pick.size() * dim) * sizeof(double));
-    for (size_t i = 0; i < pick.size(); i++) {
-      const int k = pick[i];
-      std::memcpy(r.rects + 4 * i, &rc[4 * k], 4 * sizeof(int));
-      r.scores[i] = dets.score[a + k];
-      double* sh = r.shapes + i * dim;
-      std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(double));
-      relocate_dialect_cpp(sh, L, rc[4 * k], rc[4 * k + 1], rc[4 * k + 2], rc[4 * k + 3]);
-    }
-  }, dets.gid.size() < 6000);
-  fill_stats(stats, rs, sp.windows * n, c->hm.T, c->hm.K, now_ms() - t0);
-  return 0;
+  if (width <= 0 || height <= 0) { fail("frame has no pixels"); return -1; }
+  for (int i = 0; i < n; i++) if (!frames[i]) { fail("null frame pointer"); return -1; }
+  return detect_cpp_device(c, nullptr, 0, n, width, height, CppCall{minimum_size, step, factor, overlap, nms}, stats, out, frames);
 } JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppDevice(void* cascador, const unsigned char* d_frames, size_t frame_stride, int n, int width, int height,
+                            int minimum_size, int step, double factor, double overlap, int nms,
+                            jdaStats* stats, jdaResultD* out) try {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_frames || !out || n < 0) { fail("bad arguments"); return -1; }
+  return detect_cpp_device(c, d_frames, frame_stride, n, width, height, CppCall{minimum_size, step, factor, overlap, nms}, stats, out);
+} JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppRagged(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
+                            int minimum_size, int step, double factor, double overlap, int nms,
+                            jdaStats* stats, jdaResultD* out) try {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !images || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  return detect_ragged_cpp(c, images, nullptr, nullptr, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, out);
+} JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppRaggedDevice(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
+                                  const int* heights, int n, int minimum_size, int step, double factor, double overlap, int nms,
+                                  jdaStats* stats, jdaResultD* out) try {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
+  return detect_ragged_cpp(c, nullptr, d_base, offsets, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, out);
+} JDA_ABI_CATCH_SYNC(-1)
+
+void jdaResultsDRelease(jdaResultD* results, int n) {
+  if (!results) return;
+  for (int i = 0; i < n; i++) {
+    std::free(results[i].rects); std::free(results[i].shapes); std::free(results[i].scores);
+    results[i].rects = nullptr; results[i].shapes = nullptr; results[i].scores = nullptr; results[i].n = 0;
+  }
+}
 
 }  // extern "C"

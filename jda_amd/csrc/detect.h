@@ -24,15 +24,28 @@ int detect_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
                     float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
                     jdaResult* out, const unsigned char* const* host_frames = nullptr);
 
+// detect_cpp.cpp: dialect CPP, method 1 (cascador.cpp:310-376,431-477) on a uniform batch; frames on the device
+// (d_frames) or, with host_frames set, in host memory
+struct CppCall { int minimum_size, step; double factor, overlap; int nms; };
+int detect_cpp_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height, const CppCall& call,
+                      jdaStats* stats, jdaResultD* out, const unsigned char* const* host_frames = nullptr);
+// NMS (cascador.cpp:387-429), relocation (462-474) and the jdaResultD of one image from its n candidates in scan order:
+// rects (x, y, w, h), scores, window-normalised shapes of `dim` doubles each
+void emit_cpp_result(const int* rects4, const double* scores, const double* shapes, int n, int L, double overlap, bool nms,
+                     jdaResultD* out);
+jdaResultD empty_result_d(int landmark_n);
+
 // tickets.cpp
 int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, int width, int height,
                     float scale, int min_size, int max_size, float th, const jdaDetectOptions* opt,
                     const unsigned char* const* host_frames = nullptr);
 int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out);
 
-// ragged.cpp
+// ragged.cpp: a list of differently sized images as one job, either dialect
 int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
                   const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
                   const jdaDetectOptions* opt, jdaResult* out);
+int detect_ragged_cpp(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                      const int* widths, const int* heights, int n, const CppCall& call, jdaStats* stats, jdaResultD* out);
 
 }  // namespace jda

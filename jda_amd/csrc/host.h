@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <map>
@@ -462,6 +463,10 @@ struct LaneSet {
   Lane* detach(size_t i) { Lane* l = v[i]; v.erase(v.begin() + i); return l; }   // the caller keeps it (submitted batch)
   ~LaneSet() {
     if (v.empty()) return;
+    // unwinding (an exception on its way to the C ABI's barrier): what the call has queued on its lanes is waited for
+    // HERE, while the lanes are still this call's -- once they are back in the pool another caller may take them
+    if (std::uncaught_exceptions() > 0)
+      for (Lane* l : v) { if (l->stream) (void)hipStreamSynchronize(l->stream); if (l->side) (void)hipStreamSynchronize(l->side); }
     { std::lock_guard<std::mutex> lk(c->mu); for (Lane* l : v) l->busy = false; }
     c->lane_cv.notify_all();
   }
@@ -519,6 +524,7 @@ struct RunStats {
   double gpu_ms = 0, scan_ms = 0, scan_lds_ms = 0;
   int scan_launches = 0;
   int dense_passes = 0;
+  int scan_fallbacks = 0;      // passes run again with k_scan because k_scan_p's launch tripped a watchdog / came back short
 };
 
 

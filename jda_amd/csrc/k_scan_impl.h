@@ -14,7 +14,8 @@
 //
 // This file is the kernel and its launchers; three translation units include it and instantiate one third of the
 // (Real, TRACE, MODE, BLOCK, DEPTH, RAGGED, NORM) combinations each, so that they compile side by side (one unit took
-// 80 s of a 95-s build): k_scan.hip (dialect C, uniform batches), k_scan_d.hip (dialect CPP), k_scan_r.hip (ragged).
+// 80 s of a 95-s build): k_scan.hip (dialect C, uniform batches), k_scan_d.hip (dialect CPP), k_scan_r.hip (ragged, dialect C),
+// k_scan_dr.hip (ragged, dialect CPP).
 #pragma once
 #include "kernels_common.h"
 #include "scan_walk.h"
@@ -666,13 +667,18 @@ hipError_t launch_scan_ragged_mode(const DevPlan* d_plan, const DevModelT<Real>&
 }
 }  // namespace
 
+#if defined(JDA_SCAN_TU_RAGGED) || defined(JDA_SCAN_TU_RAGGED_DOUBLE)
+// (no trace: ragged passes are jdaDetectBatchRagged's / jdaDetectBatchCppRagged's; everything else runs image by image)
 #ifdef JDA_SCAN_TU_RAGGED
-// (dialect C, no trace: ragged passes are jdaDetectBatchRagged's; everything else runs image by image)
+#define JDA_RAGGED_REAL float
+#else
+#define JDA_RAGGED_REAL double
+#endif
 template <>
-hipError_t launch_scan_ragged<float>(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
-                                     const DevModelT<float>& m, const S0Node* table, const WorkT<float>& w, int pix_bytes,
+hipError_t launch_scan_ragged<JDA_RAGGED_REAL>(int mode, int block, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
+                                     const DevModelT<JDA_RAGGED_REAL>& m, const S0Node* table, const WorkT<JDA_RAGGED_REAL>& w, int pix_bytes,
                                      int blk_base, int blk_n, hipStream_t stream) {
-  using Real = float;
+  using Real = JDA_RAGGED_REAL;
   if (blk_n <= 0) return hipSuccess;
   if (!w.segs || !w.blk || trace) return hipErrorInvalidValue;
   switch (mode) {
@@ -686,11 +692,6 @@ hipError_t launch_scan_ragged<float>(int mode, int block, bool trace, int handof
 }
 #endif
 #ifdef JDA_SCAN_TU_DOUBLE
-template <>
-hipError_t launch_scan_ragged<double>(int, int, bool, int, int, int, const DevPlan*, const DevModelT<double>&, const S0Node*,
-                                      const WorkT<double>&, int, int, int, hipStream_t) {
-  return hipErrorInvalidValue;
-}
 template hipError_t launch_scan<double>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<double>&,
                                         const S0Node*, const WorkT<double>&, hipStream_t);
 #endif

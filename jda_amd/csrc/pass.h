@@ -602,7 +602,8 @@ struct Pass {
 
   // The persistent scan of this pass gave up (watchdog) or came back short: nothing of the pass has been counted or
   // collected yet, so the whole pass is issued again on the same lane with k_scan's closed tiles, and the caller gets
-  // correct results plus a note in jdaGetLastError() / on stderr (the call itself succeeds).
+  // correct results, a note on stderr and jdaStats::scan_fallbacks (the call itself succeeds: jdaGetLastError() stays
+  // empty -- an empty result with a non-empty error string is jdaDetect's only failure signal).
   bool recover_scan(unsigned long long err, long long got, long long expect) {
     char msg[256];
     std::snprintf(msg, sizeof msg, "k_scan_p: watchdog word %llu, %lld of %lld windows covered -- pass of %d frame(s) run again with k_scan",
@@ -614,7 +615,7 @@ struct Pass {
     p_launches = 0; post_issued = false; posted = false; post_cap = 0; mid_direct = false; n_tail = -1; n_out = 0; out_copied = 0;
     host_frames = nullptr;                 // (already in the staging buffer)
     if (!issue_scan(a_hbuf, a_hs, a_qbuf, a_qs, nullptr) || !after_tail() || !issue_counters() || !after_counters()) return false;
-    g_err = msg;
+    rs->scan_fallbacks++;                  // (jdaStats::scan_fallbacks: the error channel stays for errors)
     return true;
   }
 

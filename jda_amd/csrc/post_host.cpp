@@ -58,6 +58,10 @@ class PostPool {
     while (job->done.load(std::memory_order_acquire) < job->chunks) std::this_thread::yield();
     { std::lock_guard<std::mutex> lk(mu_); job_.reset(); armed_until_.store(0.0); }
     job_mu_.unlock();
+    // an item threw on a worker (an allocation inside fn): it was caught there -- an exception that leaves a std::thread
+    // body ends the process -- and is raised again here, on the caller's thread, where the C ABI's barrier turns it
+    // into the entry's error value
+    if (job->threw.load(std::memory_order_acquire)) throw std::bad_alloc();
   }
 
  private:
@@ -65,11 +69,13 @@ class PostPool {
     const std::function<void(int)>* fn = nullptr;   // valid until every chunk is done (run() waits for that)
     int n = 0, chunks = 0, chunk = 8;
     std::atomic<int> next{0}, done{0};
+    std::atomic<bool> threw{false};
   };
   static void work(Job& j) {
     for (int c; (c = j.next.fetch_add(1)) < j.chunks;) {
       const int e = std::min(j.n, (c + 1) * j.chunk);
-      for (int i = c * j.chunk; i < e; i++) (*j.fn)(i);
+      try { for (int i = c * j.chunk; i < e; i++) (*j.fn)(i); }
+      catch (...) { j.threw.store(true, std::memory_order_release); }
       j.done.fetch_add(1, std::memory_order_release);
     }
   }
@@ -150,6 +156,7 @@ void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int T, int 
   st->scan_cart_n = rs.carts_scan; st->scan_patch_n = rs.win_scan; st->scan_launches = rs.scan_launches;
   st->handoff_n = rs.tail;
   st->dense_passes = rs.dense_passes;
+  st->scan_fallbacks = rs.scan_fallbacks;
   st->scan_lds_ms = rs.scan_lds_ms; st->scan_lds_cart_n = rs.carts_scan - rs.carts_scan_glb;
 }
 

@@ -1,5 +1,5 @@
-// libjda.so, host side: images of different sizes as ONE job (jdaDetectBatchRagged[Device]; the reference's FDDB loop,
-// src/test.cpp:100-170, is one Detect per image).
+// libjda.so, host side: images of different sizes as ONE job (jdaDetectBatchRagged[Device], jdaDetectBatchCppRagged[Device];
+// the reference's FDDB loop, src/test.cpp:100-170, is one Detect per image).
 #include "detect.h"
 
 namespace jda {
@@ -11,6 +11,10 @@ namespace jda {
 // passes: the window sizes of c/jda.c:331-333 are the same series for every image (an image uses the prefix that fits
 // it), so the levels, their tile shapes and stage-0 tables are shared, and the images are staged with ONE row pitch.
 // Per image the results are those of jdaDetect on that image.
+// Dialect CPP (r06) -- the dialect the reference's fddb() itself runs, joincascador.Detect with method 1
+// (src/test.cpp:142, cascador.cpp:310-376): its window sizes are minimum_size, int(win * factor), ... with a fixed pixel
+// step (cascador.cpp:314,369), again one series for every image, of which an image takes the prefix that fits both its
+// sides (cascador.cpp:333).  The same job structure serves it, on the fp64 instantiations of the kernels.
 
 struct RaggedJob {
   int n = 0;
@@ -21,6 +25,10 @@ struct RaggedJob {
   ScanPlan levels;                  // global level list; nx, ny = nominal (mean) grids, width = pitch
   std::vector<int> n_lv;            // levels image i has (a prefix of the global list)
   PlanEntry* pe = nullptr;
+  bool cpp = false;                 // dialect CPP (call: its parameters), else dialect C (scale, min_size, max_size)
+  CppCall call{};
+  float scale = 0.f; int min_size = 0, max_size = 0;
+  int real_bytes() const { return cpp ? 8 : 4; }
   uint8_t* d_job_raw = nullptr;     // host job with a helper thread: every chunk's tight images go here ...
   std::vector<size_t> raw_off;      // ... chunk k at d_job_raw + raw_off[k]
 };
@@ -37,7 +45,8 @@ static int ragged_levels_of(const RaggedJob& job, int w, int h) {
 
 // Geometry of a ragged call: common pitch, global levels with nominal grids, the plan (tile shapes + tables).
 // Returns 0 = ok, 1 = this job needs the per-image fallback, -1 = error.
-static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size, int max_size) {
+static int ragged_prepare(Cascador* c, RaggedJob* job) {
+  const float scale = job->scale; const int min_size = job->min_size, max_size = job->max_size;
   int max_w = 0, max_min = 0;
   for (int i = 0; i < job->n; i++) {
     if (job->widths[i] <= 0 || job->heights[i] <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
@@ -46,7 +55,8 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
     max_min = std::max(max_min, std::min(job->widths[i], job->heights[i]));
   }
   std::string err;
-  if (!plan_dialect_c(max_min, max_min, scale, min_size, max_size, &job->levels, &err)) { fail(err); return -1; }
+  if (job->cpp ? !plan_dialect_cpp(max_min, max_min, job->call.minimum_size, job->call.step, job->call.factor, &job->levels, &err)
+               : !plan_dialect_c(max_min, max_min, scale, min_size, max_size, &job->levels, &err)) { fail(err); return -1; }
   const int nl = (int)job->levels.levels.size();
   if (nl > kMaxLevels) return 1;
   int pitch = (max_w + 15) & ~15;
@@ -78,8 +88,13 @@ static int ragged_prepare(Cascador* c, RaggedJob* job, float scale, int min_size
   job->levels.windows = 0;
   unsigned sb; std::memcpy(&sb, &scale, 4);
   PlanKey key{pitch, nl, 3 /* ragged, dialect C */, (int)sb, std::max(min_size, 24), max_size <= 0 ? -1 : max_size, h};
+  if (job->cpp) {
+    unsigned long long fb; std::memcpy(&fb, &job->call.factor, 8);
+    h = (h ^ fb) * 1099511628211ull;
+    key = PlanKey{pitch, nl, 4 /* ragged, dialect CPP */, job->call.minimum_size, job->call.step, c->similarity, h};
+  }
   std::unique_lock<std::mutex> lk(c->mu);
-  if (!get_plan(c, lk, key, job->levels, JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
+  if (!get_plan(c, lk, key, job->levels, job->cpp ? JDA_DIALECT_CPP : JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
   if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
   if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
   for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;
@@ -120,12 +135,13 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   int th_lds[kMaxLevels];
   {
     const HostModel& hm = c->hm;
-    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), 4));
+    const int rb = job.real_bytes();
+    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), rb));
     for (int l = 0; l < nl; l++) {
       const DevLevel& d = hp.lv[l];
       if (d.tiled == 2) { th_lds[l] = d.th; continue; }
       const int nominal = d.pitch * (d.win + (d.th - 1) * d.step);
-      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), 4, false, d.tw * d.th > 256 ? 512 : 256);
+      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), rb, false, d.tw * d.th > 256 ? 512 : 256);
       const int per_cu = std::max(1, (160 * 1024) / (fixed + nominal));
       const int room = (160 * 1024) / per_cu - fixed - 64;
       th_lds[l] = ragged_th_lds(d, std::max(nominal, std::min(room, nominal * (int)c->kn.ragged_tile_grow_pct / 100)));
@@ -347,55 +363,141 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
   return now_ms() - t0;
 }
 
+// The same for dialect CPP: candidates of an image in scan order -> Rect(x, y, win, win) (cascador.cpp:339), NMS by score
+// (cascador.cpp:387-429), relocation (462-474), jdaResultD.
+static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<double>& dets,
+                          const CppCall& call, jdaResultD* out) {
+  const double t0 = now_ms();
+  const int L = c->hm.L, dim = c->hm.dim();
+  const DevPlan& hp = job.pe->hp;
+  std::vector<size_t> first(ch.n + 1, dets.gid.size());
+  {
+    size_t i = 0;
+    for (int f = 0; f < ch.n; f++) {
+      first[f] = i;
+      while (i < dets.gid.size() && dets.gid[i] < ch.gid_base[f + 1]) i++;
+    }
+    first[ch.n] = i;
+  }
+  parallel_for(ch.n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    static thread_local std::vector<int> rc;
+    rc.resize(cnt * 4);
+    const int W = ch.widths[f], H = ch.heights[f];
+    int l = 0;
+    uint32_t lbase = ch.gid_base[f];
+    int nx = 0, cntl = 0;
+    auto level_grid = [&](int lv) {
+      const DevLevel& d = hp.lv[lv];
+      nx = (W - d.win) / d.step + 1;
+      cntl = nx * ((H - d.win) / d.step + 1);
+    };
+    if (cnt) level_grid(0);
+    for (size_t i = 0; i < cnt; i++) {          // gids ascend: levels are walked once
+      const uint32_t g = dets.gid[a + i];
+      while (g >= lbase + (uint32_t)cntl) { lbase += (uint32_t)cntl; l++; level_grid(l); }
+      const uint32_t rel = g - lbase;
+      const DevLevel& d = hp.lv[l];
+      rc[4 * i] = (int)(rel % (uint32_t)nx) * d.step; rc[4 * i + 1] = (int)(rel / (uint32_t)nx) * d.step;
+      rc[4 * i + 2] = d.win; rc[4 * i + 3] = d.win;
+    }
+    emit_cpp_result(rc.data(), dets.score.data() + a, dets.shape.data() + a * dim, (int)cnt, L, call.overlap, call.nms != 0, &out[f]);
+  }, dets.gid.size() < 6000);
+  return now_ms() - t0;
+}
+
 static void add_stats(RunStats* a, const RunStats& b) {
   a->carts += b.carts; a->out += b.out; a->carts_scan += b.carts_scan; a->carts_scan_glb += b.carts_scan_glb;
   a->win_scan += b.win_scan; a->tail += b.tail; a->gpu_ms += b.gpu_ms; a->scan_ms += b.scan_ms;
-  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes;
+  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes; a->scan_fallbacks += b.scan_fallbacks;
   for (int t = 0; t < kMaxStages; t++) a->stage_done[t] += b.stage_done[t];
 }
 
+// What the two dialects do differently around a ragged job: the call's parameters, the per-image fallback, the
+// post-processing and the result type.
+struct RagSideC {
+  using Real = float; using Result = jdaResult;
+  float scale; int min_size, max_size; float th; const jdaDetectOptions* opt; jdaResult* out;
+  jdaStats* stats() const { return opt ? opt->stats : nullptr; }
+  bool apply_th() const { return true; }
+  Real final_th() const { return th; }
+  void blank(int n, int L) const { for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; } }
+  bool filled(int i) const { return out[i].bboxes != nullptr; }
+  void set_empty(int i, int L) const { out[i] = empty_result(L); }
+  void describe(RaggedJob* job) const { job->cpp = false; job->scale = scale; job->min_size = min_size; job->max_size = max_size; }
+  bool usable(Cascador*) const { return true; }
+  // one image as a pass of its own (detect.cpp)
+  int one_image(Cascador* c, const unsigned char* host, const uint8_t* dev, int W, int H, jdaStats* st1, int i) const {
+    jdaDetectOptions o1;
+    if (opt) o1 = *opt; else jdaDetectOptionsInit(&o1);
+    o1.stats = st1; o1.hip_stream = nullptr;
+    const unsigned char* one[1] = {host};
+    return host ? detect_c_device(c, nullptr, 0, 1, W, H, scale, min_size, max_size, th, &o1, out + i, one)
+                : detect_c_device(c, dev, (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
+  }
+  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets) const { return post_ragged(c, job, ch, dets, opt, out + ch.i0); }
+  bool device_post(Cascador* c, int n_imgs) const { return c->kn.device_post >= 1 && n_imgs >= c->kn.device_post_min_frames; }
+  bool post_nms() const { return !opt || opt->nms; }
+  float post_overlap() const { return opt ? opt->nms_overlap : 0.3f; }
+};
+struct RagSideCpp {
+  using Real = double; using Result = jdaResultD;
+  CppCall call; jdaStats* st; jdaResultD* out;
+  jdaStats* stats() const { return st; }
+  bool apply_th() const { return false; }                  // Validate has no final threshold (cascador.cpp:166-211)
+  Real final_th() const { return 0.0; }
+  void blank(int n, int L) const { for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].rects = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; } }
+  bool filled(int i) const { return out[i].rects != nullptr; }
+  void set_empty(int i, int L) const { out[i] = empty_result_d(L); }
+  void describe(RaggedJob* job) const { job->cpp = true; job->call = call; }
+  bool usable(Cascador* c) const { return cpp_model_complete(c); }
+  int one_image(Cascador* c, const unsigned char* host, const uint8_t* dev, int W, int H, jdaStats* st1, int i) const {
+    const unsigned char* one[1] = {host};
+    return host ? detect_cpp_device(c, nullptr, 0, 1, W, H, call, st1, out + i, one)
+                : detect_cpp_device(c, dev, (size_t)W * H, 1, W, H, call, st1, out + i);
+  }
+  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<double>& dets) const { return post_ragged(c, job, ch, dets, call, out + ch.i0); }
+  bool device_post(Cascador*, int) const { return false; }  // (k_post is dialect C's NMS; the multimap NMS runs on the host)
+  bool post_nms() const { return call.nms != 0; }
+  float post_overlap() const { return (float)call.overlap; }
+};
+
 // A ragged job: images of different sizes, in host memory (host_imgs) or on the device (d_base + d_offsets).
-int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
-                         const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
-                         const jdaDetectOptions* opt, jdaResult* out) {
+template <typename Side>
+static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                           const int* widths, const int* heights, int n, const Side& side) {
+  using Real = typename Side::Real;
   const double t_call = now_ms();
-  if (!c || !out || n < 0 || !widths || !heights || (!host_imgs && !(d_base && d_offsets))) { fail("bad arguments"); return -1; }
+  if (!c || !side.out || n < 0 || !widths || !heights || (!host_imgs && !(d_base && d_offsets))) { fail("bad arguments"); return -1; }
   const int L = c->hm.L;
-  for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
+  side.blank(n, L);
+  if (!side.usable(c)) return -1;
   if (n == 0) return 0;
   {
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!ensure_device(c) || !upload_model<float>(c)) return -1;
+    if (!ensure_device(c) || !upload_model<Real>(c)) return -1;
   }
   RunStats total;
   long long patch_n = 0;
   double post_ms = 0;
-  jdaDetectOptions o1;
   jdaStats st1;
   auto finish = [&]() {
-    fill_stats(opt ? opt->stats : nullptr, total, patch_n, c->hm.T, c->hm.K, post_ms);
-    if (opt && opt->stats) opt->stats->call_ms = now_ms() - t_call;
+    fill_stats(side.stats(), total, patch_n, c->hm.T, c->hm.K, post_ms);
+    if (side.stats()) side.stats()->call_ms = now_ms() - t_call;
     return 0;
   };
   // per-image passes: models the ragged scan does not cover (multi-scale split nodes, levels without a tile), and
   // cascades that reject so little that the dense kernel is the right tool
   auto fallback = [&]() -> int {
     for (int i = 0; i < n; i++) {
-      if (opt) o1 = *opt; else jdaDetectOptionsInit(&o1);
-      o1.stats = &st1; o1.hip_stream = nullptr;
       const int W = widths[i], H = heights[i];
       if (W <= 0 || H <= 0) { fail("image " + std::to_string(i) + " has no pixels"); return -1; }
-      int rc;
-      if (host_imgs) {
-        const unsigned char* one[1] = {host_imgs[i]};
-        rc = detect_c_device(c, nullptr, 0, 1, W, H, scale, min_size, max_size, th, &o1, out + i, one);
-      } else {
-        rc = detect_c_device(c, d_base + d_offsets[i], (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
-      }
+      if (host_imgs && !host_imgs[i]) { fail("null image pointer"); return -1; }
+      const int rc = side.one_image(c, host_imgs ? host_imgs[i] : nullptr, host_imgs ? nullptr : d_base + d_offsets[i], W, H, &st1, i);
       if (rc != 0) return -1;
       total.carts += st1.cart_total_n; total.out += st1.face_patch_n; total.carts_scan += st1.scan_cart_n;
       total.win_scan += st1.scan_patch_n; total.tail += st1.handoff_n; total.gpu_ms += st1.gpu_ms; total.scan_ms += st1.scan_ms;
-      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes;
+      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes; total.scan_fallbacks += st1.scan_fallbacks;
       for (int t = 0; t < 16 && t < kMaxStages; t++) total.stage_done[t] += st1.stage_done_n[t];
       patch_n += st1.patch_n; post_ms += st1.host_ms;
     }
@@ -404,12 +506,13 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
   if (c->hm.multi_scale()) return fallback();
   RaggedJob job;
   job.n = n; job.widths = widths; job.heights = heights; job.host_imgs = host_imgs; job.d_base = d_base; job.d_offsets = d_offsets;
-  const int prep = ragged_prepare(c, &job, scale, min_size, max_size);
+  side.describe(&job);
+  const int prep = ragged_prepare(c, &job);
   PlanPin pin{c, job.pe};
   if (prep < 0) return -1;
   if (prep > 0) return fallback();
   if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
-    for (int i = 0; i < n; i++) out[i] = empty_result(L);
+    for (int i = 0; i < n; i++) side.set_empty(i, L);
     return finish();
   }
 
@@ -457,7 +560,7 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
   }
   const int n_chunks = (int)starts.size() - 1;
   const int lanes = std::min(std::min(kRaggedLanes, n_chunks), (int)std::max<long long>(1, c->kn.max_lanes));
-  struct Slot { bool busy = false; RaggedChunk ch; Pass<float> pass; RawDets<float> dets; RunStats rs; };
+  struct Slot { bool busy = false; RaggedChunk ch; Pass<Real> pass; RawDets<Real> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
   LaneSet held(c);
   if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0, true)) return -1;
@@ -498,7 +601,7 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
       const int dev = c->device;
       const int copy_threads = (int)std::max<long long>(1, std::min<long long>(16, c->kn.ragged_stage_threads));
       uint8_t* stage[2] = {(uint8_t*)held.v[0]->h_raw.p, (uint8_t*)held.v[1]->h_raw.p};
-      auto uploader = [&, dev, copy_threads, stage]() {
+      auto uploader_body = [&, dev, copy_threads, stage]() {
         bool good = hipSetDevice(dev) == hipSuccess;
         auto publish = [&](int k_done) {
           std::lock_guard<std::mutex> lk(up.mu);
@@ -550,12 +653,22 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
         }
         if (!good) publish(0);
       };
+      // (a thread body: an exception that left it would end the process -- a failed allocation in there fails the job)
+      auto uploader = [&up, uploader_body]() {      // (the body by VALUE: it is a local of this block, the thread outlives the block)
+        try { uploader_body(); }
+        catch (...) {
+          std::lock_guard<std::mutex> lk(up.mu);
+          up.failed = true;
+          try { up.err = "upload of a ragged chunk failed: C++ exception (out of host memory?)"; } catch (...) {}
+          up.cv.notify_all();
+        }
+      };
       try { up.th = std::thread(uploader); }
       catch (...) { job.d_job_raw = nullptr; }          // (no thread to be had: the chunks upload themselves, as without a helper)
     }
   }
   auto collect = [&](Slot& sl) -> bool {
-    Pass<float>& p = sl.pass;
+    Pass<Real>& p = sl.pass;
     sl.busy = false;
     if (!p.after_tail() || !p.issue_counters() || !p.after_counters() || !p.collect()) return false;
     float ms_scan = 0, ms_all = 0;
@@ -564,7 +677,7 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
       (void)hipEventElapsedTime(&ms_all, p.ev[0], p.ev[3]);
     }
     sl.rs.scan_ms += ms_scan; sl.rs.gpu_ms += ms_all;
-    post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+    post_ms += side.post(c, job, sl.ch, sl.dets);
     add_stats(&total, sl.rs);
     patch_n += sl.ch.windows;
     return true;
@@ -573,27 +686,27 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
     const int lane = ci % lanes;
     Slot& sl = slots[lane];
     if (sl.busy && !collect(sl)) { ok = false; break; }
-    sl.dets = RawDets<float>(); sl.rs = RunStats(); sl.rs.timed = opt && opt->stats;
+    sl.dets = RawDets<Real>(); sl.rs = RunStats(); sl.rs.timed = side.stats() != nullptr;
     Lane* ln = held.v[lane];
     if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
     if (sl.ch.windows == 0) {                        // images too small for any window
-      post_ms += post_ragged(c, job, sl.ch, sl.dets, opt, out + sl.ch.i0);
+      post_ms += side.post(c, job, sl.ch, sl.dets);
       continue;
     }
     // workspace: every lane holds a whole chunk (its previous chunk has been collected above)
     {
       const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(c->kn.ragged_chunk_windows, 0x7fffffffLL))
                                        : (size_t)sl.ch.windows;
-      if (!ensure_workspace<float>(ln, want, false, c->hm.dim())) { ok = false; break; }
+      if (!ensure_workspace<Real>(ln, want, false, c->hm.dim())) { ok = false; break; }
     }
-    Pass<float>& p = sl.pass;
-    p = Pass<float>();
-    p.c = c; p.pe = job.pe; p.trace = nullptr; p.dets = &sl.dets; p.rs = &sl.rs; p.apply_th = true; p.th = th; p.multi = false;
+    Pass<Real>& p = sl.pass;
+    p = Pass<Real>();
+    p.c = c; p.pe = job.pe; p.trace = nullptr; p.dets = &sl.dets; p.rs = &sl.rs; p.apply_th = side.apply_th(); p.th = side.final_th(); p.multi = false;
     p.solo = lanes == 1;
     p.bind(ln, lane, nullptr);
     p.f0 = 0; p.nf = sl.ch.n; p.rag = &sl.ch;
-    if (c->kn.device_post >= 1 && sl.ch.n >= c->kn.device_post_min_frames) {
-      p.want_post = true; p.post_nms = !opt || opt->nms; p.post_overlap = opt ? opt->nms_overlap : 0.3f;
+    if (side.device_post(c, sl.ch.n)) {
+      p.want_post = true; p.post_nms = side.post_nms(); p.post_overlap = side.post_overlap();
       sl.dets.p_n.assign((size_t)sl.ch.n, -1); sl.dets.p_first.assign((size_t)sl.ch.n, 0);
     }
     p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
@@ -620,8 +733,19 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
     return -1;
   }
   for (int i = 0; i < n; i++)
-    if (!out[i].bboxes) out[i] = empty_result(L);     // (chunks fill every image; belt and braces)
+    if (!side.filled(i)) side.set_empty(i, L);     // (chunks fill every image; belt and braces)
   return finish();
+}
+
+int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                  const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
+                  const jdaDetectOptions* opt, jdaResult* out) {
+  return detect_ragged_t(c, host_imgs, d_base, d_offsets, widths, heights, n, RagSideC{scale, min_size, max_size, th, opt, out});
+}
+
+int detect_ragged_cpp(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                      const int* widths, const int* heights, int n, const CppCall& call, jdaStats* stats, jdaResultD* out) {
+  return detect_ragged_t(c, host_imgs, d_base, d_offsets, widths, heights, n, RagSideCpp{call, stats, out});
 }
 
 }  // namespace jda

@@ -83,7 +83,11 @@ bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint
   if (host_frames && n >= 2 * host_chunk && c->kn.lanes >= 2) lanes = 2;
 
   // frames per sub-batch, bounded by the workspace budget (shared by the lanes)
-  const size_t bpw = bytes_per_window<Real>(dim, want_trace);
+  // (method 0 on a multi-scale model: every window also owns a half_size^2 + quarter_size^2 patch in the lane's pyramid
+  // buffer -- 1.9 KB with the shipped 36 / 24 -- which must come out of the same budget, or a batch asks for several
+  // times workspace_mb and fails instead of running in more passes)
+  const size_t bpw = bytes_per_window<Real>(dim, want_trace) +
+                     (multi && host.patch_hs > 0 ? (size_t)host.patch_hs * host.patch_hs + (size_t)host.patch_qs * host.patch_qs : 0);
   const long long budget = (c->kn.workspace_mb << 20) / lanes;
   long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
   fpp = std::min<long long>(fpp, (n + lanes - 1) / lanes);

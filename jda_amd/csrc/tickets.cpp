@@ -39,6 +39,13 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
     if (slot >= 0) c->pending[slot].reserved = true;
   }
   if (slot < 0) { fail("every submit slot is in use: wait for a batch first"); return -1; }
+  // The reservation is given back on EVERY way out that has not committed the ticket -- an error return or an exception
+  // (std::bad_alloc from the assignments below; the C ABI's barrier turns it into -1): a slot left reserved would be
+  // lost to the cascador for good.
+  struct Reservation {
+    Cascador* c; PendingBatch* pb; bool committed = false;
+    ~Reservation() { if (!committed) { std::lock_guard<std::mutex> lk(c->mu); pb->reserved = false; } }
+  } reservation{c, &c->pending[slot]};
   PendingBatch& pb = c->pending[slot];
   pb.join_issuer();
   pb.reset();
@@ -64,7 +71,7 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
     pb.host_ptrs.assign(host_frames, host_frames + n);       // (the helper thread reads them after Submit has returned)
     p.host_frames = pb.host_ptrs.data(); p.host_fbytes = (size_t)width * height;
   }
-  auto give_up = [&]() { std::lock_guard<std::mutex> lk(c->mu); pb.reserved = false; return -1; };
+  auto give_up = [&]() { return -1; };      // (the Reservation guard releases the slot)
   // opt->hip_stream: the stream the caller produced the frames on -- the scan is ordered behind the work
   // already queued there (the batch itself still runs on the lane's own stream)
   if (opt && opt->hip_stream) {
@@ -76,6 +83,7 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
     pb.lane = lanes.detach(0);             // the ticket holds the lane (still busy) and the plan pin until its Wait
     pin.pe = nullptr;
     pb.active = true; pb.reserved = false;
+    reservation.committed = true;
   };
   if (host_frames && c->kn.host_submit_thread) {
     // the copy + scan launches of this ticket on their own thread (joined by Wait): a pageable H2D copy blocks
@@ -86,9 +94,15 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
     PendingBatch* pbp = &pb;
     const int dev = c->device;
     auto issue = [pbp, dev]() {
-      if (hipSetDevice(dev) != hipSuccess || !pbp->pass.issue_scan(nullptr, 0, nullptr, 0, nullptr)) {
+      // (a thread body: nothing may be thrown out of it -- std::terminate -- so a failed allocation becomes issue_ok = false)
+      try {
+        if (hipSetDevice(dev) != hipSuccess || !pbp->pass.issue_scan(nullptr, 0, nullptr, 0, nullptr)) {
+          pbp->issue_ok = false;
+          pbp->issue_err = g_err.empty() ? std::string("issuing the batch failed") : g_err;
+        }
+      } catch (...) {
         pbp->issue_ok = false;
-        pbp->issue_err = g_err.empty() ? std::string("issuing the batch failed") : g_err;
+        try { pbp->issue_err = "issuing the batch failed: C++ exception (out of host memory?)"; } catch (...) {}
       }
     };
     // (no C++ exception may cross the C ABI: when the process cannot start another thread the batch is issued here,
@@ -111,6 +125,22 @@ int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
     if (!ensure_device(c)) { c->pending[slot].waiting = false; return -1; }   // the waiting thread's current device may differ
   }
   PendingBatch& pb = c->pending[slot];
+  // Whatever happens below -- success, an error, an exception out of the host post-processing -- the ticket is closed on
+  // the way out: its stream is drained first when the pass did not complete (kernels may still read the caller's frames
+  // and write the lane's pinned buffers), then the lane goes back to the pool and the plan is unpinned.  A ticket left
+  // `active` and `waiting` would hold its lane and its plan pin for the life of the cascador.
+  struct Closer {
+    Cascador* c; PendingBatch* pb; bool done = false;
+    ~Closer() {
+      if (!done && pb->lane) { (void)hipStreamSynchronize(pb->lane->stream); if (pb->lane->side) (void)hipStreamSynchronize(pb->lane->side); (void)hipGetLastError(); }
+      std::lock_guard<std::mutex> lk(c->mu);
+      if (pb->pe && pb->pe->pins > 0) pb->pe->pins--;
+      pb->pe = nullptr;
+      if (pb->lane) { pb->lane->busy = false; c->lane_cv.notify_all(); }
+      pb->lane = nullptr;
+      pb->active = false; pb->waiting = false;
+    }
+  } closer{c, &pb};
   const int L = c->hm.L, n = pb.n;
   for (int i = 0; i < n; i++) { out[i].n = 0; out[i].landmark_n = L; out[i].bboxes = nullptr; out[i].shapes = nullptr; out[i].scores = nullptr; }
   Pass<float>& p = pb.pass;
@@ -119,7 +149,6 @@ int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
   if (!ok) fail(pb.issue_err);
   p.dets = &pb.dets; p.rs = &pb.rs;
   ok = ok && p.after_tail() && p.after_mid() && p.issue_counters() && p.after_counters() && p.collect();
-  if (!ok) (void)hipStreamSynchronize(pb.lane->stream);
   double post_ms = 0;
   if (ok) {
     float ms_scan = 0, ms_all = 0;
@@ -132,14 +161,7 @@ int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out) {
     post_ms = post_c(c, pb.sp, pb.dets, n, pb.opt_set ? &pb.opt : nullptr, out);
     fill_stats(stats, pb.rs, pb.sp.windows * n, c->hm.T, c->hm.K, post_ms);
     if (stats) stats->call_ms = now_ms() - pb.t_submit;
-  }
-  {
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (pb.pe && pb.pe->pins > 0) pb.pe->pins--;
-    pb.pe = nullptr;
-    if (pb.lane) { pb.lane->busy = false; c->lane_cv.notify_all(); }
-    pb.lane = nullptr;
-    pb.active = false; pb.waiting = false;
+    closer.done = true;
   }
   return ok ? 0 : -1;
 }

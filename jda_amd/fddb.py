@@ -120,13 +120,23 @@ def detect_fold_ragged(casc, grays, c_call=None):
     return out, st
 
 
+def detect_fold_ragged_cpp(casc, grays, params=None):
+    """Dialect CPP -- the dialect the reference's fddb() itself runs (joincascador.Detect, method 1, src/test.cpp:142) --
+    with one fold's (or shard's) images as ONE jdaDetectBatchCppRagged job.  -> ([(rects, scores, shapes)], stats)"""
+    p = dict(FDDB_DEFAULTS)
+    p.update(params or {})
+    res, st = casc.detect_ragged_cpp(grays, p["minimum_size"], p["step"], p["factor"], p["overlap"], p["nms"], stats=True)
+    return [(r["rects"], r["scores"], r["shapes"]) for r in res], st
+
+
 def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, world=1, device=None, log=None,
         ragged=None, c_call=None):
     """The whole `jda fddb` run.  With world > 1 the images are split in contiguous blocks over the
     ranks, every rank detects its block, and the (image, rect, score, landmarks) rows
     are gathered on rank 0, which writes the ten fold-XX-out.txt files.  Returns per-fold stats on rank 0.
-    ragged (default: on for dialect "c"): the images of a fold that fall into this rank's block are decoded first and
-    go through the ragged entry as one job; off: one call per image, like the reference's loop."""
+    ragged (default: on): the images of a fold that fall into this rank's block are decoded first and go through the
+    dialect's ragged entry as one job (jdaDetectBatchCppRagged / jdaDetectBatchRagged); off: one call per image, like the
+    reference's loop."""
     from . import dist as jdist
     job = list_job(fddb_dir, folds)
     lo, hi = jdist.shard_range(len(job), rank, world)
@@ -136,13 +146,14 @@ def run(casc, fddb_dir, folds=range(1, 11), dialect="cpp", params=None, rank=0, 
         # (the ragged entry is an additive symbol: an older libjda.so loaded through JDA_LIB_PATH may lack it -- then the
         # fold goes image by image, like the reference's loop)
         from . import api as japi
-        ragged = dialect == "c" and hasattr(japi.lib, "jdaDetectBatchRagged")
+        ragged = hasattr(japi.lib, "jdaDetectBatchCppRagged" if dialect == "cpp" else "jdaDetectBatchRagged")
     pending = []                                              # (idx, gray) of the fold being collected
 
     def flush(fold):
         if not pending:
             return []
-        per_image, st = detect_fold_ragged(casc, [g for _, g in pending], c_call)
+        grays = [g for _, g in pending]
+        per_image, st = detect_fold_ragged_cpp(casc, grays, params) if dialect == "cpp" else detect_fold_ragged(casc, grays, c_call)
         local_stats.setdefault(fold, FoldStats()).add(st)
         done = [(i, r) for (i, _), r in zip(pending, per_image)]
         del pending[:]

@@ -51,6 +51,16 @@ class FakeCascador:
         st = dict(patch_n=g.size, face_patch_n=n, nonface_patch_n=g.size - n, cart_gothrough_n=7 * (g.size - n))
         return ([res], st) if stats else [res]
 
+    def detect_ragged_cpp(self, images, minimum_size, step, factor, overlap, nms, stats=False):
+        """A fold's images as one job (fddb.run's default for dialect "cpp"): image by image the per-image answer."""
+        res, tot = [], dict(patch_n=0, face_patch_n=0, nonface_patch_n=0, cart_gothrough_n=0)
+        for g in images:
+            (r,), st = self.detect_batch_cpp(g[None], minimum_size, step, factor, overlap, nms, stats=True)
+            res.append(r)
+            for k in tot:
+                tot[k] += st[k]
+        return (res, tot) if stats else res
+
 
 def _expected_files(fddb_dir):
     from jda_amd import fddb
@@ -111,10 +121,10 @@ def test_run_sharded_over_gloo_matches_single(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dialect,ragged", [("cpp", None), ("c", None), ("c", False)])
+@pytest.mark.parametrize("dialect,ragged", [("cpp", None), ("cpp", False), ("c", None), ("c", False)])
 def test_fddb_end_to_end_gpu(built, model_file, tmp_path, dialect, ragged):
-    """Real detector: every fold file equals what the oracle produces for the same decoded images (dialect C: a fold as
-    one ragged job -- the default -- and image by image like the reference's loop)."""
+    """Real detector: every fold file equals what the oracle produces for the same decoded images (a fold as one ragged
+    job of its dialect -- the default -- and image by image like the reference's loop)."""
     from jda_amd import api, fddb
     from oracle.pyoracle import Oracle
     d = str(tmp_path / "fddb")

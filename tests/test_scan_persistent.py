@@ -137,15 +137,15 @@ for name, call in (("sync", lambda: c.detect_batch_device(frames, stats=True)),
                    ("ticket", lambda: c.wait_batch(c.submit_batch_device(frames), stats=True))):
     dets, st = call()
     err = api.last_error()
-    out[name] = {"err": err, "scan_patch_n": st["scan_patch_n"], "patch_n": st["patch_n"], "cart_total_n": st["cart_total_n"],
+    out[name] = {"err": err, "fallbacks": st["scan_fallbacks"], "scan_patch_n": st["scan_patch_n"], "patch_n": st["patch_n"], "cart_total_n": st["cart_total_n"],
                  "n": [len(d["scores"]) for d in dets],
                  "digest": [__import__("hashlib").sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in dets]}
 # a ragged job too (the persistent kernel's RAGGED instantiation: tiles from the chunk's block map)
 rng = np.random.default_rng(3)
 base = synth.make_frames(8, 400, 300, seed=79)
 imgs = [np.ascontiguousarray(base[i %% 8][:int(rng.integers(200, 301)), :int(rng.integers(260, 401))]) for i in range(%(n_rag)d)]
-dets = c.detect_ragged(imgs)
-out["ragged"] = {"err": api.last_error(), "n": [len(d["scores"]) for d in dets],
+dets, st = c.detect_ragged(imgs, stats=True)
+out["ragged"] = {"err": api.last_error(), "fallbacks": st["scan_fallbacks"], "n": [len(d["scores"]) for d in dets],
                  "digest": [__import__("hashlib").sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in dets]}
 print("RESULT " + json.dumps(out))
 """
@@ -155,7 +155,8 @@ def test_a_tripped_watchdog_is_noticed_and_the_pass_rerun(gpu, tmp_path):
     """k_scan_p's wait loops have watchdogs (a scheduling bug must not hang the device).  A launch that trips one loses
     windows; it used to return them short with rc 0.  Now the kernel sets an error word, the host also compares the
     windows covered with the plan's, and either way runs the pass again with k_scan's closed tiles: correct results,
-    a note on stderr and in jdaGetLastError().  libjda_wd.so (jda_amd/build.py:build_watchdog) is the product with the
+    a note on stderr and jdaStats.scan_fallbacks -- NOT in jdaGetLastError(): an empty result with a non-empty error
+    string is how jdaDetect reports failure, and a recovered pass that finds no face is not one.  libjda_wd.so (jda_amd/build.py:build_watchdog) is the product with the
     idle watchdog of k_scan_p.hip at zero -- every persistent launch trips it."""
     import hashlib
     import json
@@ -194,10 +195,10 @@ def test_a_tripped_watchdog_is_noticed_and_the_pass_rerun(gpu, tmp_path):
     digest = [hashlib.sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in want]
     for name in ("sync", "ticket"):
         g = got[name]
-        assert "k_scan_p: watchdog word" in g["err"], (name, g["err"])
+        assert g["err"] == "" and g["fallbacks"] >= 1, (name, g["err"], g["fallbacks"])
         assert g["n"] == [len(d["scores"]) for d in want] and g["digest"] == digest, name
         assert g["scan_patch_n"] == st["scan_patch_n"] == g["patch_n"] and g["cart_total_n"] == st["cart_total_n"], name
     g = got["ragged"]
-    assert "k_scan_p: watchdog word" in g["err"], g["err"]
+    assert g["err"] == "" and g["fallbacks"] >= 1, (g["err"], g["fallbacks"])
     assert g["n"] == [len(d["scores"]) for d in want_rag]
     assert g["digest"] == [hashlib.sha256(b"".join(np.ascontiguousarray(d[k]).tobytes() for k in ("bboxes", "scores", "shapes"))).hexdigest() for d in want_rag]
