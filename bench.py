@@ -114,6 +114,47 @@ def cpu_baseline(model_file, dims, frames, budget_s=20.0):
             "single_thread_value": single, "single_thread_sample": "%d frames" % n1}
 
 
+def make_checker(model_file, dims):
+    """The CPU answer for one image: the compiled reference c/jda.c (oracle/_ref, kind "reference") where a build for these
+    dimensions exists, else the oracle's restatement ("port").  Test infrastructure, used AFTER the timed regions only."""
+    from oracle import pyoracle
+    try:
+        ref = pyoracle.Reference(model_file, dims, 8)
+        return "reference", ref.detect
+    except Exception:
+        orc = pyoracle.Oracle(model_file)
+        return "port", orc.detect
+
+
+def rows_equal(rows, index, want):
+    """Are the packed rows [index, x, y, size, score, shape...] of image `index` exactly the detections `want`
+    (dict bboxes / scores / shapes of the checker)?  Bit for bit (float32 viewed as uint32)."""
+    rows = np.asarray(rows, np.float32)
+    got = rows[rows[:, 0] == np.float32(index)] if len(rows) else rows.reshape(0, rows.shape[1] if rows.ndim == 2 else 0)
+    n = len(want["scores"])
+    if len(got) != n:
+        return False
+    if n == 0:
+        return True
+    exp = np.concatenate([np.full((n, 1), index, np.float32), want["bboxes"].astype(np.float32),
+                          want["scores"].reshape(n, 1).astype(np.float32), want["shapes"].astype(np.float32)], axis=1)
+    return bool(np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(exp).view(np.uint32)))
+
+
+def rows_equal_d(rows, index, want):
+    """The same for dialect CPP's float64 rows [index, x, y, w, h, score, shape...] against dict rects / scores / shapes."""
+    rows = np.asarray(rows, np.float64)
+    got = rows[rows[:, 0] == float(index)] if len(rows) else rows.reshape(0, rows.shape[1] if rows.ndim == 2 else 0)
+    n = len(want["scores"])
+    if len(got) != n:
+        return False
+    if n == 0:
+        return True
+    exp = np.concatenate([np.full((n, 1), float(index)), want["rects"].astype(np.float64),
+                          want["scores"].reshape(n, 1), want["shapes"]], axis=1)
+    return bool(np.array_equal(np.ascontiguousarray(got).view(np.uint64), np.ascontiguousarray(exp).view(np.uint64)))
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -218,6 +259,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def lsync():
+        """Rank-local: the legs only rank 0 runs (after the job-wide timed regions) must not enter a collective."""
+        torch.cuda.synchronize()
+
     gather_kind = ["none (one rank)"]
 
     gather_cache = {}
@@ -278,6 +323,8 @@ def main():
         kind = "torch.distributed all_gather (%s)" % backend if world > 1 else "none (one rank)"
         return jdist.PipelinedGather(4096, width, device=gather_dev), kind
 
+    private = {}          # (not part of the JSON line: the last timed step's rows of the most recent run_regime)
+
     def run_regime(regime, steps, warmup, th, lanes=None, depth=1):
         """lanes=1 serialises the library's two sub-batch lanes and keeps the global-pixel launch on the lane's own
         stream (JDA_LANES=1, JDA_SIDE_STREAM=0): the k_scan launches then run back to back and the HIP-event span
@@ -323,6 +370,7 @@ def main():
             rows, st = out if want_stats else (out, None)
             if world > 1:
                 gather.start(rows)
+            private["step_rows"] = rows
             return len(rows), st
 
         def submit():
@@ -347,10 +395,12 @@ def main():
         t0 = time.perf_counter()
         stats = []
         n_det = 0
+        last_rows = None
         if depth == 1:
             for _ in range(steps):
                 n_det, st = step(True)
                 stats.append(st)
+            last_rows = (np.array(private["step_rows"], copy=True), counter[0] % R)
         else:
             # two batches in flight from this one thread: the scan of step i+1 is queued before step i is
             # collected (jdaDetectBatchSubmit / jdaDetectBatchWait), so the GPU works on it while the host parts of
@@ -366,6 +416,10 @@ def main():
                     gather.start(rows)
                 n_det = len(rows)
                 stats.append(st)
+                if i == steps - 1:
+                    # what the LAST TIMED step produced, and which resident batch it ran on (submitted `steps` submits after
+                    # the warm-up's): checked against the reference after the clock has stopped (parity_check below)
+                    last_rows = (np.array(rows, copy=True), counter[0] % R)
         gather.drain()
         barrier()
         el = time.perf_counter() - t0
@@ -403,6 +457,7 @@ def main():
             "batches_in_flight": depth,
             "rank_ms_per_step": [e / steps * 1e3 for e in rank_el] if rank_el else None,
         }
+        private["last_rows"] = last_rows
         for c in cascs:
             c.close()
         return info, mp
@@ -431,6 +486,7 @@ def main():
             selftest = "ok (%s)" % kind0.split(":")[0]
 
     casc_info, casc_model = run_regime("cascade", args.steps, args.warmup, call["th"], depth=args.depth)
+    headline_rows = private.get("last_rows")          # (rows of the last TIMED step, index of the batch it ran on)
     rank_ms = casc_info.get("rank_ms_per_step")
     # one caller, one batch at a time (what a single jdaDetectBatchDevice loop sees)
     single_info = casc_info if args.depth <= 1 else run_regime("cascade", max(1, min(20, args.steps)), 2, call["th"])[0]
@@ -461,14 +517,16 @@ def main():
                     q.append(casc.submit_batch_host(srcs[(i + ahead) % 2], **kw))
                 casc.wait_batch(q.pop(0), keep_results="packed")
         run(3)
-        barrier(); t0 = time.perf_counter()
+        lsync(); t0 = time.perf_counter()
         run(steps)
-        barrier(); el = time.perf_counter() - t0
+        lsync(); el = time.perf_counter() - t0
         casc.close()
         return windows_step * steps / el
 
+    # (single-GPU legs from here on run on rank 0 only, at every N: the other ranks wait at the closing barrier, so that a
+    # line printed by an N-rank job carries the same keys as the one-GPU line)
     host_info = None
-    if world == 1:
+    if rank == 0:
         hs = max(2, min(30, args.steps))
         host_info = {"pageable_windows_per_s": host_leg(False, hs), "pinned_windows_per_s": host_leg(True, hs), "steps": hs,
                      "entry": "jdaDetectBatchSubmitHost / jdaDetectBatchWait, three tickets (two batches submitted ahead)"}
@@ -477,7 +535,10 @@ def main():
     #      varied aspect, the reference's one-Detect-per-image loop, src/test.cpp:100-170) as ONE ragged job
     #      (jdaDetectBatchRaggedDevice), images resident in HBM, sharded over the ranks in contiguous blocks,
     #      detections gathered on rank 0 inside the timed region.  A FIXED job: strong scaling. ----
-    def fddb_leg(reps):
+    def fddb_set():
+        """This rank's contiguous block of the FDDB-shaped image set (2,845 images <= 450x450), built once."""
+        if "fddb_set" in private:
+            return private["fddb_set"]
         n_img = 2845
         rng = np.random.default_rng(0)
         sizes = []
@@ -493,6 +554,11 @@ def main():
         buf = np.concatenate([im.reshape(-1) for im in imgs]) if imgs else np.zeros(0, np.uint8)
         ws, hs = [sizes[i][0] for i in range(lo, hi)], [sizes[i][1] for i in range(lo, hi)]
         d_buf = torch.from_numpy(buf).to(dev)
+        private["fddb_set"] = (n_img, sizes, lo, hi, imgs, offs, tot, buf, ws, hs, d_buf)
+        return private["fddb_set"]
+
+    def fddb_leg(reps):
+        n_img, sizes, lo, hi, imgs, offs, tot, buf, ws, hs, d_buf = fddb_set()
         casc = api.Cascador(casc_model, device=local_rank)
         gather, _ = make_gather()
         kw = dict(scale=call["scale"], min_size=call["min_size"], max_size=call["max_size"], th=call["th"])
@@ -515,6 +581,7 @@ def main():
             t = torch.tensor([el, float(windows)], dtype=torch.float64, device=gather_dev)
             tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); el = float(tm[0].item())
             dist.all_reduce(t, op=dist.ReduceOp.SUM); windows = int(t[1].item())
+        private["fddb_rows"] = (np.array(rows, copy=True), lo, imgs)      # the last TIMED job's rows (parity_check below)
         info = {"images": n_img, "images_per_s": n_img * reps / el, "windows_per_s": windows * reps / el,
                 "ms_per_job": el / reps * 1e3, "jobs_timed": reps, "windows_per_job": windows, "scaling": "strong",
                 "entry": "jdaDetectBatchRaggedDevice (images resident in HBM), one host thread per GPU",
@@ -567,12 +634,96 @@ def main():
             raise
         fddb_info = {"error": repr(e)}
 
+    # ---- dialect CPP, the dialect the reference's own `jda fddb` runs: joincascador.Detect with fddb.method = 1
+    #      (src/test.cpp:142; model/config.json:41-45: minimum_size 20, step 5, scale 1.2, overlap 0.3, nms on).  Two legs,
+    #      both with the data resident in HBM: the headline batch (256 x 640x480: 140,215 windows per frame) through
+    #      jdaDetectBatchCppDevice, and the FDDB-shaped job as ONE jdaDetectBatchCppRaggedDevice job per rank (strong
+    #      scaling over the ranks, float64 rows gathered on rank 0 inside the timed region).  PARITY UNPINNED:
+    #      the fp64 src/jda path cannot be compiled here; checked against the oracle's restatement after the clock stops. ----
+    CPP = dict(minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True)
+
+    def cpp_leg(reps):
+        casc = api.Cascador(casc_model, device=local_rank)
+        wpf_cpp = synth.count_windows_cpp(W, H, CPP["minimum_size"], CPP["step"], CPP["factor"])
+        for j in range(2):
+            casc.detect_batch_cpp_device(d_batches[j % R], keep_results=False, **CPP)
+        barrier(); t0 = time.perf_counter()
+        for i in range(reps):
+            rows, st = casc.detect_batch_cpp_device(d_batches[i % R], stats=True, keep_results="packed", frame_offset=rank * B, **CPP)
+        barrier(); el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=gather_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t[0].item())
+        private["cpp_rows"] = (np.array(rows, copy=True), (reps - 1) % R)
+        casc.close()
+        return {"windows_per_s": wpf_cpp * B * world * reps / el, "images_per_s": B * world * reps / el, "ms_per_step": el / reps * 1e3,
+                "windows_per_frame": wpf_cpp, "gpu_ms_per_step": st["gpu_ms"], "host_post_ms_per_step": st["host_ms"],
+                "average_cart_n": st["average_cart_n"], "face_patch_n": st["face_patch_n"], "detections_after_nms": len(rows),
+                "steps": reps, "scaling": "weak", "dtype": "f64",
+                "entry": "jdaDetectBatchCppDevice (frames resident in HBM), synchronous, two sub-batch lanes",
+                "call": "Detect, method 1: minimum_size 20, step 5, factor 1.2, overlap 0.3, nms (model/config.json:41-45)",
+                "parity": "unpinned (oracle restatement only)"}
+
+    def fddb_cpp_leg(reps):
+        from jda_amd import fddb as jfddb
+        n_img, sizes, lo, hi, imgs, offs, tot, buf, ws, hs, d_buf = fddb_set()
+        casc = api.Cascador(casc_model, device=local_rank)
+
+        def job(src):
+            rows, st = casc.detect_ragged_cpp_packed(src, offs, ws, hs, stats=True, keep_results="packed", frame_offset=lo, **CPP)
+            if world > 1:
+                jfddb._gather64(rows, gather_dev)       # float64 rows -> rank 0 (torch.distributed: counts, then padded blocks)
+            return rows, st
+        for _ in range(2):
+            job(d_buf)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(reps):
+            rows, st = job(d_buf)
+        barrier(); el = time.perf_counter() - t0
+        windows = st["patch_n"]
+        if world > 1:
+            t = torch.tensor([el, float(windows)], dtype=torch.float64, device=gather_dev)
+            tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX); el = float(tm[0].item())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM); windows = int(t[1].item())
+        private["fddb_cpp_rows"] = (np.array(rows, copy=True), lo, imgs)
+        info = {"images": n_img, "images_per_s": n_img * reps / el, "windows_per_s": windows * reps / el,
+                "ms_per_job": el / reps * 1e3, "jobs_timed": reps, "windows_per_job": windows, "scaling": "strong", "dtype": "f64",
+                "entry": "jdaDetectBatchCppRaggedDevice (images resident in HBM), one host thread per GPU",
+                "sharding": "contiguous blocks of images over %d rank(s)" % world,
+                "gather": "torch.distributed (float64 rows)" if world > 1 else "none (one rank)",
+                "face_patch_n": st["face_patch_n"], "average_cart_n": st["average_cart_n"],
+                "parity": "unpinned (oracle restatement only)"}
+        if world == 1:
+            job(buf)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                job(buf)
+            info["host_images_per_s"] = n_img * reps / (time.perf_counter() - t0)
+            # the reference's structure, one Detect per image (src/test.cpp:100-170), through the per-image entry
+            k = min(100, len(imgs))
+            t0 = time.perf_counter()
+            for i in range(k):
+                casc.detect_batch_cpp(imgs[i][None], **CPP)
+            info["per_image_loop_images_per_s"] = k / (time.perf_counter() - t0)
+        casc.close()
+        return info
+
+    cpp_info = fddb_cpp_info = None
+    try:
+        cpp_info = cpp_leg(max(1, min(5, args.steps)))
+        fddb_cpp_info = fddb_cpp_leg(max(1, min(5, args.steps)))
+    except Exception as e:
+        if world > 1:
+            raise
+        cpp_info = cpp_info or {"error": repr(e)}
+        fddb_cpp_info = fddb_cpp_info or {"error": repr(e)}
+
     # ---- BASELINE.json configs[2] at its stated size, live: 256 x 1920x1080 frames resident in HBM (531 MB), scale 1.5
     #      (8 window sizes), shipped model dimensions, cascade regime.  The frames are 32 synthesised ones (synth.make_frames,
     #      1.3 s of host time instead of 10 s for 256) and seven cyclic shifts of each, made on the device: 256 distinct
     #      frames of the same statistics at 256 distinct places in HBM ----
     config2_live = None
-    if rank == 0 and world == 1 and not args.no_config2:
+    if rank == 0 and not args.no_config2:
         try:
             n_base, n_var = 32, 8
             f2 = synth.make_frames(n_base, 1920, 1080, seed=0)
@@ -589,8 +740,9 @@ def main():
                 c2.detect_batch_device(d2, 1.5, keep_results=False)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
-                _, st2 = c2.detect_batch_device(d2, 1.5, keep_results=False, stats=True)
+                rows2, st2 = c2.detect_batch_device(d2, 1.5, keep_results="packed", stats=True)
             torch.cuda.synchronize(); el2 = (time.perf_counter() - t0) / 3
+            private["config2_rows"] = (np.array(rows2, copy=True), f2[0].copy(), mp2)      # frame 0 of the last timed call (parity_check)
             config2_live = {"ms_per_call": el2 * 1e3, "windows_per_s": st2["patch_n"] / el2, "gpu_ms": st2["gpu_ms"],
                             "scan_ms": st2["scan_ms"], "average_cart_n": st2["average_cart_n"],
                             "windows_per_call": st2["patch_n"], "frames": int(d2.shape[0]),
@@ -620,7 +772,7 @@ def main():
     #      68 landmarks, depth 6: W = 243.7 MB, 34.8 MB per stage) with every window of a 1080p frame walking all 14,000
     #      carts -- each window gathers K 544-byte weight rows per stage, far more than L2 holds ----
     x_info = None
-    if rank == 0 and world == 1 and not args.no_allpass and not args.no_x:
+    if rank == 0 and not args.no_allpass and not args.no_x:
         try:
             xd = (7, 2000, 68, 6)
             xp = os.path.join(synth.cache_dir(), "x_allpass.model")
@@ -631,9 +783,9 @@ def main():
             xf = torch.from_numpy(synth.make_frames(1, 1920, 1080, seed=4)).to(dev)
             for _ in range(2):
                 xc.detect_batch_device(xf, th=float("inf"), keep_results=False)
-            barrier(); t0 = time.perf_counter()
+            lsync(); t0 = time.perf_counter()
             _, xs = xc.detect_batch_device(xf, th=float("inf"), keep_results=False, stats=True)
-            barrier(); xel = time.perf_counter() - t0
+            lsync(); xel = time.perf_counter() - t0
             xc.close()
             xalg = algorithmic_bytes(xd, xs["cart_total_n"], xs["stage_done_n"][:7], xs["patch_n"], 0)
             x_info = {"workload": "BASELINE.json configs[4]: T=7 K=2000 L=68 D=6 (float model 259.6 MB), one 1920x1080 frame, canonical "
@@ -653,19 +805,73 @@ def main():
                 x_info["traffic_over_algorithmic"] = tj["traffic_line_bytes"] / tj["algorithmic_bytes"]
                 x_info["traffic_GBps_in_profiled_run"] = tj["traffic_line_bytes"] / tj["duration_s"] / 1e9
                 x_info["traffic_useful_equivalent"] = tj["traffic_useful_equivalent_bytes"]
-                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json (from profiles/r04_x_allpass.txt) -- builder-run, NOT measured in this run: "
+                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json: %s -- builder-run rocprofv3 --pmc passes, NOT measured in this run: "
                                             "fabric read requests of the k_finish dispatch x 128 B (= FETCH_SIZE x 2), FETCH_SIZE calibrated on a gather of "
-                                            "544-byte rows of known size (0.65 counted bytes per useful byte); Infinity-Cache hits are included, no counter "
-                                            "separates them from HBM reads")
+                                            "544-byte rows of known size; Infinity-Cache hits are included, no counter separates them from HBM reads"
+                                            % tj.get("source", "?"))
+                # the counters were taken on a particular build: is it the device code this run uses?
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import pmc_traffic
+                    x_info["traffic_from_this_device_code"] = tj.get("kernel_sources_sha256") == pmc_traffic.kernel_sources_sha256()
+                except Exception:
+                    x_info["traffic_from_this_device_code"] = None
         except Exception as e:
             x_info = {"error": repr(e)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         try:
             cpu = cpu_baseline(casc_model, dims, frames)
         except Exception as e:  # the checker is optional for the measurement itself
             cpu = {"value": None, "unit": "windows/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+
+    # ---- did the timed regions compute the right thing?  After every clock has stopped, rank 0 compares what the LAST
+    #      TIMED call of each leg returned -- three frames of the headline batch, three images of the FDDB job, one frame of
+    #      configs[2] -- bit for bit with the compiled reference c/jda.c (kind "reference") or, where no build of it exists
+    #      for the dimensions, the oracle's restatement ("port"); the dialect-CPP legs with the oracle (unpinned).  The
+    #      checker is test infrastructure: nothing inside a timed region touches it. ----
+    parity = None
+    if rank == 0 and not args.no_cpu:
+        parity = {"kind": None, "ok": True, "legs": {}}
+        try:
+            kind, detect = make_checker(casc_model, dims)
+            parity["kind"] = kind
+            cargs = (call["scale"], call["min_size"], call["max_size"], call["th"])
+            if headline_rows is not None:
+                rows, j = headline_rows
+                fs = sorted({0, B // 2, B - 1})
+                parity["legs"]["headline"] = all(rows_equal(rows, rank * B + f, detect(frames_all[j][f], *cargs)) for f in fs)
+                parity["headline_frames"] = [int(f) for f in fs]
+                parity["headline_rows_in_last_timed_step"] = int(len(rows))
+            if private.get("fddb_rows") is not None:
+                rows, lo, imgs = private["fddb_rows"]
+                idx = sorted({0, len(imgs) // 2, len(imgs) - 1}) if imgs else []
+                parity["legs"]["fddb"] = all(rows_equal(rows, lo + i, detect(imgs[i], *cargs)) for i in idx)
+            if private.get("config2_rows") is not None:
+                rows2, frame0, mp2 = private["config2_rows"]
+                kind2, detect2 = make_checker(mp2, dims)
+                parity["legs"]["config2"] = rows_equal(rows2, 0, detect2(frame0, 1.5, call["min_size"], call["max_size"], call["th"]))
+                parity["config2_kind"] = kind2
+            from oracle import pyoracle
+            if private.get("cpp_rows") is not None or private.get("fddb_cpp_rows") is not None:
+                orc = pyoracle.Oracle(casc_model)
+                cppa = (CPP["minimum_size"], CPP["step"], CPP["factor"], CPP["overlap"], CPP["nms"])
+                if private.get("cpp_rows") is not None:
+                    rows, j = private["cpp_rows"]
+                    parity["legs"]["cpp"] = all(rows_equal_d(rows, rank * B + f, orc.detect_cpp(frames_all[j][f], *cppa)) for f in (0, B - 1))
+                if private.get("fddb_cpp_rows") is not None:
+                    rows, lo, imgs = private["fddb_cpp_rows"]
+                    idx = sorted({0, len(imgs) // 2, len(imgs) - 1}) if imgs else []
+                    parity["legs"]["fddb_cpp"] = all(rows_equal_d(rows, lo + i, orc.detect_cpp(imgs[i], *cppa)) for i in idx)
+            parity["ok"] = all(parity["legs"].values()) and len(parity["legs"]) > 0
+        except Exception as e:                      # noqa: BLE001 -- (the checker is optional for the measurement itself)
+            parity = {"kind": "unavailable", "ok": None, "error": repr(e), "legs": parity.get("legs", {})}
+        if parity.get("ok") is False:
+            sys.stderr.write("bench.py: PARITY CHECK FAILED: %r\n" % (parity,))
+
+    if world > 1:
+        dist.barrier()          # (the other ranks have waited here while rank 0 ran its single-GPU legs and the checks)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the LDS-tiled k_scan launches of one step ----
@@ -707,8 +913,7 @@ def main():
                             "kernel": "k_stage (dense mode), shipped dimensions, all-pass regime",
                             "carts_per_s": carts_s, "lane_reads_per_cart": reads,
                             "what": "LDS crossbar bytes: (%d walk + %d weight-row) lane-reads of 4 B per window-cart x carts / device span of the step" % (lane_reads_per_cart, 2 * L),
-                            "counters": {"lds_pipe_busy_frac": 0.37, "valu_busy_frac": 0.27, "lds_bank_conflict_cycles": 0,
-                                         "source": "profiles/r04_allpass_k_stage.txt (SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU x 4 cycles / 4 SIMDs, per CU-clock of the LDS-tiled k_stage launches; 64-frame batch) -- builder-run, NOT measured in this run"}}
+                            "counters_in": "profiles/r04_allpass_k_stage.txt (builder-run rocprofv3 --pmc SQ passes of k_stage: LDS pipe and VALU busy fractions; not echoed here)"}
         # ---- flat scalars under `config` and `roofline`: the two objects a reader of the driver's record keeps ----
         def g(d, *ks):
             for k in ks:
@@ -736,6 +941,17 @@ def main():
             "config4_allpass_windows_per_s": g(x_info, "windows_per_s"), "config4_allpass_ms_per_frame": g(x_info, "ms_per_step"),
             "one_lane_ms_per_step": roof_info["ms_per_step"], "average_cart_n": casc_info["average_cart_n"],
             "detections_after_nms": casc_info["detections_after_nms"],
+            # dialect CPP -- the reference's own fddb() dialect (Detect, method 1), resident data, measured in this run
+            "cpp_windows_per_s": g(cpp_info, "windows_per_s"), "cpp_ms_per_step": g(cpp_info, "ms_per_step"),
+            "cpp_windows_per_frame": g(cpp_info, "windows_per_frame"),
+            "fddb_cpp_images_per_s": g(fddb_cpp_info, "images_per_s"), "fddb_cpp_ms_per_job": g(fddb_cpp_info, "ms_per_job"),
+            "fddb_cpp_windows_per_s": g(fddb_cpp_info, "windows_per_s"),
+            "fddb_cpp_per_image_loop_images_per_s": g(fddb_cpp_info, "per_image_loop_images_per_s"),
+            "cpp_parity": "unpinned (fp64 src/jda path not compilable here; checked against the oracle's restatement)",
+            # what the last timed call of each leg returned, compared bit for bit after the clocks stopped: "reference" =
+            # the compiled c/jda.c, "port" = the oracle's restatement, False = a mismatch, None = no checker available
+            "parity_checked": (parity["kind"] if parity and parity.get("ok") else (False if parity and parity.get("ok") is False else None)),
+            "parity_legs": g(parity, "legs"),
         }
         if rank_ms is not None:
             cfg_extra.update({"rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms)})
@@ -790,6 +1006,9 @@ def main():
             "cpu_baseline": cpu,
             # ---- detail (a reader of the full line; the driver's record keeps config / roofline / cpu_baseline) ----
             "fddb": fddb_info,
+            "cpp": cpp_info,
+            "fddb_cpp": fddb_cpp_info,
+            "parity": parity,
             "config2": config2_live,
             "roofline_hbm_regime": x_info,
             "roofline_allpass": allpass_roof,

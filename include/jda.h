@@ -330,6 +330,12 @@ JDA_API int jdaDetectBatchCppRaggedDevice(void *cascador, const unsigned char *d
                                           double factor, double overlap, int nms,
                                           jdaStats *stats, jdaResultD *out);
 
+/* Flattens n dialect-CPP results into rows of (6 + 2*landmark_n) doubles: [frame_offset + i, x, y, w, h, score, shape...]
+ * (the rows reference src/test.cpp:153-163 prints per image, plus the landmarks) -- what is gathered across GPUs for the
+ * dialect-CPP FDDB job.  rows may be NULL to query the row count.  Returns the number of rows, or -1 if capacity_rows is
+ * too small. */
+JDA_API int jdaResultsDPack(const jdaResultD *results, int n, int frame_offset, double *rows, int capacity_rows);
+
 /* Releases n dialect-CPP results at once (same as n jdaResultDRelease calls). */
 JDA_API void jdaResultsDRelease(jdaResultD *results, int n);
 

@@ -134,6 +134,7 @@ def _load():
                                                       C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
         lib.jdaResultsDRelease.restype = None
         lib.jdaResultsDRelease.argtypes = [C.POINTER(jdaResultD), C.c_int]
+        lib.jdaResultsDPack.argtypes = [C.POINTER(jdaResultD), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
     lib.jdaDetectBatchCppPyramid.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats), C.POINTER(jdaResultD)]
     if hasattr(lib, "jdaDetectBatchCppPyramidMS"):
@@ -524,7 +525,15 @@ class Cascador:
         out = [_take_d(res[i]) for i in range(n)]
         return (out, st.asdict()) if stats else out
 
-    def _collect_d(self, res, n, keep_results):
+    def _collect_d(self, res, n, keep_results, frame_offset=0):
+        if keep_results == "packed":
+            # one C call: rows [frame, x, y, w, h, score, shape...] (float64) of every detection of the batch
+            rows = lib.jdaResultsDPack(res, n, frame_offset, None, 0)
+            out = np.empty((max(rows, 0), 6 + self.dim), np.float64)
+            if rows > 0:
+                lib.jdaResultsDPack(res, n, frame_offset, out.ctypes.data_as(C.POINTER(C.c_double)), rows)
+            lib.jdaResultsDRelease(res, n)
+            return out
         if keep_results:
             return [_take_d(res[i]) for i in range(n)]
         out = [res[i].n for i in range(n)]
@@ -532,7 +541,7 @@ class Cascador:
         return out
 
     def detect_batch_cpp_device(self, d_frames, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,
-                                keep_results=True):
+                                keep_results=True, frame_offset=0):
         """jdaDetectBatchCppDevice: a torch uint8 CUDA tensor [n, h, w] resident in HBM."""
         assert d_frames.is_cuda and d_frames.dtype.itemsize == 1 and d_frames.is_contiguous()
         n, h, w = d_frames.shape
@@ -542,7 +551,7 @@ class Cascador:
                                          overlap, 1 if nms else 0, C.byref(st) if stats else None, res)
         if rc != 0:
             raise JdaError(last_error())
-        out = self._collect_d(res, n, keep_results)
+        out = self._collect_d(res, n, keep_results, frame_offset)
         return (out, st.asdict()) if stats else out
 
     def detect_ragged_cpp(self, images, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,
@@ -564,7 +573,7 @@ class Cascador:
         return (out, st.asdict()) if stats else out
 
     def detect_ragged_cpp_packed(self, buf, offsets, widths, heights, minimum_size=20, step=5, factor=1.2, overlap=0.3,
-                                 nms=True, stats=False, keep_results=True):
+                                 nms=True, stats=False, keep_results=True, frame_offset=0):
         """The same for images packed in ONE buffer (image i = buf[offsets[i] : offsets[i] + w*h]): a numpy uint8 array
         (jdaDetectBatchCppRagged) or a torch uint8 CUDA tensor (jdaDetectBatchCppRaggedDevice)."""
         n = len(offsets)
@@ -585,7 +594,7 @@ class Cascador:
                                                    factor, overlap, 1 if nms else 0, sp, res)
         if rc != 0:
             raise JdaError(last_error())
-        out = self._collect_d(res, n, keep_results)
+        out = self._collect_d(res, n, keep_results, frame_offset)
         return (out, st.asdict()) if stats else out
 
     def detect_batch_cpp_pyramid(self, frames, origin_size=48, step=5, factor=1.2, overlap=0.3, nms=True, stats=False,

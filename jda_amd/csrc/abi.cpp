@@ -621,6 +621,27 @@ int jdaDetectBatchCppRaggedDevice(void* cascador, const unsigned char* d_base, c
   return detect_ragged_cpp(c, nullptr, d_base, offsets, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, out);
 } JDA_ABI_CATCH_SYNC(-1)
 
+int jdaResultsDPack(const jdaResultD* results, int n, int frame_offset, double* rows, int capacity_rows) try {
+  if (!results || n < 0) return -1;
+  long long total = 0;
+  for (int i = 0; i < n; i++) total += results[i].n;
+  if (!rows) return (int)total;
+  if (total > capacity_rows) return -1;
+  double* o = rows;
+  for (int i = 0; i < n; i++) {
+    const jdaResultD& r = results[i];
+    const int dim = 2 * r.landmark_n;
+    for (int j = 0; j < r.n; j++) {
+      o[0] = (double)(frame_offset + i);
+      for (int k = 0; k < 4; k++) o[1 + k] = (double)r.rects[4 * j + k];
+      o[5] = r.scores[j];
+      std::memcpy(o + 6, r.shapes + (size_t)j * dim, dim * sizeof(double));
+      o += 6 + dim;
+    }
+  }
+  return (int)total;
+} JDA_ABI_CATCH(-1)
+
 void jdaResultsDRelease(jdaResultD* results, int n) {
   if (!results) return;
   for (int i = 0; i < n; i++) {

@@ -117,8 +117,10 @@ inline long long env_ll(const char* name, long long dflt) {
   X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 4000000) /* windows per chunk of a ragged batch at most */ \
+  X(ragged_chunk_windows_cpp, "JDA_RAGGED_CHUNK_WINDOWS_CPP", 8000000) /* ... of a dialect-CPP ragged batch */ \
   X(ragged_chunk_min_windows, "JDA_RAGGED_CHUNK_MIN_WINDOWS", 1500000) /* ... and at least, where a small job is cut into ragged_split chunks */ \
   X(ragged_split, "JDA_RAGGED_SPLIT", 3)    /* chunks a job smaller than that many full chunks is cut into */ \
+  X(ragged_merge, "JDA_RAGGED_MERGE", -1)   /* LDS-tiled levels of a ragged chunk: one launch per occupancy class (1) or per level (0); -1: per class for dialect CPP, per level for dialect C (k_scan_p takes single-level launches) */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
@@ -162,7 +164,7 @@ struct Knobs {
   // Values no code path can work with are refused (jdaSetOption returns -1): negative sizes and counts; the rest of
   // a knob's range is clamped where it is used.
   bool set(const char* key, long long v) {
-    static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "host_chunk", "ragged_chunk_windows",
+    static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "host_chunk", "ragged_chunk_windows", "ragged_chunk_windows_cpp",
                                                "ragged_chunk_min_windows", "h2d_min_bytes", "merge_blocks", "finish_merge", "wide_max", "lanes_min_windows",
                                                "ragged_stage_threads", "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls", "scan_p_tile_kb", "scan_p_grid"};
     for (const char* k : non_negative) if (std::strcmp(key, k) == 0 && v < 0) return false;

@@ -94,7 +94,9 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   constexpr int LF = BLOCK * 8;          // bytes of lfbuf: 8 trees per lane and round in the pair phases
   const int node_n = m.node_n, leaf_n = m.leaf_n;
   const int K = min(m.K, handoff);     // this kernel stops here and hands survivors to k_finish
-  const bool ilp8 = GLB || (opts & 1);   // 8 instead of 4 trees in flight per lane (levels with few resident waves)
+  // 8 instead of 4 trees in flight per lane (levels with few resident waves); fp64 LDS tiles: never (eight fp64 leaf scores
+  // and thresholds in flight are 32 registers the 80-register instantiation does not have: it spilled them, r06)
+  const bool ilp8 = GLB || (sizeof(Real) == 4 && (opts & 1));
   const int first_phase = (opts >> 8) & 0xff;   // carts before the first compaction (8 or 16)
   const ScanLds<Real, TRACE> L(pix_bytes, chunk, node_n, leaf_n, M_MAX, LF);
   const uint8_t* pix = lds + L.pix;
@@ -422,36 +424,45 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
           JDA_STAMP(-100 - (r0 - c0));          // timing build: trees of this round done
           if (wv < replay_waves) {
             int k = r0;
-            // 16 carts at a time when none of them is normalised: all leaf scores and thresholds
+            // RB carts at a time when none of them is normalised: all leaf scores and thresholds
             // are fetched first (two LDS round trips for the batch instead of two per 4 carts),
-            // then the recurrence runs in registers, strictly in cart order (c/jda.c:395-399)
-            for (; k + 16 <= r1; k += 16) {
+            // then the recurrence runs in registers, strictly in cart order (c/jda.c:395-399).
+            // RB = 16 for fp32; 8 for fp64, whose sums, leaf scores and thresholds take two registers each (16 at a
+            // time were 96 registers of state: the 512-thread instantiation spilled them, r06)
+            constexpr int RB = sizeof(Real) == 8 ? 8 : 16;
+            for (; k + RB <= r1; k += RB) {
               if (__ballot(alive) == 0ull) break;
-              const ThNorm<Real> pm = *(const ThNorm<Real>*)&t_par[k + (lane & 15)];   // lane u (mod 16): cart k+u
+              const ThNorm<Real> pm = *(const ThNorm<Real>*)&t_par[k + (lane & (RB - 1))];   // lane u (mod RB): cart k+u
               if (NORM && __ballot(pm.norm != (Real)0) != 0ull) break;       // rare: the generic loop below takes over
               // thresholds: lane u holds cart k+u's; broadcast with readlane HERE, with the whole wave
               // active -- inside the divergent block below the lanes without a live window would not
               // have loaded theirs
-              Real thv[16];
+              Real thv[RB];
 #pragma unroll
-              for (int u = 0; u < 16; u++) thv[u] = rl(pm.th, u);
+              for (int u = 0; u < RB; u++) thv[u] = rl(pm.th, u);
               if (alive) {
-                int lf[16];
-                Real lsv[16];
-                // the window's 16 leaf indices are 16 consecutive bytes of lfbuf[window][cart]
-                const uint4 pk = *(const uint4*)(lfbuf + item * rc + (k - r0));
-                const unsigned pw4[4] = {pk.x, pk.y, pk.z, pk.w};
+                int lf[RB];
+                Real lsv[RB];
+                // the window's RB leaf indices are RB consecutive bytes of lfbuf[window][cart]
+                unsigned pw4[4];
+                if constexpr (RB == 16) {
+                  const uint4 pk = *(const uint4*)(lfbuf + item * rc + (k - r0));
+                  pw4[0] = pk.x; pw4[1] = pk.y; pw4[2] = pk.z; pw4[3] = pk.w;
+                } else {
+                  const uint2 pk = *(const uint2*)(lfbuf + item * rc + (k - r0));
+                  pw4[0] = pk.x; pw4[1] = pk.y; pw4[2] = 0u; pw4[3] = 0u;
+                }
 #pragma unroll
-                for (int u = 0; u < 16; u++) lf[u] = (int)((pw4[u >> 2] >> (8 * (u & 3))) & 0xffu);
+                for (int u = 0; u < RB; u++) lf[u] = (int)((pw4[u >> 2] >> (8 * (u & 3))) & 0xffu);
 #pragma unroll
-                for (int u = 0; u < 16; u++) lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]];
-                // branch-free: the 16 partial sums (the same adds in the same order), a bit per
+                for (int u = 0; u < RB; u++) lsv[u] = t_leaf[(k + u) * leaf_n + lf[u]];
+                // branch-free: the RB partial sums (the same adds in the same order), a bit per
                 // rejecting cart, then the first set bit names the cart the window died at
-                Real sums[16];
+                Real sums[RB];
                 Real sc = score;
                 unsigned rej = 0u;
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < RB; u++) {
                   sc = sc + lsv[u];                                          // c/jda.c:396 (no normalisation here)
                   sums[u] = sc;
                   rej |= (sc < thv[u]) ? (1u << u) : 0u;                     // c/jda.c:399
@@ -460,7 +471,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                   const int j = __ffs((int)rej) - 1;
                   Real sd = sums[0];
 #pragma unroll
-                  for (int u = 1; u < 16; u++) sd = (j >= u) ? sums[u] : sd;
+                  for (int u = 1; u < RB; u++) sd = (j >= u) ? sums[u] : sd;
                   if (TRACE)
                     for (int u = 0; u <= j; u++) hash = fnv_step(hash, lf[u]);
                   score = sd;
@@ -470,7 +481,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
                 } else {
                   if (TRACE) {
 #pragma unroll
-                    for (int u = 0; u < 16; u++) hash = fnv_step(hash, lf[u]);
+                    for (int u = 0; u < RB; u++) hash = fnv_step(hash, lf[u]);
                   }
                   score = sc;
                 }
@@ -595,8 +606,8 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
     hipLaunchKernelGGL(kern, grid, block, lds_req, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
                        pix_bytes, handoff, chunk, cp_max, opts, 0);
   };
-  // (opts bit 1: no cart of [0, handoff) normalises -- the lean instantiation, dialect C without trace only)
-  if constexpr (sizeof(Real) == 4 && !TRACE) {
+  // (opts bit 1: no cart of [0, handoff) normalises -- the lean instantiation, passes without trace only)
+  if constexpr (!TRACE) {
     if (opts & 2) {
       if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, false, false>);
       else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, false, false>);
@@ -652,7 +663,7 @@ hipError_t launch_scan_ragged_mode(const DevPlan* d_plan, const DevModelT<Real>&
     hipLaunchKernelGGL(kern, dim3((unsigned)blk_n), dim3(BLOCK), L.total, stream, d_plan, m, table, w, -1, 0,
                        pix_bytes, handoff, chunk, cp_max, opts, blk_base);
   };
-  if constexpr (sizeof(Real) == 4 && !TRACE) {
+  if constexpr (!TRACE) {
     if (opts & 2) {
       if (m.D == 4) go(k_scan<Real, 4, TRACE, MODE, BLOCK, true, false>);
       else if (m.D == 6) go(k_scan<Real, 6, TRACE, MODE, BLOCK, true, false>);

@@ -275,8 +275,42 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     L.blk_n = bi - L.blk_base;
     if (L.blk_n > 0) ch->launches.push_back(L);
   };
+  // ragged_merge: the LDS-tiled levels of a chunk as one launch per OCCUPANCY CLASS (levels whose workgroups fit the same
+  // number of times into a CU's LDS) instead of one per level.  A chunk of 4 M windows over ten levels is ~900 workgroups
+  // per level against 768 resident ones (3 per CU): every per-level launch runs a full round and a fifth of a second one
+  // (r06 kernel trace of the dialect-CPP job: 60-85 us per launch where 35-40 would do).  Merged, a class is thousands of
+  // workgroups and the tail is paid once.  -1 = auto: on for dialect CPP (no persistent scan there), off for dialect C
+  // (its single-level launches are what k_scan_p takes).
+  const long long merge_knob = c->kn.ragged_merge;
+  const bool merge_classes = merge_knob < 0 ? job.cpp : merge_knob != 0;
   if (small) merged(1);
-  else
+  else if (merge_classes) {
+    const HostModel& hm = c->hm;
+    const int rb = job.real_bytes();
+    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), rb));
+    int cls[kMaxLevels];
+    bool any[kMaxLevels];
+    for (int l = 0; l < nl; l++) {
+      cls[l] = -1; any[l] = false;
+      if (hp.lv[l].tiled != 1) continue;
+      const int lds = (int)scan_lds_bytes(pix_of(l), chunk, hm.node_n(), hm.leaf_n(), rb, false, win_max[l] > 256 ? 512 : 256);
+      cls[l] = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
+    }
+    for (int i = 0; i < n; i++) for (int l = 0; l < job.n_lv[i0 + i]; l++) any[l] = true;
+    for (int k = 8; k >= 1; k--) {
+      RaggedChunk::Launch L{1, 256, 0, bi, 0};
+      int members = 0, last = -1;
+      for (int l = 0; l < nl; l++)
+        if (cls[l] == k && any[l]) { members++; last = l; L.pix_bytes = std::max(L.pix_bytes, pix_of(l)); if (win_max[l] > 256) L.block = 512; }
+      if (!members) continue;
+      if (members == 1) { L.level = last; emit_level(last); }
+      else
+        for (int g0 = 0; g0 < n; g0 += 8)                   // (group-major, like merged(): eight images stay in L2 from level to level)
+          for (int l = 0; l < nl; l++) if (cls[l] == k && any[l]) emit_group(l, g0);
+      L.blk_n = bi - L.blk_base;
+      if (L.blk_n > 0) ch->launches.push_back(L);
+    }
+  } else
     for (int l = 0; l < nl; l++)
       if (hp.lv[l].tiled == 1) {
         RaggedChunk::Launch L{1, win_max[l] > 256 ? 512 : 256, pix_of(l), bi, 0};
@@ -520,6 +554,9 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   //      in 16 bits), walked through up to three lanes as a software pipeline: while the GPU works on chunks i-1 and i-2
   //      the host builds and issues chunk i and post-processes chunk i-3 ----
   const DevPlan& hp = job.pe->hp;
+  // (dialect CPP scans ~3.4x the windows of dialect C on the same images -- 20-pixel windows, 5-pixel step -- in levels of
+  // few workgroups each: larger chunks, measured 42.3 -> 38.1 ms for the FDDB-shaped job)
+  const long long chunk_windows = job.cpp ? c->kn.ragged_chunk_windows_cpp : c->kn.ragged_chunk_windows;
   // host images: uploaded by a helper thread, below (packed = every image right behind the one before in memory)
   bool helper = host_imgs != nullptr && c->kn.ragged_uploader != 0, packed = helper;
   std::vector<size_t> tight(helper ? (size_t)n + 1 : 0, 0);       // image i at tight[i] of the job's tight image buffer
@@ -544,7 +581,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     // ragged_chunk_min_windows each), so that its lanes overlap too: the scan of one chunk next to the latency-bound
     // finishing kernels of another (a 356-image shard of the FDDB-sized job as one chunk: 1.58 ms, as three: 1.50)
     const long long split = std::max<long long>(1, c->kn.ragged_split);
-    const long long full = std::max<long long>(1, std::min<long long>(c->kn.ragged_chunk_windows,
+    const long long full = std::max<long long>(1, std::min<long long>(chunk_windows,
                                                                       std::max<long long>(c->kn.ragged_chunk_min_windows, (total + split - 1) / split)));
     long long target = full;
     starts.push_back(0);
@@ -563,7 +600,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   struct Slot { bool busy = false; RaggedChunk ch; Pass<Real> pass; RawDets<Real> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
   LaneSet held(c);
-  if (!held.take(lanes, n_chunks > 1 ? (size_t)c->kn.ragged_chunk_windows : 0, true)) return -1;
+  if (!held.take(lanes, n_chunks > 1 ? (size_t)chunk_windows : 0, true)) return -1;
   bool ok = true;
 
   // ---- host images, several chunks: a helper thread brings chunk after chunk into a buffer of the job (the first
@@ -695,7 +732,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     }
     // workspace: every lane holds a whole chunk (its previous chunk has been collected above)
     {
-      const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(c->kn.ragged_chunk_windows, 0x7fffffffLL))
+      const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(chunk_windows, 0x7fffffffLL))
                                        : (size_t)sl.ch.windows;
       if (!ensure_workspace<Real>(ln, want, false, c->hm.dim())) { ok = false; break; }
     }

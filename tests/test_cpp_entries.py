@@ -89,7 +89,7 @@ def test_cpp_ragged_edge_cases(built, gpu, model_file):
 
 
 def test_cpp_ragged_in_several_chunks_and_from_device_memory(built, gpu, model_file):
-    """More chunks than lanes (ragged_chunk_windows forced small): the software pipeline reuses lanes; packed host
+    """More chunks than lanes (ragged_chunk_windows_cpp forced small): the software pipeline reuses lanes; packed host
     buffer, separate host allocations and device-resident images agree."""
     import torch
     from jda_amd import api, synth
@@ -106,7 +106,7 @@ def test_cpp_ragged_in_several_chunks_and_from_device_memory(built, gpu, model_f
     buf = np.concatenate([im.reshape(-1) for im in imgs])
     ws, hs = [s[0] for s in sizes], [s[1] for s in sizes]
     for chunk in (6000000, 200000, 20000):
-        c.set_option("ragged_chunk_windows", chunk)
+        c.set_option("ragged_chunk_windows_cpp", chunk)
         got_list, st = c.detect_ragged_cpp(imgs, stats=True)
         got_buf = c.detect_ragged_cpp_packed(buf, offs, ws, hs)
         got_dev = c.detect_ragged_cpp_packed(torch.from_numpy(buf).to(gpu), offs, ws, hs)
