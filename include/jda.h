@@ -143,6 +143,8 @@ JDA_API int jdaSetDevice(void *cascador, int device);
  *   "lanes"         sub-batches of one synchronous call that run side by side on their own streams (2)
  *   "dense"         whole-stage tile kernel for models that reject little: 0 off, 1 auto, 2 always (1)
  *   "workspace_mb"  device workspace budget of a call in MiB; larger batches run in several passes (24576)
+ *   "ws_bound"      size the survivor queues of a pass from the fractions earlier passes left in them ("ws_factor_pct" = 400 % of
+ *                   them, at least "ws_min_entries" = 65536) instead of for every window; a pass that outgrows them is rerun (1)
  *   "plan_cache"    scan plans (one per frame size and call parameters) kept per cascador (64)
  *   "predict"       size the finishing launches from the previous pass instead of a host round trip (1)
  *   "scan_p"        the persistent form of the stage-0 scan for large uniform batches: 0 off, 1 where it suits, 2 wherever it fits (1)
@@ -185,6 +187,8 @@ typedef struct {
   long long scan_lds_cart_n;  /* carts evaluated by the LDS-tiled k_scan launches (scan_cart_n minus the global-pixel levels) */
   int scan_fallbacks;         /* passes of this call that were run a second time with the closed-tile scan kernel because the
                                  persistent one tripped a watchdog or covered too few windows (results are correct; see stderr) */
+  int ws_regrows;             /* passes of this call that were run a second time because a queue sized from earlier passes'
+                                 survivor fractions was too small (option "ws_bound"; results are correct; see stderr) */
 } jdaStats;
 
 typedef struct {

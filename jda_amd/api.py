@@ -47,7 +47,8 @@ class jdaStats(C.Structure):
                 ("host_ms", C.c_double), ("scan_cart_n", C.c_longlong), ("scan_patch_n", C.c_longlong),
                 ("scan_launches", C.c_int), ("handoff_n", C.c_longlong), ("cart_total_n", C.c_longlong),
                 ("call_ms", C.c_double), ("dense_passes", C.c_int), ("scan_lds_ms", C.c_double),
-                ("scan_lds_cart_n", C.c_longlong), ("scan_fallbacks", C.c_int)]
+                ("scan_lds_cart_n", C.c_longlong), ("scan_fallbacks", C.c_int),
+                ("ws_regrows", C.c_int)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "stage_done_n"}

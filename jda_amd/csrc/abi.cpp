@@ -572,8 +572,10 @@ long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int 
 // timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
 __attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {
   Cascador* c = (Cascador*)cascador;
-  if (!c || c->lanes.empty() || !c->lanes[0]->wf.dbg) return -1;
-  return hipMemcpy(out, c->lanes[0]->wf.dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  if (!c || c->lanes.empty()) return -1;
+  const unsigned long long* dbg = c->lanes[0]->real_bytes == 8 ? c->lanes[0]->wd.dbg : c->lanes[0]->wf.dbg;
+  if (!dbg) return -1;
+  return hipMemcpy(out, dbg, sizeof(unsigned long long) * 65536 * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 

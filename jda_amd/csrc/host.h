@@ -115,11 +115,15 @@ inline long long env_ll(const char* name, long long dflt) {
   X(lanes_min_windows, "JDA_LANES_MIN_WINDOWS", 2000000)                                               \
   X(host_chunk, "JDA_HOST_CHUNK", 128)      /* frames per sub-batch when the frames come from host memory */ \
   X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
+  X(ws_bound, "JDA_WS_BOUND", 1)            /* queues of a pass sized from the fractions earlier passes left in them (0: for the worst case, every window in every queue) */ \
+  X(ws_factor_pct, "JDA_WS_FACTOR_PCT", 400) /* ... times this safety factor, in percent */ \
+  X(ws_min_entries, "JDA_WS_MIN_ENTRIES", 65536) /* ... and never fewer entries than this */ \
   X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 4000000) /* windows per chunk of a ragged batch at most */ \
   X(ragged_chunk_windows_cpp, "JDA_RAGGED_CHUNK_WINDOWS_CPP", 8000000) /* ... of a dialect-CPP ragged batch */ \
   X(ragged_chunk_min_windows, "JDA_RAGGED_CHUNK_MIN_WINDOWS", 1500000) /* ... and at least, where a small job is cut into ragged_split chunks */ \
   X(ragged_split, "JDA_RAGGED_SPLIT", 3)    /* chunks a job smaller than that many full chunks is cut into */ \
+  X(ragged_lanes, "JDA_RAGGED_LANES", 3)    /* chunks of a ragged job in flight (lanes it takes), 1..8 */ \
   X(ragged_merge, "JDA_RAGGED_MERGE", -1)   /* LDS-tiled levels of a ragged chunk: one launch per occupancy class (1) or per level (0); -1: per class for dialect CPP, per level for dialect C (k_scan_p takes single-level launches) */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
@@ -276,7 +280,6 @@ constexpr int kFinishTileWin1 = 0;   // carts of stage 0 k_scan evaluates before
 // tickets of the submit/wait entries (frames coming over PCIe: a ticket lives for upload 1.4 ms + kernels 1.7 ms + host
 // work, so the link and the GPU are only both kept busy with three in flight)
 constexpr int kTickets = 3;
-constexpr int kRaggedLanes = 3;      // chunks of a ragged job in flight
 
 struct PendingBatch;          // a submitted, not yet collected batch (submit/wait entries), defined after Pass
 
@@ -318,6 +321,7 @@ struct Lane {
   HostPinned h_pn, h_pbb, h_psc, h_psh;      // ... post-processed on the device (k_post): per-frame count / first row (+ flag), boxes, scores, shapes
   DevBuf ws;                                 // per-window arrays, carved for one dialect at a time
   size_t cap = 0; bool trace = false; int dim = 0, real_bytes = 0;
+  size_t cap_q = 0, cap_m = 0; bool dense_ws = false;   // entries of the hand-off queue / of the mid queue and the detection list; k_stage's per-window state is there
   WorkT<float> wf{};
   WorkT<double> wd{};
   DevBuf frames;                             // staging of host frames (the call's first lane holds the whole batch)
@@ -357,7 +361,7 @@ struct Lane {
     HostPinned* hb[] = {&h_gid, &h_score, &h_shape, &h_tab, &h_raw, &h_pn, &h_pbb, &h_psc, &h_psh};
     for (DevBuf* b : db) { if (bag && b->p) { bag->dev.push_back(b->p); b->p = nullptr; b->bytes = 0; } else b->release(); }
     for (HostPinned* b : hb) { if (bag && b->p) { bag->host.push_back(b->p); b->p = nullptr; b->bytes = 0; } else b->release(); }
-    cap = 0; trace = false; dim = 0; real_bytes = 0;
+    cap = 0; cap_q = 0; cap_m = 0; trace = false; dense_ws = false; dim = 0; real_bytes = 0;
     wf = WorkT<float>{}; wd = WorkT<double>{};
   }
   void destroy() {
@@ -494,8 +498,29 @@ void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool
 // ---------------------------------------------------------------- workspace (lanes.cpp)
 
 template <typename Real> size_t bytes_per_window(int dim, bool trace);
-// The lane's per-window arrays for `cap` windows of dialect Real (grow-only; the lane is idle).
-template <typename Real> bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim);
+// The lane's arrays for a pass over `cap` windows of dialect Real (grow-only; the lane is idle): cap_q entries of the
+// hand-off queue, cap_m of the mid queue and the detection list (0: cap, the worst case), dense: k_stage's per-window state.
+template <typename Real> bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim, size_t cap_q = 0, size_t cap_m = 0, bool dense = true);
+template <typename Real> size_t workspace_bytes(size_t cap, size_t cap_q, size_t cap_m, bool trace, bool dense, int dim);
+
+// How many entries the queues of a pass over `windows` windows get (r06; before: every queue held every window).  From the
+// fractions earlier passes on the plan left in them (PlanEntry::pred_*, negative: none yet) times ws_factor_pct, never
+// below ws_min_entries; without a prediction an eighth / a thirty-second of the windows.  A pass that outgrows them is
+// noticed by its counters and run again with room (Pass::recover_overflow): bounding costs time in that case, never results.
+struct QueueCaps { size_t q, m; };
+inline QueueCaps queue_caps(const Knobs& kn, size_t windows, double pred_tail, double pred_mid, double pred_out, bool full) {
+  if (full || kn.ws_bound == 0) return {windows, windows};
+  const double f = (double)std::max<long long>(100, kn.ws_factor_pct) / 100.0;
+  const size_t floor_n = (size_t)std::max<long long>(1, kn.ws_min_entries);
+  const double fq = pred_tail >= 0 ? pred_tail * f : 0.125;
+  const double pm = std::max(pred_mid, pred_out);
+  const double fm = pm >= 0 ? pm * f : 1.0 / 32.0;
+  auto clampn = [&](double frac) {
+    const double v = frac * (double)windows + 64.0;
+    return std::min(windows, std::max(floor_n, v >= (double)windows ? windows : (size_t)v));
+  };
+  return {clampn(fq), clampn(fm)};
+}
 
 // ---------------------------------------------------------------- the pipeline
 
@@ -526,6 +551,7 @@ struct RunStats {
   double gpu_ms = 0, scan_ms = 0, scan_lds_ms = 0;
   int scan_launches = 0;
   int dense_passes = 0;
+  int ws_regrows = 0;          // passes run again because a queue sized from earlier passes was too small (Pass::recover_overflow)
   int scan_fallbacks = 0;      // passes run again with k_scan because k_scan_p's launch tripped a watchdog / came back short
 };
 

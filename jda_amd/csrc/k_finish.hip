@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   // (t_begin > 0), or -- survivors -- the mid queue as k_filter0 leaves it: windows that passed every cart of stage 0,
   // still holding the mean shape (their stage-0 leaves are walked again here, no score is applied)
   const bool from_scan = t_begin == 0 && !survivors;
-  const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)w.cap);
+  const unsigned n = (unsigned)min(w.counters[from_scan ? kCntTail : kCntMid], (unsigned long long)(from_scan ? w.cap_q : w.cap_m));
   unsigned long long carts_acc = 0;
 
 #ifdef JDA_SCAN_TIMING
@@ -180,6 +180,9 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real acc = kCpp ? (Real)0 : sh[d];
         const Real* col = wt + d;
         int k = 0;
+#ifdef JDA_EXP_NOREG
+        k = K;      // (experiment build, never the product: how long do the walks alone take?)
+#endif
         for (; k + 32 <= K; k += 32) {          // 32 row loads in flight, then 32 ordered adds
           Real r[32];
           // (STREAM is a template parameter: as a run-time branch the optimiser merges the two forms of the load and
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         unsigned o = 0;
         if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
         o = (unsigned)__shfl((int)o, 0);
-        if (o < w.cap) {
+        if (o < w.cap_m) {
           if (lane == 0) { w.out_gid[o] = gid; w.out_score[o] = score; }
           for (int d = lane; d < dim; d += 64) w.out_shape[(size_t)o * dim + d] = sh[d];
         }
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       unsigned o = 0;
       if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
       o = (unsigned)__shfl((int)o, 0);
-      if (o < w.cap) {
+      if (o < w.cap_m) {
         if (lane == 0) { w.m_gid[o] = gid; w.m_score[o] = score; w.m_xy[o] = xy; w.m_wf[o] = wf; if (TRACE) w.m_hash[o] = hash; }
         for (int d = lane; d < dim; d += 64) w.m_shape[(size_t)o * dim + d] = sh[d];
       }
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_filter0(const DevPlan* __restrict__ pla
   constexpr int NW = 2;                    // windows a wave walks side by side: their memory round trips overlap
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int K = m.K, node_n = m.node_n, leaf_n = m.leaf_n;
-  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap_q);
   const Real* leaf_tab = m.leaf;
   const int W = plan->width;
   unsigned long long carts_acc = 0;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void k_filter0(const DevPlan* __restrict__ pla
         unsigned o = 0;
         if (lane == 0) o = (unsigned)atomicAdd(&w.counters[kCntMid], 1ull);
         o = (unsigned)__shfl((int)o, 0);
-        if (o < w.cap && lane == 0) {
+        if (o < w.cap_m && lane == 0) {
           w.m_gid[o] = gid[u]; w.m_score[o] = score[u]; w.m_xy[o] = xy[u]; w.m_wf[o] = wf[u];
           if (TRACE) w.m_hash[o] = hash[u];
         }
@@ -432,7 +435,7 @@ hipError_t launch_finish_impl(bool trace, int t_begin, int t_end, bool apply_th,
   // n_hint >= 0: the queue length is known on the host -> one window per workgroup (up to
   // 1M workgroups, grid-stride beyond), so the hardware dispatcher balances the very
   // uneven per-window cost; n_hint < 0: fixed grid, windows dealt round-robin.
-  unsigned blocks = w.cap;
+  unsigned blocks = t_begin == 0 && !survivors ? w.cap_q : w.cap_m;
   if (blocks > 256u * 64u) blocks = 256u * 64u;
   if (n_hint >= 0) blocks = (unsigned)std::min<long long>(n_hint, 1 << 20);
   if (blocks == 0) return hipSuccess;

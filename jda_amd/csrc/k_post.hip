@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_post(const DevPlan* __restrict__ plan, 
   __shared__ unsigned char keep[kPostMaxDets];
   __shared__ int s_n, s_over, s_lit, s_kept, s_base;
   const int frame = (int)blockIdx.x, tid = (int)threadIdx.x;
-  const unsigned n_out = (unsigned)min(w.counters[kCntOut], (unsigned long long)w.cap);
+  const unsigned n_out = (unsigned)min(w.counters[kCntOut], (unsigned long long)w.cap_m);
   const unsigned wpf = (unsigned)plan->windows;
   const unsigned g_lo = rag_gid ? rag_gid[frame] : 0u, g_hi = rag_gid ? rag_gid[frame + 1] : 0u;
   if (tid == 0) { s_n = 0; s_over = 0; s_lit = 0; s_kept = 0; s_base = 0; }

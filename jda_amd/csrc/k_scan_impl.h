@@ -540,7 +540,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
       const int widx = q_widx[cur * M_MAX + i];
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const unsigned slot = gbase + i;
-      if (slot < w.cap) {
+      if (slot < w.cap_q) {
         w.q_gid[slot] = (uint32_t)(gid0 + (wy0 + wy) * lv.nx + wx0 + wx);
         w.q_score[slot] = q_score[cur * M_MAX + i];
         w.q_kstart[slot] = (uint32_t)K;

@@ -427,7 +427,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
       const int wy = widx / tw_s, wx = widx - wy * tw_s;
       const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
       const unsigned slot = gbase + (unsigned)rank;
-      if (slot < w.cap) {
+      if (slot < (cfg.to_mid ? w.cap_m : w.cap_q)) {
         const uint32_t gid = RAGGED ? (uint32_t)(g2.x + (wy0 + wy) * g2.y + wx0 + wx)
                                     : (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
         const uint32_t xy = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);

@@ -223,7 +223,7 @@ void k_stage(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
     if (TRACE) { w.tr_carts[gid] = carts_n; w.tr_score[gid] = score; w.tr_hash[gid] = hash; }
     if (alive && !(apply_th && score < final_th)) {                       // c/jda.c:414
       const unsigned o = (unsigned)atomicAdd(&w.counters[kCntOut], 1ull);
-      if (o < w.cap) {
+      if (o < w.cap_m) {
         w.out_gid[o] = gid; w.out_score[o] = score;
         const Real* src = w.m_shape + (size_t)gid * dim;
         for (int d = 0; d < dim; d++) w.out_shape[(size_t)o * dim + d] = src[d];

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
 #define JDA_WSTAMP() do { } while (0)
 #endif
   if (tid < kMaxStages) stage_cnt[tid] = 0;
-  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap);
+  const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap_q);
   unsigned long long carts_acc = 0;
 
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
       if (tid == 0) misc[1] = (int)atomicAdd(&w.counters[kCntOut], 1ull);
       __syncthreads();
       const unsigned o = (unsigned)misc[1];
-      if (o < w.cap) {
+      if (o < w.cap_m) {
         if (tid == 0) { w.out_gid[o] = gid; w.out_score[o] = score; }
         for (int d = tid; d < dim; d += BLOCK) w.out_shape[(size_t)o * dim + d] = sh[d];
       }

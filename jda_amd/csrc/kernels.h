@@ -169,7 +169,12 @@ struct WorkT {
   uint32_t* out_gid; Real* out_score; Real* out_shape;
   // per-window trace (all null when off), indexed by gid
   int* tr_carts; Real* tr_score; uint32_t* tr_hash; Real* tr_shape;
-  unsigned cap;                                                // capacity of every per-window array
+  unsigned cap;                                                // windows of the pass at most: entries of the per-window arrays (trace; dense mode's state)
+  // The queues are sized from what earlier passes left in them, not for the worst case (r06): cap_q entries of the hand-off
+  // queue (q_*), cap_m of the mid queue (m_*) and of the detection list (out_*).  A kernel never writes past them; the
+  // counters keep counting, so the host sees an overflow as counter > capacity and runs the pass again with room
+  // (Pass::recover_overflow).  Dense mode uses m_* as per-window state: the host gives it cap_m >= cap.
+  unsigned cap_q, cap_m;
   // ragged batch (all null otherwise): (image, level) segments, the block map of the scan launches, image offsets
   const RagSeg* segs; const RagBlk* blk; const unsigned long long* img_off;
 #ifdef JDA_SCAN_TIMING

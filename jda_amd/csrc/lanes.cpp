@@ -65,6 +65,8 @@ Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted, Lane::B
 
 // ---------------------------------------------------------------- workspace
 
+// Bytes of the per-window arrays of a pass sized for the WORST case: every window in every queue (what a pass costs when
+// its queues cannot be bounded: traces, dense mode, plans without a prediction under ws_bound = 0).
 template <typename Real>
 size_t bytes_per_window(int dim, bool trace) {
   size_t b = (4 + sizeof(Real) + 4 + 8) + 2 * (4 + sizeof(Real) + (size_t)dim * sizeof(Real)) + 8 + 4;
@@ -72,56 +74,77 @@ size_t bytes_per_window(int dim, bool trace) {
   return b;
 }
 
-// The lane's per-window arrays for `cap` windows of dialect Real (grow-only; the lane is idle: its holder has
-// collected whatever ran on it).
+namespace {
+// The arrays of a workspace for `cap` windows with cap_q hand-off entries and cap_m mid-queue / detection entries, carved
+// out of one allocation (base == nullptr: only the size is computed).
 template <typename Real>
-bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim) {
-  if (ln->cap >= cap && (ln->trace || !trace) && ln->dim == dim && ln->real_bytes == (int)sizeof(Real)) return true;
-  trace = trace || (ln->trace && ln->dim == dim && ln->real_bytes == (int)sizeof(Real));
-  cap = std::max(cap, ln->real_bytes == (int)sizeof(Real) && ln->dim == dim ? ln->cap : (size_t)0);
-  WorkT<Real>& w = Sel<Real>::work(ln);
-  auto carve = [&](Carver& cv) {
-    w.q_gid = cv.take<uint32_t>(cap);
-    w.q_score = cv.take<Real>(cap);
-    w.q_kstart = cv.take<uint32_t>(cap);
-    w.q_xy = cv.take<uint32_t>(cap);
-    w.q_wf = cv.take<uint32_t>(cap);
-    w.q_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
-    w.m_gid = cv.take<uint32_t>(cap);
-    w.m_score = cv.take<Real>(cap);
-    w.m_hash = trace ? cv.take<uint32_t>(cap) : nullptr;
-    w.m_shape = cv.take<Real>(cap * dim);
-    w.m_xy = cv.take<uint32_t>(cap);
-    w.m_wf = cv.take<uint32_t>(cap);
-    w.st_carts = cv.take<int>(cap);
-    w.out_gid = cv.take<uint32_t>(cap);
-    w.out_score = cv.take<Real>(cap);
-    w.out_shape = cv.take<Real>(cap * dim);
-    w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
+size_t carve_workspace(void* base, WorkT<Real>& w, size_t cap, size_t cap_q, size_t cap_m, bool trace, bool dense, int dim) {
+  Carver cv(base);
+  w.q_gid = cv.take<uint32_t>(cap_q);
+  w.q_score = cv.take<Real>(cap_q);
+  w.q_kstart = cv.take<uint32_t>(cap_q);
+  w.q_xy = cv.take<uint32_t>(cap_q);
+  w.q_wf = cv.take<uint32_t>(cap_q);
+  w.q_hash = trace ? cv.take<uint32_t>(cap_q) : nullptr;
+  w.m_gid = cv.take<uint32_t>(cap_m);
+  w.m_score = cv.take<Real>(cap_m);
+  w.m_hash = trace ? cv.take<uint32_t>(cap_m) : nullptr;
+  w.m_shape = cv.take<Real>(cap_m * dim);
+  w.m_xy = cv.take<uint32_t>(cap_m);
+  w.m_wf = cv.take<uint32_t>(cap_m);
+  w.st_carts = dense ? cv.take<int>(cap) : nullptr;          // (dense mode only: k_stage)
+  w.out_gid = cv.take<uint32_t>(cap_m);
+  w.out_score = cv.take<Real>(cap_m);
+  w.out_shape = cv.take<Real>(cap_m * dim);
+  w.counters = cv.take<unsigned long long>(kCntShards * kCntStride);
 #ifdef JDA_SCAN_TIMING
-    w.dbg = cv.take<unsigned long long>(65536 * 32);
+  w.dbg = cv.take<unsigned long long>(65536 * 32);
 #endif
-    if (trace) {
-      w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
-      w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
-    } else {
-      w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
-    }
-  };
+  if (trace) {
+    w.tr_carts = cv.take<int>(cap); w.tr_score = cv.take<Real>(cap);
+    w.tr_hash = cv.take<uint32_t>(cap); w.tr_shape = cv.take<Real>(cap * dim);
+  } else {
+    w.tr_carts = nullptr; w.tr_score = nullptr; w.tr_hash = nullptr; w.tr_shape = nullptr;
+  }
+  return cv.off + 256;
+}
+}  // namespace
+
+template <typename Real>
+size_t workspace_bytes(size_t cap, size_t cap_q, size_t cap_m, bool trace, bool dense, int dim) {
+  WorkT<Real> w{};
+  if (dense) cap_m = std::max(cap_m, cap);
+  return carve_workspace<Real>(nullptr, w, cap, std::min(cap_q, cap), std::min(cap_m, cap), trace, dense, dim);
+}
+
+// The lane's arrays for a pass over `cap` windows of dialect Real whose hand-off queue holds cap_q and whose mid queue
+// and detection list hold cap_m entries (0: cap, the worst case); dense: the per-window state of k_stage too (then
+// cap_m >= cap).  Grow-only per size; the lane is idle: its holder has collected whatever ran on it.
+template <typename Real>
+bool ensure_workspace(Lane* ln, size_t cap, bool trace, int dim, size_t cap_q, size_t cap_m, bool dense) {
+  if (cap_q == 0 || cap_q > cap) cap_q = cap;
+  if (cap_m == 0 || cap_m > cap) cap_m = cap;
+  if (dense) cap_m = cap;
+  const bool same = ln->dim == dim && ln->real_bytes == (int)sizeof(Real);
+  if (same && ln->cap >= cap && ln->cap_q >= cap_q && ln->cap_m >= cap_m && (ln->trace || !trace) && (ln->dense_ws || !dense)) return true;
+  if (same) {
+    trace = trace || ln->trace; dense = dense || ln->dense_ws;
+    cap = std::max(cap, ln->cap); cap_q = std::max(cap_q, ln->cap_q); cap_m = std::max(cap_m, ln->cap_m);
+  }
+  if (dense) cap_m = std::max(cap_m, cap);
+  WorkT<Real>& w = Sel<Real>::work(ln);
   if (ln->stream) (void)hipStreamSynchronize(ln->stream);      // nothing may still use the old carving
   w = WorkT<Real>{};
-  Carver sz(nullptr);
-  carve(sz);
-  if (!ln->ws.reserve(sz.off + 256)) {
+  const size_t bytes = carve_workspace<Real>(nullptr, w, cap, cap_q, cap_m, trace, dense, dim);
+  if (!ln->ws.reserve(bytes)) {
     // the old allocation is gone: forget every pointer carved out of it
-    ln->cap = 0; ln->trace = false; ln->real_bytes = 0;
+    ln->cap = 0; ln->cap_q = 0; ln->cap_m = 0; ln->trace = false; ln->dense_ws = false; ln->real_bytes = 0;
     ln->wf = WorkT<float>{}; ln->wd = WorkT<double>{};
     return false;
   }
-  Carver cv(ln->ws.p);
-  carve(cv);
-  w.cap = (unsigned)cap;
-  ln->cap = cap; ln->trace = trace; ln->dim = dim; ln->real_bytes = (int)sizeof(Real);
+  (void)carve_workspace<Real>(ln->ws.p, w, cap, cap_q, cap_m, trace, dense, dim);
+  w.cap = (unsigned)cap; w.cap_q = (unsigned)cap_q; w.cap_m = (unsigned)cap_m;
+  ln->cap = cap; ln->cap_q = cap_q; ln->cap_m = cap_m; ln->trace = trace; ln->dense_ws = dense; ln->dim = dim; ln->real_bytes = (int)sizeof(Real);
   return true;
 }
 
@@ -148,7 +171,9 @@ bool copy_frames_h2d(uint8_t* dst, size_t stride, const unsigned char* const* fr
 
 template size_t bytes_per_window<float>(int, bool);
 template size_t bytes_per_window<double>(int, bool);
-template bool ensure_workspace<float>(Lane*, size_t, bool, int);
-template bool ensure_workspace<double>(Lane*, size_t, bool, int);
+template bool ensure_workspace<float>(Lane*, size_t, bool, int, size_t, size_t, bool);
+template bool ensure_workspace<double>(Lane*, size_t, bool, int, size_t, size_t, bool);
+template size_t workspace_bytes<float>(size_t, size_t, size_t, bool, bool, int);
+template size_t workspace_bytes<double>(size_t, size_t, size_t, bool, bool, int);
 
 }  // namespace jda

@@ -22,13 +22,35 @@ struct Pass {
   void bind(Lane* l, int index, hipStream_t stream) {
     ln = l; lane = index; st = stream ? stream : l->stream; ev = l->ev; h_cnt = l->h_cnt;
     timed = !rs || rs->timed || c->kn.debug_times;
-    w = Sel<Real>::work(l); cap = l->cap;
+    w = Sel<Real>::work(l); cap = l->cap; cap_q = w.cap_q; cap_m = w.cap_m;
     std::lock_guard<std::mutex> lk(c->mu);
     hint_dense = pe->dense_hint; pred_tail = pe->pred_tail; pred_out = pe->pred_out; pred_mid = pe->pred_mid;
     busy_lanes = 0;
     for (auto& up : c->lanes) busy_lanes += up->busy ? 1 : 0;
   }
   WorkT<Real> w; size_t cap = 0;
+  size_t cap_q = 0, cap_m = 0;     // entries of the hand-off queue / of the mid queue and the detection list (WorkT::cap_q, cap_m)
+  bool counted = false;            // after_counters has folded and tallied this pass's counters
+  int overflow_runs = 0;           // times this pass has been issued again because a queue was too small (recover_overflow)
+  // The lane's workspace has been carved again (grown): its array pointers replace the pass's, what the pass itself set
+  // (frames, pyramid images, ragged tables) stays.
+  void adopt_workspace() {
+    WorkT<Real> nw = Sel<Real>::work(ln);
+    nw.frames = w.frames; nw.frame_stride = w.frame_stride; nw.n_frames = w.n_frames;
+    nw.half = w.half; nw.half_stride = w.half_stride; nw.hw = w.hw; nw.hh = w.hh;
+    nw.quarter = w.quarter; nw.quarter_stride = w.quarter_stride; nw.qw = w.qw; nw.qh = w.qh;
+    nw.patch_hs = w.patch_hs; nw.patch_qs = w.patch_qs;
+    nw.segs = w.segs; nw.blk = w.blk; nw.img_off = w.img_off;
+    w = nw; cap = ln->cap; cap_q = w.cap_q; cap_m = w.cap_m;
+  }
+  // Dense mode keeps per-window state in the mid-queue arrays (k_stage): every window needs an entry.
+  bool grow_for_dense() {
+    if (ln->dense_ws && cap_m >= (size_t)windows()) return true;
+    JDA_HIP(hipStreamSynchronize(st));
+    if (!ensure_workspace<Real>(ln, std::max(cap, (size_t)windows()), want_trace(), hm().dim(), cap_q, 0, true)) return false;
+    adopt_workspace();
+    return true;
+  }
   int f0 = 0, nf = 0;
   const unsigned char* const* host_frames = nullptr; size_t host_fbytes = 0;   // frames of this sub-batch still on the host
   const RaggedChunk* rag = nullptr;   // ragged pass: images of different sizes (w.segs / w.blk / w.img_off set by stage_ragged)
@@ -247,6 +269,7 @@ struct Pass {
     const bool ok = dense_ok(&pix_cap, &lds_max);
     dense = ok && (kn().dense == 2 || hint_dense);
     if (dense) {
+      if (!grow_for_dense() || !clear_counters()) return false;     // (the counters moved with the workspace)
       if (timed) JDA_HIP(hipEventRecord(ev[1], st));
       if (timed) JDA_HIP(hipEventRecord(ev[2], st));
       finished = true;
@@ -337,18 +360,19 @@ struct Pass {
     int pix_cap, lds_max;
     if (kn().predict && pred_tail >= 0 && !(kn().dense == 1 && dense_ok(&pix_cap, &lds_max) && pred_tail + std::max(0.0, pred_mid) >= 0.4)) {
       const long long nw = windows();
-      const long long guess = std::min<long long>((long long)cap, (long long)(pred_tail * (double)nw * 1.1) + 64);
+      const long long guess = std::min<long long>((long long)cap_q, (long long)(pred_tail * (double)nw * 1.1) + 64);
       if (!launch_finishers(guess)) return false;
       predicted = true;
       const double po = pred_out >= 0 ? pred_out : 0.0;
-      const size_t to = std::min<size_t>(cap, (size_t)(po * (double)nw * 1.25) + 64);
-      if constexpr (sizeof(Real) == 4) {
+      const size_t to = std::min<size_t>(cap_m, (size_t)(po * (double)nw * 1.25) + 64);
+      bool ok;
+      if (sizeof(Real) == 4 && want_post && kn().kernel_d2h && dets && to > 0 && !want_trace() && !dense) {
         // dialect C, uniform batch: scan order, score order, NMS and relocation per frame on the device, results straight
         // into pinned memory (k_post); a frame or a row count it declines sends the pass through the host path below
-        if (want_post && kn().kernel_d2h && dets && to > 0 && !want_trace() && !dense) return issue_post(to) && issue_counters();
-      }
-      if (kn().kernel_d2h && dets && to > 0) return issue_results(0, to, true);      // counters + prefix in one launch
-      return issue_counters() && issue_results(0, to);
+        ok = issue_post(to) && issue_counters();
+      } else if (kn().kernel_d2h && dets && to > 0) ok = issue_results(0, to, true);      // counters + prefix in one launch
+      else ok = issue_counters() && issue_results(0, to);
+      return ok;
     }
     // the hand-off queue length sizes the finishing launches (one workgroup per window)
     return read_counter(kCntTail);
@@ -404,7 +428,7 @@ struct Pass {
       // the mid queue already holds stage-0 survivors (k_scan_p): the rest of the hand-off queue is filtered into it,
       // then everybody goes through k_finish(survivors)
       const long long nmid = pred_mid >= 0 ? (long long)(pred_mid * (double)windows() * 1.25) + 64 : 0;
-      const long long wg2 = std::min<long long>((long long)cap, std::max<long long>(std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)), nmid));
+      const long long wg2 = std::min<long long>((long long)cap_m, std::max<long long>(std::max<long long>(2048, n_grid / std::max<long long>(1, kn().fin_grid_div)), nmid));
       JDA_HIP(launch_filter0<Real>(want_trace(), pe->dp, model(), w, n_grid, s0_tbl(), st));
       JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, g2, wg2, s0_tbl(), (int)kn().fin_tile, st, true));
       finished = true;
@@ -451,19 +475,23 @@ struct Pass {
   bool after_tail() {
     if (finished) return true;
     JDA_HIP(hipStreamSynchronize(st));
-    n_tail = (long long)std::min<unsigned long long>(h_cnt[0], cap);
-    const long long n_alive = n_tail + (mid_direct ? (long long)std::min<unsigned long long>(h_cnt[kCntMid - kCntTail], cap) : 0);
+    // (the counters count every window the scan kept, also those a queue had no room for)
+    const unsigned long long true_tail = h_cnt[0], true_mid = mid_direct ? h_cnt[kCntMid - kCntTail] : 0ull;
+    n_tail = (long long)std::min<unsigned long long>(true_tail, cap_q);
+    const long long n_alive = (long long)(true_tail + true_mid);
     int pix_cap, lds_max;
     const double dense_frac = (double)kn().dense_pct / 100.0;
     if (dense_ok(&pix_cap, &lds_max) && (double)n_alive >= dense_frac * (double)windows() && n_alive > 4096) {
       // most windows are still alive after the scan: start over in dense mode (the scan's work
       // is a small part of T*K carts per window) and remember the choice for the next pass
       { std::lock_guard<std::mutex> lk(c->mu); pe->dense_hint = true; }
-      if (rag) return launch_finishers(n_tail);   // (a ragged pass finishes window by window; the NEXT job runs image by image, dense)
-      dense = true; finished = true;
-      if (!clear_counters()) return false;
-      return run_dense();
+      if (!rag) {                                  // (a ragged pass finishes window by window; the NEXT job runs image by image, dense)
+        dense = true; finished = true;
+        if (!grow_for_dense() || !clear_counters()) return false;
+        return run_dense();
+      }
     }
+    if (true_tail > cap_q || true_mid > cap_m) return recover_overflow(true_tail, true_mid, 0);
     return launch_finishers(n_tail);
   }
 
@@ -541,6 +569,7 @@ struct Pass {
   // step 5: statistics, (the rest of) the detections -> host (asynchronous)
   bool after_counters() {
     const int T = hm().T;
+    if (counted) return true;        // (a rerun inside after_tail has already been through here: the counters are folded and tallied ONCE)
     JDA_HIP(hipStreamSynchronize(st));
     results_pending = false;
     for (int shd = 1; shd < kCntShards; shd++) {   // fold the counter shards into shard 0
@@ -558,6 +587,8 @@ struct Pass {
           if (pe->hp.lv[l].tiled != 0) expect += (long long)pe->hp.lv[l].nx * pe->hp.lv[l].ny * nf;
       if (err != 0 || (long long)h_cnt[kCntWinScan] != expect) return recover_scan(err, (long long)h_cnt[kCntWinScan], expect);
     }
+    if (!dense && (h_cnt[kCntTail] > cap_q || h_cnt[kCntMid] > cap_m || h_cnt[kCntOut] > cap_m))
+      return recover_overflow(h_cnt[kCntTail], h_cnt[kCntMid], h_cnt[kCntOut]);
     rs->carts += (long long)h_cnt[kCntCarts];
     rs->carts_scan += (long long)h_cnt[kCntCartsScan];
     rs->carts_scan_glb += (long long)h_cnt[kCntCartsScanGlb];
@@ -569,7 +600,7 @@ struct Pass {
     n_tail = (long long)h_cnt[kCntTail];
     n_out = (size_t)h_cnt[kCntOut];
     rs->out += (long long)n_out;
-    if (n_out > cap) { fail("internal: more detections than windows"); return false; }
+    if (n_out > cap_m) { fail("internal: more detections than the detection list holds"); return false; }
     if (dense) rs->dense_passes++;
     {
       std::lock_guard<std::mutex> lk(c->mu);            // the plan and the cascador's hints are shared with concurrent callers
@@ -592,6 +623,7 @@ struct Pass {
       }
       c->last_dense = pe->dense_hint;
     }
+    counted = true;
     if (post_issued) {
       posted = ((const int*)ln->h_pn.p)[2 * nf] == 0;
       if (posted) return true;                 // (nothing else to fetch: the frames' results are in pinned memory)
@@ -612,11 +644,42 @@ struct Pass {
     no_scan_p = true;
     rs->scan_launches -= my_scan_launches; my_scan_launches = 0;
     dense = false; finished = false; lds_span = false; predicted = false; counters_issued = false; results_pending = false;
-    p_launches = 0; post_issued = false; posted = false; post_cap = 0; mid_direct = false; n_tail = -1; n_out = 0; out_copied = 0;
+    p_launches = 0; post_issued = false; posted = false; post_cap = 0; mid_direct = false; n_tail = -1; n_out = 0; out_copied = 0; counted = false;
     host_frames = nullptr;                 // (already in the staging buffer)
     if (!issue_scan(a_hbuf, a_hs, a_qbuf, a_qs, nullptr) || !after_tail() || !issue_counters() || !after_counters()) return false;
     rs->scan_fallbacks++;                  // (jdaStats::scan_fallbacks: the error channel stays for errors)
     return true;
+  }
+
+  // A queue of this pass was too small for what the scan (or a finishing kernel) kept: the kernels dropped what did not
+  // fit and kept counting, so nothing of the pass is usable but its counts.  The workspace grows to them -- a queue
+  // downstream of the one that overflowed has only seen a part of its input: its count is scaled up -- and the whole pass
+  // is issued again on the same lane; a third attempt takes the worst-case sizes.  The caller gets correct results, a note
+  // on stderr and jdaStats::ws_regrows; the plan's fractions are updated by the rerun, so the next pass is sized right.
+  bool recover_overflow(unsigned long long tail, unsigned long long mid, unsigned long long out) {
+    overflow_runs++;
+    const size_t nw = (size_t)windows();
+    size_t nq = cap_q, nm = cap_m;
+    if (overflow_runs >= 3) { nq = nw; nm = nw; }
+    else {
+      const double up = tail > cap_q ? (double)tail / (double)std::max<size_t>(1, cap_q) : 1.0;   // what the truncated hand-off queue hid from the later counts
+      if (tail > cap_q) nq = std::min(nw, (size_t)((double)tail * 1.25) + 64);
+      const double need_m = (double)std::max(mid, out) * up;
+      if (need_m > (double)cap_m || tail > cap_q) nm = std::min(nw, std::max(cap_m, (size_t)(need_m * 1.5) + 64));
+    }
+    std::fprintf(stderr, "libjda: a queue of a pass over %zu windows was too small (hand-off %llu of %zu, mid %llu / detections %llu of %zu) -- "
+                         "workspace grown to %zu / %zu entries, pass run again\n", nw, tail, cap_q, mid, out, cap_m, nq, nm);
+    JDA_HIP(hipStreamSynchronize(st));
+    if (ln->side) JDA_HIP(hipStreamSynchronize(ln->side));
+    if (!ensure_workspace<Real>(ln, std::max(cap, nw), want_trace(), hm().dim(), nq, nm, ln->dense_ws)) return false;
+    adopt_workspace();
+    rs->scan_launches -= my_scan_launches; my_scan_launches = 0;
+    dense = false; finished = false; lds_span = false; predicted = false; counters_issued = false; results_pending = false;
+    p_launches = 0; post_issued = false; posted = false; post_cap = 0; mid_direct = false; n_tail = -1; n_out = 0; out_copied = 0; counted = false;
+    host_frames = nullptr;                 // (already in the staging buffer)
+    pred_tail = -1;                        // (no prediction for the rerun: the host reads the hand-off count first)
+    rs->ws_regrows++;
+    return issue_scan(a_hbuf, a_hs, a_qbuf, a_qs, nullptr) && after_tail() && issue_counters() && after_counters();
   }
 
   // step 6: detections of this pass sorted back into scan order and appended; trace arrays

@@ -157,6 +157,7 @@ void fill_stats(jdaStats* st, const RunStats& rs, long long patch_n, int T, int 
   st->handoff_n = rs.tail;
   st->dense_passes = rs.dense_passes;
   st->scan_fallbacks = rs.scan_fallbacks;
+  st->ws_regrows = rs.ws_regrows;
   st->scan_lds_ms = rs.scan_lds_ms; st->scan_lds_cart_n = rs.carts_scan - rs.carts_scan_glb;
 }
 

@@ -443,7 +443,7 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
 static void add_stats(RunStats* a, const RunStats& b) {
   a->carts += b.carts; a->out += b.out; a->carts_scan += b.carts_scan; a->carts_scan_glb += b.carts_scan_glb;
   a->win_scan += b.win_scan; a->tail += b.tail; a->gpu_ms += b.gpu_ms; a->scan_ms += b.scan_ms;
-  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes; a->scan_fallbacks += b.scan_fallbacks;
+  a->scan_launches += b.scan_launches; a->dense_passes += b.dense_passes; a->scan_fallbacks += b.scan_fallbacks; a->ws_regrows += b.ws_regrows;
   for (int t = 0; t < kMaxStages; t++) a->stage_done[t] += b.stage_done[t];
 }
 
@@ -531,7 +531,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
       if (rc != 0) return -1;
       total.carts += st1.cart_total_n; total.out += st1.face_patch_n; total.carts_scan += st1.scan_cart_n;
       total.win_scan += st1.scan_patch_n; total.tail += st1.handoff_n; total.gpu_ms += st1.gpu_ms; total.scan_ms += st1.scan_ms;
-      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes; total.scan_fallbacks += st1.scan_fallbacks;
+      total.scan_launches += st1.scan_launches; total.dense_passes += st1.dense_passes; total.scan_fallbacks += st1.scan_fallbacks; total.ws_regrows += st1.ws_regrows;
       for (int t = 0; t < 16 && t < kMaxStages; t++) total.stage_done[t] += st1.stage_done_n[t];
       patch_n += st1.patch_n; post_ms += st1.host_ms;
     }
@@ -596,7 +596,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     starts.push_back(n);
   }
   const int n_chunks = (int)starts.size() - 1;
-  const int lanes = std::min(std::min(kRaggedLanes, n_chunks), (int)std::max<long long>(1, c->kn.max_lanes));
+  const int lanes = std::min(std::min((int)std::max<long long>(1, std::min<long long>(8, c->kn.ragged_lanes)), n_chunks), (int)std::max<long long>(1, c->kn.max_lanes));
   struct Slot { bool busy = false; RaggedChunk ch; Pass<Real> pass; RawDets<Real> dets; RunStats rs; };
   std::vector<Slot> slots(lanes);
   LaneSet held(c);
@@ -734,7 +734,9 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     {
       const size_t want = n_chunks > 1 ? std::max<size_t>((size_t)sl.ch.windows, (size_t)std::min<long long>(chunk_windows, 0x7fffffffLL))
                                        : (size_t)sl.ch.windows;
-      if (!ensure_workspace<Real>(ln, want, false, c->hm.dim())) { ok = false; break; }
+      bool want_dense = false;
+      const QueueCaps qc = plan_queue_caps(c, job.pe, want, false, &want_dense);
+      if (!ensure_workspace<Real>(ln, want, false, c->hm.dim(), qc.q, qc.m, false)) { ok = false; break; }      // (a ragged pass never runs dense)
     }
     Pass<Real>& p = sl.pass;
     p = Pass<Real>();

@@ -11,6 +11,16 @@ inline bool jda_gid_overflow(const Knobs& kn, long long n, long long wpf) {
   return (double)n * (double)wpf * (double)scale > 4294967295.0;
 }
 
+// The queue capacities of a pass over `windows` windows on plan pe, from the plan's remembered fractions (read under c->mu);
+// *dense: the plan's last pass kept most windows alive -- the pass will run k_stage and needs the per-window state.
+inline QueueCaps plan_queue_caps(Cascador* c, PlanEntry* pe, size_t windows, bool trace, bool* dense) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  *dense = c->kn.dense == 2 || (c->kn.dense != 0 && pe->dense_hint);
+  // (k_enqueue puts every window of a level without a scan tile into the hand-off queue: the worst case is the common one)
+  const bool full = trace || *dense || !pe->fast_scan || pe->any_untiled;
+  return queue_caps(c->kn, windows, pe->pred_tail, pe->pred_mid, pe->pred_out, full);
+}
+
 // Frames of a call that are still in host memory: run_device copies them sub-batch by sub-batch into the staging buffer
 // of the call's first lane (the copies of one sub-batch then overlap the kernels of the other lane).
 struct HostFrames {
@@ -89,7 +99,18 @@ bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint
   const size_t bpw = bytes_per_window<Real>(dim, want_trace) +
                      (multi && host.patch_hs > 0 ? (size_t)host.patch_hs * host.patch_hs + (size_t)host.patch_qs * host.patch_qs : 0);
   const long long budget = (c->kn.workspace_mb << 20) / lanes;
-  long long fpp = std::max<long long>(1, budget / (long long)(bpw * (size_t)wpf));
+  // (r06: the queues are sized from the plan's remembered fractions, not for every window: far more frames fit the budget.
+  // The patches of method 0 stay per window.)
+  bool want_dense = false;
+  const size_t patch_bpw = bpw - bytes_per_window<Real>(dim, want_trace);
+  auto pass_bytes = [&](long long frames) {
+    const size_t wn = (size_t)frames * (size_t)wpf;
+    const QueueCaps qc = plan_queue_caps(c, pe, wn, want_trace, &want_dense);
+    return (long long)(workspace_bytes<Real>(wn, qc.q, qc.m, want_trace, want_dense, dim) + patch_bpw * wn);
+  };
+  long long fpp = std::max<long long>(1, (n + lanes - 1) / lanes);
+  fpp = std::min<long long>(fpp, std::max<long long>(1, 0x7fffffffLL / wpf));
+  while (fpp > 1 && pass_bytes(fpp) > budget) fpp = std::max<long long>(1, std::min<long long>(fpp - 1, (long long)((double)fpp * (double)budget / (double)pass_bytes(fpp))));
   fpp = std::min<long long>(fpp, (n + lanes - 1) / lanes);
   if (host_frames && lanes > 1) fpp = std::min<long long>(fpp, std::max<long long>(1, host_chunk));
   fpp = std::min<long long>(fpp, 0x7fffffffLL / wpf);
@@ -105,8 +126,9 @@ bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint
   const size_t cap = (size_t)fpp * (size_t)wpf;
   if (!lanes_held.take(lanes, cap)) return false;
   lanes = std::min(lanes, (int)lanes_held.v.size());          // (the pool is at max_lanes: the sub-batches share the lane(s) at hand)
+  const QueueCaps qc = plan_queue_caps(c, pe, cap, want_trace, &want_dense);
   for (int l = 0; l < lanes; l++)
-    if (!ensure_workspace<Real>(lanes_held.v[l], cap, want_trace, dim)) return false;
+    if (!ensure_workspace<Real>(lanes_held.v[l], cap, want_trace, dim, qc.q, qc.m, want_dense)) return false;
 
   int hw = 0, hh = 0, qw = 0, qh = 0;
   size_t hs = 0, qs = 0;

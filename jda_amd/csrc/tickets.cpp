@@ -23,7 +23,9 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
   LaneSet lanes(c);
   if (!lanes.take(1, cap)) return -1;
   Lane* ln = lanes.v[0];
-  if (!ensure_workspace<float>(ln, cap, false, c->hm.dim())) return -1;
+  bool want_dense = false;
+  const QueueCaps qc = plan_queue_caps(c, pe, cap, false, &want_dense);
+  if (!ensure_workspace<float>(ln, cap, false, c->hm.dim(), qc.q, qc.m, want_dense)) return -1;
   if (host_frames) {
     // frames still on the host: the ticket's lane stages them on its own stream (the copy of batch i+1 then runs next
     // to the kernels of batch i, which live on the other ticket's stream)

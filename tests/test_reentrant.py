@@ -239,3 +239,76 @@ def test_idle_lanes_give_their_memory_back_while_others_call(built, gpu, model_f
     for a, b in zip(c.detect_batch(big), want_big):                             # ... and come back on demand
         _eq(a, b, "after the trim")
     c.close()
+
+
+@pytest.mark.gpu
+def test_bounded_queues_overflow_is_noticed_and_the_pass_rerun(built, model_file):
+    """r06: the survivor queues of a pass are sized from the fractions earlier passes left in them (option ws_bound), not for
+    every window.  A pass that outgrows them -- here forced: no floor, no safety factor, a cascade that keeps far more than
+    the first-pass guess -- must be noticed through its counters and run again with room: same results as with worst-case
+    queues, jdaStats.ws_regrows > 0, an empty error string; uniform batch, tickets, ragged job, dialect CPP."""
+    import torch
+    from jda_amd import api, synth
+    from conftest import same
+    p, _ = model_file((3, 20, 5, 4), 8, seed=3, cart_th=-2.5, norm_every=5)      # (keeps a third of the windows and more)
+    frames = synth.make_frames(6, 200, 150, seed=11)
+    d = torch.from_numpy(frames).cuda()
+    rng = np.random.default_rng(2)
+    imgs = [np.ascontiguousarray(frames[i % 6][:int(rng.integers(60, 151)), :int(rng.integers(60, 201))]) for i in range(20)]
+    c0 = api.Cascador(p)
+    c0.set_option("ws_bound", 0)
+    want = c0.detect_batch_device(d)
+    want_rag = c0.detect_ragged(imgs)
+    want_cpp = c0.detect_batch_cpp_device(d)
+    want_rag_cpp = c0.detect_ragged_cpp(imgs)
+    assert sum(len(w["scores"]) for w in want) > 0 and sum(len(w["scores"]) for w in want_cpp) > 0
+
+    def fresh():
+        c = api.Cascador(p)
+        c.set_option("ws_min_entries", 1); c.set_option("ws_factor_pct", 100); c.set_option("device_post_min_frames", 2)
+        c.set_option("dense", 0)              # (the sparse pipeline is what has queues; dense mode is the last case below)
+        return c
+    c = fresh()
+    got, st = c.detect_batch_device(d, stats=True)
+    assert st["ws_regrows"] >= 1 and api.last_error() == ""
+    for a, b in zip(got, want):
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(a[k], b[k]), k
+    assert st["patch_n"] == st["scan_patch_n"]
+    got2, st2 = c.detect_batch_device(d, stats=True)           # the rerun taught the plan its fractions
+    for a, b in zip(got2, want):
+        assert same(a["scores"], b["scores"])
+    c = fresh()
+    got = c.wait_batch(c.submit_batch_device(d))
+    for a, b in zip(got, want):
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(a[k], b[k]), k
+    c = fresh()
+    got, st = c.detect_ragged(imgs, stats=True)
+    assert st["ws_regrows"] >= 1
+    for a, b in zip(got, want_rag):
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(a[k], b[k]), k
+    c = fresh()
+    got, st = c.detect_batch_cpp_device(d, stats=True)
+    assert st["ws_regrows"] >= 1
+    for a, b in zip(got, want_cpp):
+        for k in ("rects", "scores", "shapes"):
+            assert same(a[k], b[k]), k
+    c = fresh()
+    got, st = c.detect_ragged_cpp(imgs, stats=True)
+    assert st["ws_regrows"] >= 1
+    for a, b in zip(got, want_rag_cpp):
+        for k in ("rects", "scores", "shapes"):
+            assert same(a[k], b[k]), k
+    # an all-pass model: the first pass finds most windows alive -> dense mode, which needs per-window state
+    pa, _ = model_file((2, 8, 5, 3), 8, seed=5)
+    ca = fresh(); ca.close()
+    ca = api.Cascador(pa); ca.set_option("ws_min_entries", 1)
+    c0 = api.Cascador(pa); c0.set_option("ws_bound", 0)
+    ga, sa = ca.detect_batch_device(d, th=0.0, stats=True)
+    wa = c0.detect_batch_device(d, th=0.0)
+    assert sa["dense_passes"] >= 1
+    for a, b in zip(ga, wa):
+        for k in ("bboxes", "scores", "shapes"):
+            assert same(a[k], b[k]), k

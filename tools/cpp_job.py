@@ -25,7 +25,7 @@ for im in imgs:
 buf = np.concatenate([im.reshape(-1) for im in imgs])
 ws, hs = [s[0] for s in sizes], [s[1] for s in sizes]
 d_buf = torch.from_numpy(buf).cuda()
-job = lambda: c.detect_ragged_cpp_packed(d_buf, offs, ws, hs, stats=True, keep_results=False)
+job = lambda: c.detect_ragged_cpp_packed(d_buf, offs, ws, hs, stats=True, keep_results="packed")
 job(); job()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(reps):
@@ -33,3 +33,4 @@ for _ in range(reps):
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / reps
 print("CPP ragged job, %d images resident: %.2f ms, %.0f images/s, %.3e windows/s, gpu_ms %.2f scan_ms %.2f host_ms %.2f launches %d handoff %d faces %d"
       % (n_img, el * 1e3, n_img / el, st["patch_n"] / el, st["gpu_ms"], st["scan_ms"], st["host_ms"], st["scan_launches"], st["handoff_n"], st["face_patch_n"]))
+print("stage_done", st["stage_done_n"][:5], "cart_total", st["cart_total_n"], "scan_cart", st["scan_cart_n"])
