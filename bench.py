@@ -771,53 +771,69 @@ def main():
     # ---- the regime of this path in which HBM / Infinity Cache traffic is the bound: BASELINE.json configs[4] (T=7, K=2000,
     #      68 landmarks, depth 6: W = 243.7 MB, 34.8 MB per stage) with every window of a 1080p frame walking all 14,000
     #      carts -- each window gathers K 544-byte weight rows per stage, far more than L2 holds ----
-    x_info = None
+    def x_leg(T_x, fw, fh, traffic_json):
+        """All-pass gather regime: T_x stages of K=2000, 68 landmarks, depth 6; every window of one fw x fh frame walks every
+        cart through k_finish and gathers K 544-byte weight rows per stage."""
+        xd = (T_x, 2000, 68, 6)
+        xp = os.path.join(synth.cache_dir(), "x_allpass.model" if T_x == 7 else "x_allpass_T%d.model" % T_x)
+        if not os.path.exists(xp):
+            synth.make_model(*xd, seed=2).save(xp + ".tmp", 4)
+            os.replace(xp + ".tmp", xp)
+        xc = api.Cascador(xp, "float", device=local_rank)
+        xf = torch.from_numpy(synth.make_frames(1, fw, fh, seed=4)).to(dev)
+        for _ in range(2):
+            xc.detect_batch_device(xf, th=float("inf"), keep_results=False)
+        lsync(); t0 = time.perf_counter()
+        _, xs = xc.detect_batch_device(xf, th=float("inf"), keep_results=False, stats=True)
+        lsync(); xel = time.perf_counter() - t0
+        xc.close()
+        xalg = algorithmic_bytes(xd, xs["cart_total_n"], xs["stage_done_n"][:T_x], xs["patch_n"], 0)
+        xrows = sum(xs["stage_done_n"][:T_x]) * xd[1] * 2 * xd[2] * 4        # the weight rows alone: K rows of 2L floats per window and stage
+        w_mb = T_x * 2000 * 32 * 136 * 4 / 1e6
+        info = {"workload": "T=%d K=2000 L=68 D=6 (W = %.1f MB, %s the 256 MB Infinity Cache), one %dx%d frame, canonical call, every cart "
+                            "threshold -inf (all-pass): %d windows x %d carts" % (T_x, w_mb, "inside" if w_mb < 256 else "BEYOND", fw, fh, xs["patch_n"], T_x * 2000),
+                "w_bytes": w_mb * 1e6, "ms_per_step": xel * 1e3, "windows_per_s": xs["patch_n"] / xel, "carts_per_s": xs["cart_total_n"] / xel,
+                "bound": "hbm", "achieved": xalg / xel / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": xalg / xel / 1e9 / HBM_PEAK_GBPS,
+                "weight_rows_GBps": xrows / xel / 1e9, "frac_weight_rows": xrows / xel / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_window": xalg / max(1, xs["patch_n"]),
+                "traffic": None, "traffic_source": None,
+                "note": "achieved = SURVEY 8(d) algorithmic bytes (10.2 MB per window: 186 B per cart + K weight rows per stage) / wall time of "
+                        "one jdaDetectBatchDevice call; frac_weight_rows prices the weight rows alone (the 186 B per cart of node / pixel "
+                        "bytes are served by L1 / L2 / LDS); a stage's rows (34.8 MB) exceed L2 (4 MB per XCD)"}
+        xt = os.path.join(ROOT, "profiles", traffic_json)
+        if os.path.exists(xt):
+            tj = json.load(open(xt))
+            info["traffic"] = tj["traffic_line_bytes"]
+            info["traffic_over_algorithmic"] = tj["traffic_line_bytes"] / tj["algorithmic_bytes"]
+            info["traffic_over_weight_rows"] = tj["traffic_line_bytes"] / tj["weight_row_bytes"]
+            info["traffic_GBps_in_profiled_run"] = tj["traffic_line_bytes"] / tj["duration_s"] / 1e9
+            info["traffic_useful_equivalent"] = tj["traffic_useful_equivalent_bytes"]
+            info["traffic_source"] = ("profiles/%s: %s -- builder-run rocprofv3 --pmc passes, NOT measured in this run: "
+                                      "fabric read requests of the k_finish dispatch x 128 B (= FETCH_SIZE x 2), FETCH_SIZE calibrated on a gather of "
+                                      "544-byte rows of known size; Infinity-Cache hits are included, no counter separates them from HBM reads"
+                                      % (traffic_json, tj.get("source", "?")))
+            # the counters were taken on a particular build: is it the device code this run uses?
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_traffic
+                info["traffic_from_this_device_code"] = tj.get("kernel_sources_sha256") == pmc_traffic.kernel_sources_sha256()
+            except Exception:
+                info["traffic_from_this_device_code"] = None
+        return info
+
+    x_info = x_big_info = None
     if rank == 0 and not args.no_allpass and not args.no_x:
         try:
-            xd = (7, 2000, 68, 6)
-            xp = os.path.join(synth.cache_dir(), "x_allpass.model")
-            if not os.path.exists(xp):
-                synth.make_model(*xd, seed=2).save(xp + ".tmp", 4)
-                os.replace(xp + ".tmp", xp)
-            xc = api.Cascador(xp, "float", device=local_rank)
-            xf = torch.from_numpy(synth.make_frames(1, 1920, 1080, seed=4)).to(dev)
-            for _ in range(2):
-                xc.detect_batch_device(xf, th=float("inf"), keep_results=False)
-            lsync(); t0 = time.perf_counter()
-            _, xs = xc.detect_batch_device(xf, th=float("inf"), keep_results=False, stats=True)
-            lsync(); xel = time.perf_counter() - t0
-            xc.close()
-            xalg = algorithmic_bytes(xd, xs["cart_total_n"], xs["stage_done_n"][:7], xs["patch_n"], 0)
-            x_info = {"workload": "BASELINE.json configs[4]: T=7 K=2000 L=68 D=6 (float model 259.6 MB), one 1920x1080 frame, canonical "
-                                  "call, every cart threshold -inf (all-pass): 303,222 windows x 14,000 carts",
-                      "ms_per_step": xel * 1e3, "windows_per_s": xs["patch_n"] / xel, "carts_per_s": xs["cart_total_n"] / xel,
-                      "bound": "hbm", "achieved": xalg / xel / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                      "frac": xalg / xel / 1e9 / HBM_PEAK_GBPS,
-                      "algorithmic_bytes_per_window": xalg / max(1, xs["patch_n"]),
-                      "traffic": None, "traffic_source": None,
-                      "note": "achieved = SURVEY 8(d) algorithmic bytes (10.2 MB per window: 186 B per cart + K weight rows per stage) "
-                              "/ wall time of one jdaDetectBatchDevice call; the 34.8 MB of a stage's weight rows exceed L2 (4 MB per "
-                              "XCD) and are served by the Infinity Cache / HBM"}
-            xt = os.path.join(ROOT, "profiles", "x_allpass_traffic.json")
-            if os.path.exists(xt):
-                tj = json.load(open(xt))
-                x_info["traffic"] = tj["traffic_line_bytes"]
-                x_info["traffic_over_algorithmic"] = tj["traffic_line_bytes"] / tj["algorithmic_bytes"]
-                x_info["traffic_GBps_in_profiled_run"] = tj["traffic_line_bytes"] / tj["duration_s"] / 1e9
-                x_info["traffic_useful_equivalent"] = tj["traffic_useful_equivalent_bytes"]
-                x_info["traffic_source"] = ("profiles/x_allpass_traffic.json: %s -- builder-run rocprofv3 --pmc passes, NOT measured in this run: "
-                                            "fabric read requests of the k_finish dispatch x 128 B (= FETCH_SIZE x 2), FETCH_SIZE calibrated on a gather of "
-                                            "544-byte rows of known size; Infinity-Cache hits are included, no counter separates them from HBM reads"
-                                            % tj.get("source", "?"))
-                # the counters were taken on a particular build: is it the device code this run uses?
-                try:
-                    sys.path.insert(0, os.path.join(ROOT, "tools"))
-                    import pmc_traffic
-                    x_info["traffic_from_this_device_code"] = tj.get("kernel_sources_sha256") == pmc_traffic.kernel_sources_sha256()
-                except Exception:
-                    x_info["traffic_from_this_device_code"] = None
+            x_info = x_leg(7, 1920, 1080, "x_allpass_traffic.json")             # BASELINE configs[4]
         except Exception as e:
             x_info = {"error": repr(e)}
+        try:
+            # the same model with twice the stages: W = 487 MB cannot sit in the Infinity Cache (a quarter-size frame keeps the
+            # leg short) -- is the configs[4] figure an HBM figure or a cache figure?
+            x_big_info = x_leg(14, 960, 540, "x_allpass_T14_traffic.json")
+        except Exception as e:
+            x_big_info = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and not args.no_cpu:
@@ -962,6 +978,12 @@ def main():
             "hbm_regime_bound": "hbm", "hbm_regime_frac": g(x_info, "frac"), "hbm_regime_achieved_GBps": g(x_info, "achieved"),
             "hbm_regime_peak_GBps": HBM_PEAK_GBPS, "hbm_regime_ms_per_step": g(x_info, "ms_per_step"),
             "hbm_regime_traffic_over_algorithmic": g(x_info, "traffic_over_algorithmic"),
+            "hbm_regime_frac_weight_rows": g(x_info, "frac_weight_rows"),
+            "hbm_regime_traffic_from_this_device_code": g(x_info, "traffic_from_this_device_code"),
+            # the same gather with W = 487 MB, beyond the 256 MB Infinity Cache (T=14, one 960x540 frame), measured in this run
+            "hbm_regime_beyond_mall_frac": g(x_big_info, "frac"), "hbm_regime_beyond_mall_frac_weight_rows": g(x_big_info, "frac_weight_rows"),
+            "hbm_regime_beyond_mall_ms_per_step": g(x_big_info, "ms_per_step"), "hbm_regime_beyond_mall_w_bytes": g(x_big_info, "w_bytes"),
+            "hbm_regime_beyond_mall_traffic_over_algorithmic": g(x_big_info, "traffic_over_algorithmic"),
             "hbm_regime_workload": "configs[4]: T=7 K=2000 L=68 D=6, one 1080p frame, all-pass: 303,222 windows x 14,000 carts",
             "allpass_lds_frac": g(allpass_roof, "frac"), "allpass_lds_achieved_GBps": g(allpass_roof, "achieved"),
             "hbm_side_measured_frac_of_hbm_peak": hbm_frac,
@@ -1011,6 +1033,7 @@ def main():
             "parity": parity,
             "config2": config2_live,
             "roofline_hbm_regime": x_info,
+            "roofline_hbm_regime_beyond_mall": x_big_info,
             "roofline_allpass": allpass_roof,
             "regimes": {"cascade": casc_info, "cascade_single_caller": single_info, "cascade_one_lane": roof_info,
                         "allpass": allpass_info, "host_frames": host_info},

@@ -221,6 +221,15 @@ def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_ubyte))
 
 
+def _ivec(v, ctype=C.c_int, dtype=np.int32):
+    """A sequence of integers as a C array argument without a Python loop (a job of thousands of images passes three of
+    them per call).  Returns (keep-alive array, pointer)."""
+    a = np.ascontiguousarray(v, dtype)
+    if a.size == 0:
+        a = np.zeros(1, dtype)
+    return a, a.ctypes.data_as(C.POINTER(ctype))
+
+
 def _take(r):
     """jdaResult -> dict of numpy copies, then release the C arrays."""
     n, dim = r.n, 2 * r.landmark_n
@@ -394,18 +403,17 @@ class Cascador:
         back): a numpy uint8 array (host entry, jdaDetectBatchRagged) or a torch uint8 CUDA tensor
         (jdaDetectBatchRaggedDevice)."""
         n = len(offsets)
-        ws = (C.c_int * max(n, 1))(*[int(v) for v in widths])
-        hs = (C.c_int * max(n, 1))(*[int(v) for v in heights])
+        _kw, ws = _ivec(widths)
+        _kh, hs = _ivec(heights)
         res = (jdaResult * max(n, 1))()
         o, st = self._opts(nms, stats)
         if isinstance(buf, np.ndarray):
             assert buf.dtype == np.uint8 and buf.flags.c_contiguous
-            base = buf.ctypes.data
-            ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[C.cast(C.c_void_p(base + int(off)), C.POINTER(C.c_ubyte)) for off in offsets])
+            _ko, ptrs = _ivec(np.asarray(offsets, np.uint64) + np.uint64(buf.ctypes.data), C.POINTER(C.c_ubyte), np.uint64)
             rc = lib.jdaDetectBatchRagged(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o), res)
         else:
             assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
-            offs = (C.c_size_t * max(n, 1))(*[int(v) for v in offsets])
+            _ko, offs = _ivec(offsets, C.c_size_t, np.uint64)
             rc = lib.jdaDetectBatchRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, scale, 0.1,
                                                 min_size, max_size, th, C.byref(o), res)
         if rc != 0:
@@ -578,19 +586,18 @@ class Cascador:
         """The same for images packed in ONE buffer (image i = buf[offsets[i] : offsets[i] + w*h]): a numpy uint8 array
         (jdaDetectBatchCppRagged) or a torch uint8 CUDA tensor (jdaDetectBatchCppRaggedDevice)."""
         n = len(offsets)
-        ws = (C.c_int * max(n, 1))(*[int(v) for v in widths])
-        hs = (C.c_int * max(n, 1))(*[int(v) for v in heights])
+        _kw, ws = _ivec(widths)
+        _kh, hs = _ivec(heights)
         res = (jdaResultD * max(n, 1))()
         st = jdaStats()
         sp = C.byref(st) if stats else None
         if isinstance(buf, np.ndarray):
             assert buf.dtype == np.uint8 and buf.flags.c_contiguous
-            base = buf.ctypes.data
-            ptrs = (C.POINTER(C.c_ubyte) * max(n, 1))(*[C.cast(C.c_void_p(base + int(off)), C.POINTER(C.c_ubyte)) for off in offsets])
+            _ko, ptrs = _ivec(np.asarray(offsets, np.uint64) + np.uint64(buf.ctypes.data), C.POINTER(C.c_ubyte), np.uint64)
             rc = lib.jdaDetectBatchCppRagged(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0, sp, res)
         else:
             assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
-            offs = (C.c_size_t * max(n, 1))(*[int(v) for v in offsets])
+            _ko, offs = _ivec(offsets, C.c_size_t, np.uint64)
             rc = lib.jdaDetectBatchCppRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, minimum_size, step,
                                                    factor, overlap, 1 if nms else 0, sp, res)
         if rc != 0:

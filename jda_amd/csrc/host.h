@@ -123,6 +123,8 @@ inline long long env_ll(const char* name, long long dflt) {
   X(ragged_chunk_windows_cpp, "JDA_RAGGED_CHUNK_WINDOWS_CPP", 8000000) /* ... of a dialect-CPP ragged batch */ \
   X(ragged_chunk_min_windows, "JDA_RAGGED_CHUNK_MIN_WINDOWS", 1500000) /* ... and at least, where a small job is cut into ragged_split chunks */ \
   X(ragged_split, "JDA_RAGGED_SPLIT", 3)    /* chunks a job smaller than that many full chunks is cut into */ \
+  X(ragged_single_windows, "JDA_RAGGED_SINGLE_WINDOWS", 5000000) /* a ragged job of at most this many windows (a rank's shard of a sharded job) runs as ONE chunk, its global-pixel launch on the lane's side stream; 0: always cut into ragged_split chunks */ \
+  X(ragged_side, "JDA_RAGGED_SIDE", 1)      /* ... (0: every launch of the single chunk on the lane's own stream) */ \
   X(ragged_lanes, "JDA_RAGGED_LANES", 3)    /* chunks of a ragged job in flight (lanes it takes), 1..8 */ \
   X(ragged_merge, "JDA_RAGGED_MERGE", -1)   /* LDS-tiled levels of a ragged chunk: one launch per occupancy class (1) or per level (0); -1: per class for dialect CPP, per level for dialect C (k_scan_p takes single-level launches) */ \
   X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \

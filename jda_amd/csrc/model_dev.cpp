@@ -122,7 +122,8 @@ bool upload_model(Cascador* c) {
   // k_finish's copy of the weight rows: every row on its own 128-byte lines (the file layout, c/jda.c:146, is what
   // k_stage and k_finish_wide stage whole carts of; a wave-per-window gather of single rows pays per line touched)
   const size_t w_rows_n = w.size() / (size_t)dim;
-  const int line_elems = 128 / (int)sizeof(Real);
+  // (w_pad = 2: rows on 64-byte boundaries -- r06 experiment: a 544-byte row is 8.5 half-lines, 576 bytes instead of 640)
+  const int line_elems = (c->kn.w_pad == 2 ? 64 : 128) / (int)sizeof(Real);
   const int w_pitch = c->kn.w_pad ? ((dim + line_elems - 1) / line_elems) * line_elems : dim;
   const bool padded = w_pitch != dim && w_rows_n * (size_t)w_pitch < (1ull << 32);      // (k_finish keeps row offsets in 32 bits)
   if (padded) sz.take<Real>(w_rows_n * (size_t)w_pitch);

@@ -405,14 +405,29 @@ struct Pass {
     const int cp_max = (int)std::max<long long>(0, std::min<long long>(256, kn().cp_max));
     const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
                      (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
+    // A job that is ONE chunk (a rank's shard of a sharded job: 4 M windows) has no other chunk's kernels next to its own,
+    // and its launches -- a few hundred to two thousand workgroups each -- do not fill the machine one after the other:
+    // the global-pixel launch is forked to the lane's side stream, next to the LDS-tiled ones (r06: the scan chain of a
+    // 356-image shard 0.78 -> 0.6 ms), like the lone lane of a uniform pass does.
+    bool side_pending = false, any_glb = false;
+    for (const RaggedChunk::Launch& l : ch.launches) any_glb = any_glb || l.mode == 2;
+    const bool fork_glb = any_glb && solo && kn().side_stream && kn().ragged_side && ch.launches.size() > 1 && busy_lanes <= kn().wide_busy_max && ln->ensure_side();
+    if (fork_glb) {       // (forked HERE, in front of the LDS-tiled launches: the side stream only waits for the images and the counters)
+      JDA_HIP(hipEventRecord(ln->ev_side[0], st));
+      JDA_HIP(hipStreamWaitEvent(ln->side, ln->ev_side[0], 0));
+    }
     for (const RaggedChunk::Launch& l : ch.launches) {
+      hipStream_t s = st;
+      if (l.mode == 2 && fork_glb) { s = ln->side; side_pending = true; }
       // (the persistent form for the levels it suits, as in a uniform pass: one workgroup per CU walks the level's tiles
       // of every image of the chunk through its slots)
-      if (l.mode == 1 && l.level >= 0 && scan_persistent(l.level, st, &l)) { rs->scan_launches++; my_scan_launches++; continue; }
+      if (l.mode == 1 && l.level >= 0 && scan_persistent(l.level, s, &l)) { rs->scan_launches++; my_scan_launches++; continue; }
       JDA_HIP(launch_scan_ragged<Real>(l.mode, l.block, false, handoff, cp_max, opts, pe->dp, m, pe->table, w, l.pix_bytes,
-                                       l.blk_base, l.blk_n, st));
+                                       l.blk_base, l.blk_n, s));
       rs->scan_launches++; my_scan_launches++;
+      if (s != st) JDA_HIP(hipEventRecord(ln->ev_side[1], s));
     }
+    if (side_pending) JDA_HIP(hipStreamWaitEvent(st, ln->ev_side[1], 0));
     if (timed) JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();
   }
@@ -660,7 +675,8 @@ struct Pass {
     overflow_runs++;
     const size_t nw = (size_t)windows();
     size_t nq = cap_q, nm = cap_m;
-    if (overflow_runs >= 3) { nq = nw; nm = nw; }
+    // (a scan that keeps a quarter of its windows or more is no cascade: the worst-case sizes at once, not in two steps)
+    if (overflow_runs >= 3 || tail * 4 > nw) { nq = nw; nm = nw; }
     else {
       const double up = tail > cap_q ? (double)tail / (double)std::max<size_t>(1, cap_q) : 1.0;   // what the truncated hand-off queue hid from the later counts
       if (tail > cap_q) nq = std::min(nw, (size_t)((double)tail * 1.25) + 64);

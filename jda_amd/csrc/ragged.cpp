@@ -543,6 +543,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   side.describe(&job);
   const int prep = ragged_prepare(c, &job);
   PlanPin pin{c, job.pe};
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: prepared at %.3f ms\n", now_ms() - t_call);
   if (prep < 0) return -1;
   if (prep > 0) return fallback();
   if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
@@ -584,13 +585,14 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     const long long full = std::max<long long>(1, std::min<long long>(chunk_windows,
                                                                       std::max<long long>(c->kn.ragged_chunk_min_windows, (total + split - 1) / split)));
     long long target = full;
+    const bool single = !helper && total <= c->kn.ragged_single_windows && n <= 65535;     // (r06: see Pass::issue_scan_ragged)
     starts.push_back(0);
     for (int i = 0; i < n; i++) {
       const long long wi = wins[(size_t)i];
       // (a job whose pixels still have to come over the link starts with a quarter and a half chunk: the GPU has work
       // after a quarter of a chunk's upload time instead of a whole one)
       if (helper) target = starts.size() == 1 ? full / 4 : (starts.size() == 2 ? full / 2 : full);
-      if (cnt > 0 && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
+      if (cnt > 0 && !single && (wsum + wi > target || cnt >= 65535)) { starts.push_back(i); wsum = 0; cnt = 0; }
       wsum += wi; cnt++;
     }
     starts.push_back(n);
@@ -725,7 +727,9 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     if (sl.busy && !collect(sl)) { ok = false; break; }
     sl.dets = RawDets<Real>(); sl.rs = RunStats(); sl.rs.timed = side.stats() != nullptr;
     Lane* ln = held.v[lane];
+    const double t_b = now_ms();
     if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
+    if (c->kn.debug_times) fprintf(stderr, "[jda] ragged chunk %d: tables built %.3f..%.3f ms (%d blocks, %d segments)\n", ci, t_b - t_call, now_ms() - t_call, sl.ch.n_blk, sl.ch.n_segs);
     if (sl.ch.windows == 0) {                        // images too small for any window
       post_ms += side.post(c, job, sl.ch, sl.dets);
       continue;
@@ -773,6 +777,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   }
   for (int i = 0; i < n; i++)
     if (!side.filled(i)) side.set_empty(i, L);     // (chunks fill every image; belt and braces)
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: done at %.3f ms (post-processing %.3f ms of it)\n", now_ms() - t_call, post_ms);
   return finish();
 }
 

@@ -10,13 +10,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from jda_amd import synth, api
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=1); ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--stages", type=int, default=7, help="T: 7 = configs[4] (W 243.7 MB, inside the 256 MB Infinity Cache); 14 = 487 MB, beyond it")
+ap.add_argument("--size", default="1920x1080")
 a = ap.parse_args()
-dims = (7, 2000, 68, 6)
-p = os.path.join(synth.cache_dir(), "x_allpass.model")
+dims = (a.stages, 2000, 68, 6)
+FW, FH = (int(v) for v in a.size.split("x"))
+p = os.path.join(synth.cache_dir(), "x_allpass.model" if a.stages == 7 else "x_allpass_T%d.model" % a.stages)
 if not os.path.exists(p):
     synth.make_model(*dims, seed=2).save(p, 4)          # cart_th = NEG_BIG: nothing is rejected
 c = api.Cascador(p, "float")
-frames = synth.make_frames(a.frames, 1920, 1080, seed=4)
+frames = synth.make_frames(a.frames, FW, FH, seed=4)
 d = torch.from_numpy(frames).cuda()
 kw = dict(th=float("inf"))
 c.detect_batch_device(d, keep_results=False, **kw)      # first pass: sparse, switches the plan to dense
@@ -30,7 +33,7 @@ win = st["patch_n"]
 carts = st["cart_total_n"]
 alg = carts * ((D - 1) * 34 + 16) + win * T * K * 2 * L * 4 + win * 2 * L * 4
 rows = win * T * K * 2 * L * 4                 # weight rows the regression gathers: K rows of 2L floats per window and stage
-print("X dims all-pass, %d frame(s) 1080p: %.1f ms per step (gpu %.1f), dense passes %d, %d windows, %.0f carts per window"
-      % (a.frames, el * 1e3, st["gpu_ms"], st["dense_passes"], win, carts / win))
+print("X dims all-pass T=%d (W %.1f MB), %d frame(s) %dx%d: %.1f ms per step (gpu %.1f), dense passes %d, %d windows, %.0f carts per window"
+      % (T, T * K * 32 * 2 * L * 4 / 1e6, a.frames, FW, FH, el * 1e3, st["gpu_ms"], st["dense_passes"], win, carts / win))
 print("  %.3e windows/s  %.3e carts/s  algorithmic bytes (SURVEY 8d, 10.2 MB per window) %.2f TB per step = %.2f TB/s = %.0f %% of the 8 TB/s HBM peak; "
-      "weight rows alone %.2f TB = %.2f TB/s" % (win / el, carts / el, alg / 1e12, alg / el / 1e12, 100 * alg / el / 8e12, rows / 1e12, rows / el / 1e12))
+      "weight rows alone %.2f TB = %.2f TB/s = %.0f %% of the peak" % (win / el, carts / el, alg / 1e12, alg / el / 1e12, 100 * alg / el / 8e12, rows / 1e12, rows / el / 1e12, 100 * rows / el / 8e12))

@@ -41,7 +41,8 @@ xd = durations(run, "k_finish")
 big = max(range(len(xs)), key=lambda i: xs[i])
 m = re.search(r"(\d+) windows", open(txt).read())
 win = int(m.group(1)) if m else 303222
-T, K, L, D = 7, 2000, 68, 6
+mt = re.search(r"all-pass T=(\d+)", open(txt).read())
+T, K, L, D = (int(mt.group(1)) if mt else 7), 2000, 68, 6
 rows = win * T * K * 2 * L * 4
 alg = win * T * K * ((D - 1) * 34 + 16) + rows + win * 2 * L * 4
 print("# tools/x_allpass.py, the k_finish dispatch that walks the stages (%d windows x %d carts):" % (win, T * K))
@@ -61,13 +62,16 @@ rd = None
 if len(sys.argv) >= 6:
     b = per_dispatch(sys.argv[5], "TCC_EA0_RDREQ_sum", "k_finish")
     rd = max(b) if b else None
-rec = {"source": "tools/sessions/r03_x.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_traffic
+rec = {"source": os.environ.get("JDA_X_SOURCE", "tools/sessions/r03_x.sh") + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
+       "kernel_sources_sha256": pmc_traffic.kernel_sources_sha256(), "stages": T, "w_bytes": T * K * 32 * 2 * L * 4,
        "windows": win, "duration_s": xd[big], "algorithmic_bytes": alg, "weight_row_bytes": rows,
        "fetch_size_bytes_as_counted": xs[big] * 1024, "gather_calibration_counted_per_useful_byte": {"w_sized_table": f[0], "1GiB_table": f[1]},
        "traffic_useful_equivalent_bytes": xs[big] * 1024 / f[0],
        "fabric_read_requests": rd, "traffic_line_bytes": (rd * 128 if rd else xs[big] * 1024 * 2),
        "note": "FETCH_SIZE tallies a 128-byte fabric request as 64 bytes on gfx950 (request count x 64 B = FETCH_SIZE, checked here); "
                "traffic_line_bytes = requests x 128 B; Infinity-Cache hits are counted, no counter separates them from HBM reads"}
-json.dump(rec, open(os.path.join(os.path.dirname(os.path.abspath(txt)), "x_allpass_traffic.json"), "w"), indent=1)
+json.dump(rec, open(os.path.join(os.path.dirname(os.path.abspath(txt)), os.environ.get("JDA_X_JSON", "x_allpass_traffic.json")), "w"), indent=1)
 print("# no rocprofv3 counter on this part separates Infinity-Cache hits from HBM reads: TCC_EA0_RDREQ_DRAM counts L2 requests routed to")
 print("# local memory, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM); the 1 GiB row shows what the same gather costs when it cannot hit.")
