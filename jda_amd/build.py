@@ -129,6 +129,8 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:      # python -m jda_amd.build --variant wpe5 JDA_SCAN_P_WAVES_PER_EU=5
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:])); sys.exit(0)
+    if "--bounds" in sys.argv:      # libjda_bounds.so: every model- / plan-derived device access checked against its extent (kernels_common.h: Bc)
+        print(_build(os.path.join(HERE, "libjda_bounds.so"), OBJDIR + "_bounds", ["-DJDA_BOUNDS_CHECK"])); sys.exit(0)
     if "--exp" in sys.argv:         # python -m jda_amd.build --exp NAME -DFLAG ...: an experiment build libjda_NAME.so (never the product)
         i = sys.argv.index("--exp")
         print(_build(os.path.join(HERE, "libjda_%s.so" % sys.argv[i + 1]), OBJDIR + "_" + sys.argv[i + 1], sys.argv[i + 2:])); sys.exit(0)

@@ -568,6 +568,24 @@ long long jdaModelStreamBytes(int T, int K, int landmark_n, int tree_depth, int 
   return model_stream_bytes(T, K, landmark_n, tree_depth, real_bytes);
 }
 
+#ifdef JDA_BOUNDS_CHECK
+namespace jda {
+void jda_bc_read_k_scan(unsigned long long*); void jda_bc_read_k_scan_d(unsigned long long*); void jda_bc_read_k_scan_r(unsigned long long*);
+void jda_bc_read_k_scan_dr(unsigned long long*); void jda_bc_read_k_scan_p(unsigned long long*); void jda_bc_read_k_finish(unsigned long long*);
+void jda_bc_read_k_wide(unsigned long long*); void jda_bc_read_k_stage(unsigned long long*);
+}
+// bounds-check build only (libjda_bounds.so): per translation unit {first violation: site << 32 | source line, violations}
+// since the last call -- out[16]; returns the total number of violations (kernels_common.h: Bc)
+__attribute__((visibility("default"))) long long jdaDebugBoundsReport(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  void (*rd[8])(unsigned long long*) = {jda_bc_read_k_scan, jda_bc_read_k_scan_d, jda_bc_read_k_scan_r, jda_bc_read_k_scan_dr,
+                                        jda_bc_read_k_scan_p, jda_bc_read_k_finish, jda_bc_read_k_wide, jda_bc_read_k_stage};
+  long long total = 0;
+  for (int i = 0; i < 8; i++) { unsigned long long v[2] = {0, 0}; rd[i](v); if (out) { out[2 * i] = v[0]; out[2 * i + 1] = v[1]; } total += (long long)v[1]; }
+  return total;
+}
+#endif
+
 #ifdef JDA_SCAN_TIMING
 // timing build only: shader-clock stamps of the k_scan workgroups of the last float pass
 __attribute__((visibility("default"))) int jdaDebugScanTiming(void* cascador, unsigned long long* out) {

@@ -56,6 +56,7 @@ __device__ __forceinline__ Stp<double> stp_calc(const double* s1, const double* 
 struct View {
   const uint8_t* img; int w, h, ox, oy;
   int pw;   // side of the patch the feature coordinates are scaled by and clamped to
+  Bc bc;    // bounds-check build: the device range the image's pixels lie in (empty otherwise)
 };
 
 // Feature of one split node for the window whose shape is sh[] (c/jda.c:370-391,
@@ -80,11 +81,15 @@ __device__ __forceinline__ int node_feature(typename DL::Node nd, const typename
     const int x1 = clamp_win(DL::coord(s1x, nd.o1x, win), win), y1 = clamp_win(DL::coord(s1y, nd.o1y, win), win);
     const int x2 = clamp_win(DL::coord(s2x, nd.o2x, win), win), y2 = clamp_win(DL::coord(s2y, nd.o2y, win), win);
     if (TILE) {
+      JDA_BC(Bc(0, (long long)tpitch * win), __umul24((unsigned)y1, (unsigned)tpitch) + (unsigned)x1, 1, kBcFinishTile);
+      JDA_BC(Bc(0, (long long)tpitch * win), __umul24((unsigned)y2, (unsigned)tpitch) + (unsigned)x2, 1, kBcFinishTile);
       const int a = tile[__umul24((unsigned)y1, (unsigned)tpitch) + (unsigned)x1];
       const int b = tile[__umul24((unsigned)y2, (unsigned)tpitch) + (unsigned)x2];
       return a - b;
     }
     // rows and widths are below 2^16: 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate)
+    JDA_BC_ADDR(v0.bc, v0.img + __umul24((unsigned)(v0.oy + y1), (unsigned)v0.w) + (unsigned)(v0.ox + x1), 1, kBcFinishPix);
+    JDA_BC_ADDR(v0.bc, v0.img + __umul24((unsigned)(v0.oy + y2), (unsigned)v0.w) + (unsigned)(v0.ox + x2), 1, kBcFinishPix);
     const int a = v0.img[__umul24((unsigned)(v0.oy + y1), (unsigned)v0.w) + (unsigned)(v0.ox + x1)];
     const int b = v0.img[__umul24((unsigned)(v0.oy + y2), (unsigned)v0.w) + (unsigned)(v0.ox + x2)];
     return a - b;
@@ -118,6 +123,9 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
   v0->img = w.img_off != nullptr ? w.frames + w.img_off[frame] : w.frames + (size_t)frame * w.frame_stride;   // ragged batch: per-image offset
   v0->w = plan->width; v0->h = plan->height; v0->ox = x; v0->oy = y;
   v0->pw = wn;
+#ifdef JDA_BOUNDS_CHECK
+  v0->bc = Bc((long long)(uintptr_t)w.bc_lo, (long long)(uintptr_t)w.bc_hi);
+#endif
   if (multi && w.patch_hs > 0) {
     // method 0 (cascador.cpp:243-245): the window's own half_size / quarter_size patches, resized from its ROI
     const DevLevel& lv = plan->lv[0];
@@ -148,7 +156,7 @@ __device__ __forceinline__ void decode_window(const DevPlan* plan, const WorkT<R
 // shifted into place (the window's first column is at any byte); a dword is only loaded when it holds at
 // least one byte of the row, so no load leaves the frame's last page.
 __device__ __forceinline__ void load_window_tile(const uint8_t* __restrict__ wbase, int W, int win, uint8_t* tile,
-                                                 int tpitch, int lane, int nthreads = 64) {
+                                                 int tpitch, int lane, int nthreads = 64, const Bc& bc = Bc()) {
   const int dpr = tpitch >> 2;
   const float inv = 1.0f / (float)dpr;
   const int total = win * dpr;
@@ -159,6 +167,14 @@ __device__ __forceinline__ void load_window_tile(const uint8_t* __restrict__ wba
     const uint8_t* p = wbase + (size_t)y * W + 4 * j;
     const unsigned sft = (unsigned)((uintptr_t)p & 3u);
     const uint32_t* q = (const uint32_t*)(p - sft);
+#ifdef JDA_BOUNDS_CHECK
+    // (aligned dwords that hold at least one byte of the row: the first may start up to 3 bytes in front of it, the last
+    // end up to 3 bytes behind it -- inside the same aligned word as a pixel of the frame, never on another page; what is
+    // checked is that every dword read OVERLAPS the frames' range)
+    if ((long long)(uintptr_t)q + 4 <= bc.lo || (long long)(uintptr_t)q >= bc.hi) jda_bc_fail(kBcWindowTileLoad, __LINE__);
+    if ((int)sft + min(4, win - 4 * j) > 4 && ((long long)(uintptr_t)(q + 1) + 4 <= bc.lo || (long long)(uintptr_t)(q + 1) >= bc.hi)) jda_bc_fail(kBcWindowTileLoad, __LINE__);
+    JDA_BC(Bc(0, (long long)tpitch * win), (long long)idx * 4, 4, kBcWindowTileLoad);
+#endif
     const uint32_t lo = q[0];
     uint32_t hi = 0;
     if ((int)sft + min(4, win - 4 * j) > 4) hi = q[1];
@@ -226,7 +242,7 @@ __device__ __forceinline__ void walk_carts(const NodeOff<typename DL::Real>* __r
 // copy in LDS (TILE) with its pitch.
 template <int G, bool TILE>
 __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, int K, const int* k, int depth, int node_n,
-                                              const uint8_t* __restrict__ pix, int pitch, int* leaf) {
+                                              const uint8_t* __restrict__ pix, int pitch, int* leaf, const Bc& bc = Bc()) {
   int node[G];
 #pragma unroll
   for (int g = 0; g < G; g++) node[g] = 0;
@@ -239,6 +255,11 @@ __device__ __forceinline__ void walk_carts_s0(const S0Node* __restrict__ tbl, in
 #pragma unroll
     for (int g = 0; g < G; g++) {
       const unsigned p1 = r[g].lo & 0x3fffffu, p2 = __builtin_amdgcn_alignbit(r[g].hi, r[g].lo, 22) & 0x3fffffu;
+#ifdef JDA_BOUNDS_CHECK
+      // bc: TILE -- indices inside the window's LDS copy; else addresses inside the frames
+      if (TILE) { JDA_BC(bc, __umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu), 1, kBcFinishTile); JDA_BC(bc, __umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu), 1, kBcFinishTile); }
+      else { JDA_BC_ADDR(bc, pix + __umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu), 1, kBcFinishPix); JDA_BC_ADDR(bc, pix + __umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu), 1, kBcFinishPix); }
+#endif
       pa[g] = pix[__umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu)];
       pb[g] = pix[__umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu)];
     }

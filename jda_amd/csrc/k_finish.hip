@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
     const bool use_tile = !MULTI && win <= tile_win;
     const int tpitch = (win + 3) & ~3;
     __syncthreads();                       // previous window's readers are done with sh (and the tile)
-    if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane);
+    if (!MULTI && use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, lane, 64, v0.bc);
     {
       const Real* src = t_begin == 0 ? m.mean_shape : w.m_shape + (size_t)i * dim;
       for (int d = lane; d < dim; d += 64) sh[d] = src[d];
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
         Real ls[kG], thk[kG], mk[kG], sk[kG];
 #pragma unroll
         for (int g = 0; g < kG; g++) kk[g] = min(k0 + g * 64 + lane, K - 1);   // clamped lanes repeat cart K-1
-        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<kG, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
-        else if (t == 0 && s0_tbl) walk_carts_s0<kG, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
+        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<kG, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf, Bc(0, (long long)tpitch * win));
+        else if (t == 0 && s0_tbl) walk_carts_s0<kG, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf, v0.bc);
         else if (!MULTI && use_tile) walk_carts<DL, kG, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch, n_deep, n_split);
         else walk_carts<DL, kG, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, nullptr, 0, n_deep, n_split);
 #pragma unroll
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       for (int k0 = 0; k0 < k_first; k0 += 128) {
         int kk[2], lf[2];
         kk[0] = min(k0 + lane, k_first - 1); kk[1] = min(k0 + 64 + lane, k_first - 1);
-        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<2, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
-        else if (t == 0 && s0_tbl) walk_carts_s0<2, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
+        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<2, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf, Bc(0, (long long)tpitch * win));
+        else if (t == 0 && s0_tbl) walk_carts_s0<2, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf, v0.bc);
         else if (!MULTI && use_tile) walk_carts<DL, 2, MULTI, ST, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, tile, tpitch, n_deep, n_split);
         else walk_carts<DL, 2, MULTI, ST>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, apply_st, lf, nullptr, 0, n_deep, n_split);
         if (k0 + lane < k_first) lbf[k0 + lane] = (uint32_t)((k0 + lane) * leaf_n + lf[0]) * (uint32_t)w_pitch;
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
           // (STREAM is a template parameter: as a run-time branch the optimiser merges the two forms of the load and
           // drops the non-temporal hint)
 #pragma unroll
-          for (int u = 0; u < 32; u++) r[u] = STREAM ? __builtin_nontemporal_load(col + lbf[k + u]) : col[lbf[k + u]];
+          for (int u = 0; u < 32; u++) { JDA_BC(Bc(0, (long long)K * leaf_n * w_pitch), (long long)lbf[k + u] + d, 1, kBcWRow); r[u] = STREAM ? __builtin_nontemporal_load(col + lbf[k + u]) : col[lbf[k + u]]; }
 #pragma unroll
           for (int u = 0; u < 32; u++) acc = acc + r[u];
         }
-        for (; k < K; k++) acc = acc + col[lbf[k]];
+        for (; k < K; k++) { JDA_BC(Bc(0, (long long)K * leaf_n * w_pitch), (long long)lbf[k] + d, 1, kBcWRow); acc = acc + col[lbf[k]]; }
         if (kCpp) {
           // stp_mc.Apply(delta, delta) (btcart.cpp:422, data.hpp:42-45) on the (dx,dy) pair held by
           // lanes d, d^1; with the identity parameter this is the literal 1*(1*x+0*y) / 1*(0*x+1*y)
@@ -269,13 +269,15 @@ namespace {
 // lm_index(K, k, d, .), so the four loads are independent of the walk and -- lanes = consecutive carts -- coalesced.
 // Only the three pixel-pair reads stay dependent: 4 memory round trips per cart instead of 6.
 __device__ __forceinline__ int walk_cart_s0_d4(const S0Node* __restrict__ tbl, unsigned K, unsigned k,
-                                               const uint8_t* __restrict__ pix, int pitch) {
+                                               const uint8_t* __restrict__ pix, int pitch, const Bc& bc = Bc()) {
   const S0Node r0 = tbl[k];
   const uint4 c1 = *(const uint4*)(tbl + K + 2u * k);                 // children of the root
   const uint4 c2a = *(const uint4*)(tbl + 3u * K + 4u * k);           // grandchildren 0, 1
   const uint4 c2b = *(const uint4*)(tbl + 3u * K + 4u * k + 2u);      // grandchildren 2, 3
   auto left = [&](uint32_t lo, uint32_t hi) {
     const unsigned p1 = lo & 0x3fffffu, p2 = __builtin_amdgcn_alignbit(hi, lo, 22) & 0x3fffffu;
+    JDA_BC_ADDR(bc, pix + __umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu), 1, kBcFinishPix);
+    JDA_BC_ADDR(bc, pix + __umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu), 1, kBcFinishPix);
     const int a = pix[__umul24(p1 >> 11, (unsigned)pitch) + (p1 & 0x7ffu)];
     const int b = pix[__umul24(p2 >> 11, (unsigned)pitch) + (p2 & 0x7ffu)];
     return a - b <= (int)((hi >> 12) & 0x3ffu) - 256;                 // c/jda.c:391-393
@@ -302,6 +304,11 @@ __global__ __launch_bounds__(256) void k_filter0(const DevPlan* __restrict__ pla
   const unsigned n = (unsigned)min(w.counters[kCntTail], (unsigned long long)w.cap_q);
   const Real* leaf_tab = m.leaf;
   const int W = plan->width;
+#ifdef JDA_BOUNDS_CHECK
+  const Bc bc_fr((long long)(uintptr_t)w.bc_lo, (long long)(uintptr_t)w.bc_hi);
+#else
+  const Bc bc_fr;
+#endif
   unsigned long long carts_acc = 0;
   const unsigned waves = gridDim.x * 4u;
   for (unsigned i0 = blockIdx.x * 4u + (unsigned)wv; i0 < n; i0 += NW * waves) {
@@ -353,8 +360,8 @@ __global__ __launch_bounds__(256) void k_filter0(const DevPlan* __restrict__ pla
         if (!go[u]) continue;
         int kk[1], l1[1];
         kk[0] = min(k0[u] + lane, K - 1);
-        if (m.D == 4) l1[0] = walk_cart_s0_d4(tbl[u], (unsigned)K, (unsigned)kk[0], wbase[u], W);
-        else walk_carts_s0<1, false>(tbl[u], K, kk, m.D, node_n, wbase[u], W, l1);
+        if (m.D == 4) l1[0] = walk_cart_s0_d4(tbl[u], (unsigned)K, (unsigned)kk[0], wbase[u], W, bc_fr);
+        else walk_carts_s0<1, false>(tbl[u], K, kk, m.D, node_n, wbase[u], W, l1, bc_fr);
         lf[u] = l1[0];
       }
 #pragma unroll
@@ -488,5 +495,7 @@ hipError_t launch_finish<double>(bool trace, int t_begin, int t_end, bool apply_
   return launch_finish_impl<DialectCPP>(trace, t_begin, t_end, apply_final_th, final_th, d_plan, m, w, groups, n_hint, s0_table, tile_win, survivors, stream);
 }
 
+
+JDA_BC_READER(k_finish)
 
 }  // namespace jda

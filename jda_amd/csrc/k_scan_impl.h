@@ -182,8 +182,14 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
   // ---- stage the pixel tile (LDS-DMA when the frame is 16-byte aligned) and the first table chunk ----
   const int W = plan->width;
   int xshift = 0;
+#ifdef JDA_BOUNDS_CHECK
+  const Bc bc_fr((long long)(uintptr_t)w.bc_lo, (long long)(uintptr_t)w.bc_hi);      // the frames' device range
+  const Bc bc_pix = GLB ? bc_fr : Bc(0, pix_bytes);                                   // what a pixel gather may touch
+#else
+  const Bc bc_fr, bc_pix;
+#endif
   if (GLB) pix = img + (size_t)y0 * W + x0;       // window origins are offsets from the tile origin in the frame
-  else xshift = load_tile<BLOCK>(lds + L.pix, w.frames, w.frame_stride, img, W, x0, y0, pw, ph, lv.pitch, tid);
+  else xshift = load_tile<BLOCK>(lds + L.pix, w.frames, w.frame_stride, img, W, x0, y0, pw, ph, lv.pitch, tid, bc_fr, Bc(0, (pix_bytes + 15) & ~15));
   auto load_tables = [&](int kb, int kc) {
     dma_to_lds<BLOCK>(lds + L.nodes, table + lv.s0_table + (size_t)kb * node_n, kc * node_n * (int)sizeof(S0Node), tid);
     dma_to_lds<BLOCK>(lds + L.leaf, m.leaf + (size_t)kb * leaf_n, kc * leaf_n * (int)sizeof(Real), tid);
@@ -316,10 +322,10 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
               if (alive) {
                 int lf[8];
                 if constexpr (RAGGED) {
-                  scan_trees<DEPTH, WIDE, 8>(t_nodes, k, node_n, pix, base, m.D, lf);
+                  scan_trees<DEPTH, WIDE, 8>(t_nodes, k, node_n, pix, base, m.D, lf, 1, 0x7fffffff, bc_pix, GLB);
                 } else {
 #pragma unroll
-                  for (int u = 0; u < 8; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+                  for (int u = 0; u < 8; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D, bc_pix, GLB) - node_n;
                 }
                 apply(std::integral_constant<int, 8>{}, k, lf, alive, score, hash, gid);
               }
@@ -330,10 +336,10 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
             if (alive) {
               int lf[4];
               if constexpr (RAGGED) {
-                scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf);
+                scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf, 1, 0x7fffffff, bc_pix, GLB);
               } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D) - node_n;
+                for (int u = 0; u < 4; u++) lf[u] = scan_tree<DEPTH, WIDE>(t_nodes + (k + u) * node_n, pix, base, m.D, bc_pix, GLB) - node_n;
               }
               apply(std::integral_constant<int, 4>{}, k, lf, alive, score, hash, gid);
             }
@@ -341,7 +347,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
           for (; k < c1; k++) {
             if (alive) {
               int lf[1];
-              lf[0] = scan_tree<DEPTH, WIDE>(t_nodes + k * node_n, pix, base, m.D) - node_n;
+              lf[0] = scan_tree<DEPTH, WIDE>(t_nodes + k * node_n, pix, base, m.D, bc_pix, GLB) - node_n;
               apply(std::integral_constant<int, 1>{}, k, lf, alive, score, hash, gid);
             }
           }
@@ -394,25 +400,25 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
             if (ka + 7 * cstride < r1) {
               int lf8[8];
               if constexpr (RAGGED) {
-                scan_trees<DEPTH, WIDE, 8>(t_nodes, ka, node_n, pix, base, m.D, lf8, cstride);
+                scan_trees<DEPTH, WIDE, 8>(t_nodes, ka, node_n, pix, base, m.D, lf8, cstride, 0x7fffffff, bc_pix, GLB);
               } else {
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                  lf8[u] = scan_tree<DEPTH, WIDE>(t_nodes + (ka + u * cstride) * node_n, pix, base, m.D) - node_n;
+                  lf8[u] = scan_tree<DEPTH, WIDE>(t_nodes + (ka + u * cstride) * node_n, pix, base, m.D, bc_pix, GLB) - node_n;
               }
 #pragma unroll
               for (int u = 0; u < 8; u++) lfbuf[item * rc + (ka + u * cstride - r0)] = (uint8_t)lf8[u];
             } else if (ka + cstride >= r1) {
-              if (ka < r1) lfbuf[item * rc + (ka - r0)] = (uint8_t)(scan_tree<DEPTH, WIDE>(t_nodes + ka * node_n, pix, base, m.D) - node_n);
+              if (ka < r1) lfbuf[item * rc + (ka - r0)] = (uint8_t)(scan_tree<DEPTH, WIDE>(t_nodes + ka * node_n, pix, base, m.D, bc_pix, GLB) - node_n);
             } else {
               for (int k = ka; k < r1; k += 4 * cstride) {
                 int lf4[4];
                 if constexpr (RAGGED) {
-                  scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf4, cstride, r1 - 1);
+                  scan_trees<DEPTH, WIDE, 4>(t_nodes, k, node_n, pix, base, m.D, lf4, cstride, r1 - 1, bc_pix, GLB);
                 } else {
 #pragma unroll
                   for (int u = 0; u < 4; u++)
-                    lf4[u] = scan_tree<DEPTH, WIDE>(t_nodes + min(k + u * cstride, r1 - 1) * node_n, pix, base, m.D) - node_n;
+                    lf4[u] = scan_tree<DEPTH, WIDE>(t_nodes + min(k + u * cstride, r1 - 1) * node_n, pix, base, m.D, bc_pix, GLB) - node_n;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
@@ -541,6 +547,7 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
       const int wy = widx / lv.tw, wx = widx - wy * lv.tw;
       const unsigned slot = gbase + i;
       if (slot < w.cap_q) {
+        JDA_BC(Bc(0, w.cap_q), slot, 1, kBcQueue);
         w.q_gid[slot] = (uint32_t)(gid0 + (wy0 + wy) * lv.nx + wx0 + wx);
         w.q_score[slot] = q_score[cur * M_MAX + i];
         w.q_kstart[slot] = (uint32_t)K;
@@ -709,6 +716,19 @@ template hipError_t launch_scan<double>(int, int, bool, int, int, int, const Dev
 #ifdef JDA_SCAN_TU_MAIN
 template hipError_t launch_scan<float>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
                                        const S0Node*, const WorkT<float>&, hipStream_t);
+#endif
+
+#ifdef JDA_SCAN_TU_MAIN
+JDA_BC_READER(k_scan)
+#endif
+#ifdef JDA_SCAN_TU_DOUBLE
+JDA_BC_READER(k_scan_d)
+#endif
+#ifdef JDA_SCAN_TU_RAGGED
+JDA_BC_READER(k_scan_r)
+#endif
+#ifdef JDA_SCAN_TU_RAGGED_DOUBLE
+JDA_BC_READER(k_scan_dr)
 #endif
 
 }  // namespace jda

@@ -114,6 +114,7 @@ __device__ __forceinline__ void dma_to_lds_rt(unsigned char* lds_dst, const void
 }
 
 struct PCtx {
+  Bc bc;                               // bounds-check build: the LDS bytes of the pixel-tile slots (empty otherwise)
   const uint8_t* lds;                  // pixels are addressed by absolute LDS offsets
   const S0Node* t_nodes; const float* t_leaf; const CartPar<float>* t_par;
   int node_n, leaf_n, D;
@@ -156,7 +157,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
       if (__ballot(alive) == 0ull) break;
       if (alive) {
         int lf[8];
-        scan_trees<DEPTH, false, 8>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf);
+        scan_trees<DEPTH, false, 8>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf, 1, 0x7fffffff, c.bc);
         p_apply<8, NORM>(c, k, lf, alive, score, my_carts);
       }
     }
@@ -165,7 +166,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
     if (__ballot(alive) == 0ull) break;
     if (alive) {
       int lf[4];
-      scan_trees<DEPTH, false, 4>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf);
+      scan_trees<DEPTH, false, 4>(c.t_nodes, k, c.node_n, c.lds, base, c.D, lf, 1, 0x7fffffff, c.bc);
       p_apply<4, NORM>(c, k, lf, alive, score, my_carts);
     }
   }
@@ -173,7 +174,7 @@ __device__ __forceinline__ void p_uni(const PCtx& c, int c0, int c1, int base, b
     if (__ballot(alive) == 0ull) break;
     if (alive) {
       int lf[1];
-      lf[0] = scan_tree<DEPTH, false>(c.t_nodes + k * c.node_n, c.lds, base, c.D) - c.node_n;
+      lf[0] = scan_tree<DEPTH, false>(c.t_nodes + k * c.node_n, c.lds, base, c.D, c.bc) - c.node_n;
       p_apply<1, NORM>(c, k, lf, alive, score, my_carts);
     }
   }
@@ -197,7 +198,7 @@ __device__ __forceinline__ void p_pair(const PCtx& c, uint8_t* lf, int lg, int c
     const int ka = r0 + 8 * grp;
     if (has_item && ((live >> item) & 1ull) && ka < r1) {
       int lf8[8];
-      scan_trees<DEPTH, false, 8>(c.t_nodes, ka, c.node_n, c.lds, base, c.D, lf8, 1, r1 - 1);
+      scan_trees<DEPTH, false, 8>(c.t_nodes, ka, c.node_n, c.lds, base, c.D, lf8, 1, r1 - 1, c.bc);
       uint2 pk;
       pk.x = (unsigned)lf8[0] | ((unsigned)lf8[1] << 8) | ((unsigned)lf8[2] << 16) | ((unsigned)lf8[3] << 24);
       pk.y = (unsigned)lf8[4] | ((unsigned)lf8[5] << 8) | ((unsigned)lf8[6] << 16) | ((unsigned)lf8[7] << 24);
@@ -364,6 +365,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
 
   PCtx c;
   c.lds = lds;
+  c.bc = Bc(L.slots, L.slots + (long long)cfg.slots * cfg.slot_bytes);
   c.t_nodes = (const S0Node*)(lds + L.nodes);
   c.t_leaf = (const float*)(lds + L.leaf);
   c.t_par = (const CartPar<float>*)(lds + L.par);
@@ -428,6 +430,7 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
       const int frame = g.z, wx0 = g.w & 0xffff, wy0 = (int)((unsigned)g.w >> 16);
       const unsigned slot = gbase + (unsigned)rank;
       if (slot < (cfg.to_mid ? w.cap_m : w.cap_q)) {
+        JDA_BC(Bc(0, cfg.to_mid ? w.cap_m : w.cap_q), slot, 1, kBcQueue);
         const uint32_t gid = RAGGED ? (uint32_t)(g2.x + (wy0 + wy) * g2.y + wx0 + wx)
                                     : (uint32_t)(frame * plan->windows + lv.base + (wy0 + wy) * lv.nx + wx0 + wx);
         const uint32_t xy = (uint32_t)((wx0 + wx) * lv.step) | ((uint32_t)((wy0 + wy) * lv.step) << 16);
@@ -588,8 +591,13 @@ void k_scan_p(const DevPlan* __restrict__ plan, DevModelT<float> m, const S0Node
             const int twe = min(tw_s, nx_s - wx0), the = min(th_s, ny_s - wy0);
             const int x0 = wx0 * lv.step, y0 = wy0 * lv.step;
             const int pw = lv.win + (twe - 1) * lv.step, ph = lv.win + (the - 1) * lv.step;
+#ifdef JDA_BOUNDS_CHECK
+            const Bc bc_fr((long long)(uintptr_t)w.bc_lo, (long long)(uintptr_t)w.bc_hi);
+#else
+            const Bc bc_fr;
+#endif
             const int xshift = load_tile<64>(lds + L.slots + s * cfg.slot_bytes, w.frames, w.frame_stride, img, W, x0, y0, pw, ph,
-                                             lv.pitch, lane);
+                                             lv.pitch, lane, bc_fr, Bc(0, cfg.slot_bytes));
             const int nbatch = (tw_s * the + 63) >> 6;
             if (lane == 0) {
               int* g = recw + 4 * (kRecGeo + s);
@@ -745,5 +753,7 @@ hipError_t launch_scan_persistent(int level, const PScanCfg& cfg, int block, int
   }
   return hipGetLastError();
 }
+
+JDA_BC_READER(k_scan_p)
 
 }  // namespace jda

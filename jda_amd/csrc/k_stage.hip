@@ -97,8 +97,13 @@ void k_stage(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
   if (__syncthreads_or(alive ? 1 : 0) == 0) return;          // nothing left to do in this tile
 
   int xshift = 0, ppitch = pitch;
+#ifdef JDA_BOUNDS_CHECK
+  const Bc bc_fr((long long)(uintptr_t)w.bc_lo, (long long)(uintptr_t)w.bc_hi);
+#else
+  const Bc bc_fr;
+#endif
   if (GLB) { pix = img + (size_t)y0 * W + x0; ppitch = W; }
-  else xshift = load_tile<BLOCK>(lds + L.pix, w.frames, w.frame_stride, img, W, x0, y0, pw, ph, pitch, tid);
+  else xshift = load_tile<BLOCK>(lds + L.pix, w.frames, w.frame_stride, img, W, x0, y0, pw, ph, pitch, tid, bc_fr, Bc(0, ((long long)pitch * ph + 15) & ~15ll));
   const int base = (wy * lv.step) * ppitch + wx * lv.step + xshift - DL::kBias * (ppitch + 1);   // pixel_pair is kBias-based
 
   // stage-start shape: LDS column for the tree walks; the regression sums start from it
@@ -161,6 +166,10 @@ void k_stage(const DevPlan* __restrict__ plan, DevModelT<typename DL::Real> m,
           int x1, y1, x2, y2;
           DL::pixel_pair(sv[g][0], sv[g][1], nd[g].o1x, nd[g].o1y, win, &x1, &y1);
           DL::pixel_pair(sv[g][2], sv[g][3], nd[g].o2x, nd[g].o2y, win, &x2, &y2);
+#ifdef JDA_BOUNDS_CHECK
+          if (GLB) { JDA_BC_ADDR(bc_fr, pix + (__umul24((unsigned)y1, (unsigned)ppitch) + (unsigned)x1 + (unsigned)base), 1, kBcStagePix); JDA_BC_ADDR(bc_fr, pix + (__umul24((unsigned)y2, (unsigned)ppitch) + (unsigned)x2 + (unsigned)base), 1, kBcStagePix); }
+          else if (valid) { JDA_BC(Bc(0, (long long)pitch * ph), __umul24((unsigned)y1, (unsigned)ppitch) + (unsigned)x1 + (unsigned)base, 1, kBcStagePix); JDA_BC(Bc(0, (long long)pitch * ph), __umul24((unsigned)y2, (unsigned)ppitch) + (unsigned)x2 + (unsigned)base, 1, kBcStagePix); }
+#endif
           pa[g] = pix[__umul24((unsigned)y1, (unsigned)ppitch) + (unsigned)x1 + (unsigned)base];   // 24-bit multiply: full rate
           pb[g] = pix[__umul24((unsigned)y2, (unsigned)ppitch) + (unsigned)x2 + (unsigned)base];
         }
@@ -320,5 +329,7 @@ size_t stage_lds_bytes(int dim, int node_n, int leaf_n, int real_bytes) {
                          : (size_t)DenseLds<double, NodeD>(0, dim, node_n, leaf_n, 4, dense_acc(dim)).total;
 }
 
+
+JDA_BC_READER(k_stage)
 
 }  // namespace jda

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
     const bool use_tile = win <= tile_win;
     const int tpitch = (win + 3) & ~3;
     __syncthreads();                               // the previous window's readers are done with LDS
-    if (use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, tid, BLOCK);
+    if (use_tile) load_window_tile(wbase, v0.w, win, tile, tpitch, tid, BLOCK, v0.bc);
     for (int d = tid; d < dim; d += BLOCK) sh[d] = m.mean_shape[d];
     __syncthreads();
     JDA_WSTAMP();
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
         const int k = k0 + tid;
         int kk[1], lf[1];
         kk[0] = min(k, K - 1);
-        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<1, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf);
-        else if (t == 0 && s0_tbl) walk_carts_s0<1, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf);
+        if (t == 0 && s0_tbl && use_tile) walk_carts_s0<1, true>(s0_tbl, K, kk, m.D, node_n, tile, tpitch, lf, Bc(0, (long long)tpitch * win));
+        else if (t == 0 && s0_tbl) walk_carts_s0<1, false>(s0_tbl, K, kk, m.D, node_n, wbase, v0.w, lf, v0.bc);
         else if (use_tile) walk_carts<DL, 1, false, false, true>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf, tile, tpitch, n_deep, n_split);
         else walk_carts<DL, 1, false, false>(n_off, n_meta, K, kk, m.D, node_n, sh, win, v0, v1, v2, stp, false, lf, nullptr, 0, n_deep, n_split);
         if (k < K) {
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
           if (K >= CH) {
             Real x[CH], y[CH];
 #pragma unroll
-            for (int q = 0; q < CH; q++) x[q] = col[lbf[q]];
+            for (int q = 0; q < CH; q++) { JDA_BC(Bc(0, (long long)K * leaf_n * dim), (long long)lbf[q] + dc, 1, kBcWRow); x[q] = col[lbf[q]]; }
             for (k = CH; k + CH <= K; k += CH) {
 #pragma unroll
-              for (int q = 0; q < CH; q++) y[q] = col[lbf[k + q]];
+              for (int q = 0; q < CH; q++) { JDA_BC(Bc(0, (long long)K * leaf_n * dim), (long long)lbf[k + q] + dc, 1, kBcWRow); y[q] = col[lbf[k + q]]; }
 #pragma unroll
               for (int q = 0; q < CH; q++) a = a + x[q];          // c/jda.c:404-411, in cart order
 #pragma unroll
@@ -267,6 +267,9 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
+              if (e + u * BLOCK < total) { JDA_BC(Bc(0, (long long)K * leaf_n * dim), off[u], 1, kBcWRow); JDA_BC(Bc(0, (long long)RC * dim), base + u * BLOCK + (tid & 63), 1, kBcWRow); }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
               if (e + u * BLOCK < total)
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + off[u]), (lds_ptr_t)((unsigned char*)rows + (size_t)(base + u * BLOCK) * 4), 4, 0, 0);
             e += 8 * BLOCK;
@@ -282,13 +285,13 @@ __global__ __launch_bounds__(BLOCK) void k_finish_wide(const DevPlan* __restrict
 #pragma unroll
             for (int u = 0; u < 8; u++) {
               rr[u] = r; ddv[u] = d;
-              if (e0 + u * BLOCK + tid < total) v[u] = wt[lbf[r0 + r] + d];
+              if (e0 + u * BLOCK + tid < total) { JDA_BC(Bc(0, (long long)K * leaf_n * dim), (long long)lbf[r0 + r] + d, 1, kBcWRow); v[u] = wt[lbf[r0 + r] + d]; }
               r += dr; d += dd;
               if (d >= dim) { d -= dim; r++; }
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
-              if (e0 + u * BLOCK + tid < total) rows[rr[u] * dim + ddv[u]] = v[u];
+              if (e0 + u * BLOCK + tid < total) { JDA_BC(Bc(0, (long long)RC * dim), rr[u] * dim + ddv[u], 1, kBcWRow); rows[rr[u] * dim + ddv[u]] = v[u]; }
           }
         }
         __syncthreads();
@@ -433,5 +436,7 @@ hipError_t launch_finish_wide<double>(bool trace, bool apply_final_th, double fi
                                       const S0Node* s0_table, hipStream_t stream, bool conc) {
   return launch_finish_wide_impl<DialectCPP>(trace, apply_final_th, final_th, d_plan, m, w, n_hint, s0_table, stream, conc);
 }
+
+JDA_BC_READER(k_wide)
 
 }  // namespace jda

@@ -180,6 +180,9 @@ struct WorkT {
 #ifdef JDA_SCAN_TIMING
   unsigned long long* dbg;                                     // [65536][16] shader-clock stamps of k_scan workgroups
 #endif
+#ifdef JDA_BOUNDS_CHECK
+  const uint8_t* bc_lo; const uint8_t* bc_hi;                  // bounds-check build: the device range [lo, hi) the pass's frames occupy
+#endif
 };
 
 // Work counters live in kCntShards copies, one 256-byte line apart, so that the

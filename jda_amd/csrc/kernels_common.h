@@ -103,6 +103,46 @@ __device__ __forceinline__ double rl(double v, int j) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- bounds-check build (`python -m jda_amd.build --bounds` -> libjda_bounds.so; never the product) ----------------------
+// The pool refuses GPU AddressSanitizer runs, and output equality cannot see a read that is in bounds by luck.  With
+// -DJDA_BOUNDS_CHECK every accessor below that computes an address from model or plan data -- tile loads, pixel gathers
+// of the scans and the finishing kernels, the stage-0 tables, the weight-row gather -- checks it against the extent of
+// what it reads (Bc: LDS tile bytes, the frames' device range, table entries) and records the first violation (site,
+// source line) and their number in a per-translation-unit device word that jdaDebugBoundsReport collects.  In the
+// product build Bc is empty and every check compiles to nothing.
+struct Bc {
+#ifdef JDA_BOUNDS_CHECK
+  long long lo = 0, hi = (1ll << 62);      // valid indices (or addresses): [lo, hi)
+  __host__ __device__ Bc() {}
+  __host__ __device__ Bc(long long lo_, long long hi_) : lo(lo_), hi(hi_) {}
+#else
+  __host__ __device__ Bc() {}
+  __host__ __device__ Bc(long long, long long) {}
+#endif
+};
+enum BcSite : int { kBcScanPixLds = 1, kBcScanPixGlb = 2, kBcTileLoad = 3, kBcFinishPix = 4, kBcFinishTile = 5, kBcWRow = 6,
+                    kBcNodeTable = 7, kBcWindowTileLoad = 8, kBcS0Table = 9, kBcStagePix = 10, kBcQueue = 11 };
+#ifdef JDA_BOUNDS_CHECK
+static __device__ unsigned long long jda_bc_word[2];      // [0] first violation: site << 32 | line; [1] violations
+__device__ __forceinline__ void jda_bc_fail(int site, int line) {
+  atomicCAS(&jda_bc_word[0], 0ull, ((unsigned long long)(unsigned)site << 32) | (unsigned)line);
+  atomicAdd(&jda_bc_word[1], 1ull);
+}
+// index (or address) i, n elements from it, inside bc?
+#define JDA_BC(bc, i, n, site) do { const long long i_ = (long long)(i); if (i_ < (bc).lo || i_ + (long long)(n) > (bc).hi) jda_bc_fail(site, __LINE__); } while (0)
+#define JDA_BC_ADDR(bc, p, n, site) JDA_BC(bc, (long long)(uintptr_t)(p), n, site)
+// one per translation unit that has device code: hands its word to abi.cpp and clears it
+#define JDA_BC_READER(tu) \
+  extern "C" void jda_bc_read_##tu(unsigned long long* out) { \
+    unsigned long long v[2] = {0, 0}, z[2] = {0, 0}; \
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(jda_bc_word), sizeof v); (void)hipMemcpyToSymbol(HIP_SYMBOL(jda_bc_word), z, sizeof z); \
+    out[0] = v[0]; out[1] = v[1]; }
+#else
+#define JDA_BC(bc, i, n, site) do { } while (0)
+#define JDA_BC_ADDR(bc, p, n, site) do { } while (0)
+#define JDA_BC_READER(tu)
+#endif
+
 // Orders this wave's LDS writes before its later LDS reads by OTHER lanes of the same wave (a wave's DS
 // operations execute in order, so no instruction is needed -- only the compiler must not move them).
 __device__ __forceinline__ void wave_lds_sync() {
@@ -157,7 +197,7 @@ __device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __res
 template <int BLOCK>
 __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* frames, size_t frame_stride,
                                          const uint8_t* img, int W, int x0, int y0, int pw, int ph, int pitch,
-                                         int tid) {
+                                         int tid, const Bc& bc_frames = Bc(), const Bc& bc_lds = Bc()) {
   constexpr int NW = BLOCK / 64;
   const int lane = tid & 63, wv = tid >> 6;
   if (((W & 15) | (int)(frame_stride & 15) | (int)(((uintptr_t)frames) & 15)) == 0) {
@@ -176,6 +216,7 @@ __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* 
     for (int base = wv * 64; base < nchunks; base += BLOCK) {
       if (i < nchunks) {
         const uint8_t* g = g0 + (size_t)row * W + (min(col, maxcol) << 4);
+        JDA_BC_ADDR(bc_frames, g, 16, kBcTileLoad); JDA_BC(bc_lds, ((long long)(base + lane)) << 4, 16, kBcTileLoad);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(lds_pix + (base << 4)), 16, 0, 0);
       }
       i += BLOCK; row += dr; col += dc;
@@ -196,9 +237,9 @@ __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* 
       for (int r0 = wv * 8; r0 < ph; r0 += NW * 8) {
         uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * w4 + c];
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) { JDA_BC_ADDR(bc_frames, &g[(size_t)(r0 + u) * w4 + c], 4, kBcTileLoad); v[u] = g[(size_t)(r0 + u) * w4 + c]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) d[(r0 + u) * p4 + c] = v[u];
+        for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) { JDA_BC(bc_lds, ((long long)(r0 + u) * p4 + c) * 4, 4, kBcTileLoad); d[(r0 + u) * p4 + c] = v[u]; }
       }
     }
     return xshift;
@@ -210,9 +251,9 @@ __device__ __forceinline__ int load_tile(unsigned char* lds_pix, const uint8_t* 
     for (int r0 = wv * 8; r0 < ph; r0 += NW * 8) {
       uint8_t v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) v[u] = g[(size_t)(r0 + u) * W + c];
+      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) { JDA_BC_ADDR(bc_frames, &g[(size_t)(r0 + u) * W + c], 1, kBcTileLoad); v[u] = g[(size_t)(r0 + u) * W + c]; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) lds_pix[(r0 + u) * pitch + c] = v[u];
+      for (int u = 0; u < 8; u++) if (cok && r0 + u < ph) { JDA_BC(bc_lds, (long long)(r0 + u) * pitch + c, 1, kBcTileLoad); lds_pix[(r0 + u) * pitch + c] = v[u]; }
     }
   }
   return 0;

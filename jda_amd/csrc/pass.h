@@ -37,6 +37,9 @@ struct Pass {
   void adopt_workspace() {
     WorkT<Real> nw = Sel<Real>::work(ln);
     nw.frames = w.frames; nw.frame_stride = w.frame_stride; nw.n_frames = w.n_frames;
+#ifdef JDA_BOUNDS_CHECK
+    nw.bc_lo = w.bc_lo; nw.bc_hi = w.bc_hi;
+#endif
     nw.half = w.half; nw.half_stride = w.half_stride; nw.hw = w.hw; nw.hh = w.hh;
     nw.quarter = w.quarter; nw.quarter_stride = w.quarter_stride; nw.qw = w.qw; nw.qh = w.qh;
     nw.patch_hs = w.patch_hs; nw.patch_qs = w.patch_qs;
@@ -397,6 +400,9 @@ struct Pass {
     }
     JDA_HIP(launch_repack(raw, (uint8_t*)ln->rag_frames.p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
     w.frames = (const uint8_t*)ln->rag_frames.p; w.frame_stride = 0; w.n_frames = ch.n;
+#ifdef JDA_BOUNDS_CHECK
+    w.bc_lo = w.frames; w.bc_hi = w.frames + ch.frame_bytes;       // (bounds-check build: the staged images of the chunk)
+#endif
     w.segs = (const RagSeg*)(tab + ch.off_segs); w.blk = (const RagBlk*)(tab + ch.off_blk);
     w.img_off = (const unsigned long long*)(tab + ch.off_imgoff);
     if (!clear_counters()) return false;

@@ -173,6 +173,12 @@ bool run_device_impl(Cascador* c, LaneSet& lanes_held, PlanEntry* pe, const uint
       p.cap = cap;
       p.f0 = f0; p.nf = std::min<int>((int)fpp, n - f0);
       p.w.frames = d_frames + (size_t)f0 * stride; p.w.frame_stride = stride; p.w.n_frames = p.nf;
+#ifdef JDA_BOUNDS_CHECK
+      // (bounds-check build: the bytes the caller vouches for -- n frames `stride` apart, the last one width x height)
+      // (JDA_BOUNDS_TEST_SHRINK: the checker's own negative control -- with the range cut short it MUST report)
+      static const long long bc_shrink = env_ll("JDA_BOUNDS_TEST_SHRINK", 0);
+      p.w.bc_lo = d_frames; p.w.bc_hi = d_frames + (size_t)(n - 1) * stride + (size_t)pe->sp.width * pe->sp.height - bc_shrink;
+#endif
       if (host_frames) { p.host_frames = host_frames + f0; p.host_fbytes = host_fbytes; }
       p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
       p.w.hw = hw; p.w.hh = hh; p.w.qw = qw; p.w.qh = qh;

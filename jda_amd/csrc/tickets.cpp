@@ -67,6 +67,9 @@ int submit_c_device(Cascador* c, const uint8_t* d_frames, size_t stride, int n, 
   p.bind(ln, 0, nullptr);
   p.f0 = 0; p.nf = n;
   p.w.frames = d_frames; p.w.frame_stride = stride; p.w.n_frames = n;
+#ifdef JDA_BOUNDS_CHECK
+  p.w.bc_lo = d_frames; p.w.bc_hi = d_frames + (size_t)(n - 1) * stride + (size_t)width * height;
+#endif
   p.w.half = nullptr; p.w.quarter = nullptr; p.w.half_stride = p.w.quarter_stride = 0;
   p.w.hw = p.w.hh = p.w.qw = p.w.qh = 0;
   if (host_frames) {
