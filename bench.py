@@ -612,17 +612,20 @@ def main():
 
                     def shard_job():
                         return casc.detect_ragged_packed(d_sub, so, ws[a:b], hs[a:b], stats=True, keep_results="packed", frame_offset=a, **kw)
-                    shard_job()
-                    nrep = max(2, reps)
-                    t1 = time.perf_counter()
+                    shard_job(); shard_job()
+                    nrep = max(3, reps)
+                    ts = []
                     for _ in range(nrep):
+                        t1 = time.perf_counter()
                         shard_job()
-                    mean = (time.perf_counter() - t1) / nrep
-                    per.append(mean); worst = max(worst, mean)
-                pred[str(nn)] = {"max_shard_ms": worst * 1e3, "min_shard_ms": min(per) * 1e3, "speedup": t_full / worst}
+                        ts.append(time.perf_counter() - t1)
+                    med = float(np.median(ts))          # (the median of the runs: one descheduled host thread does not define a shard)
+                    per.append(med); worst = max(worst, med)
+                pred[str(nn)] = {"max_shard_ms": worst * 1e3, "min_shard_ms": min(per) * 1e3, "speedup": t_full / worst,
+                                 "shard_ms": [round(t * 1e3, 4) for t in per]}
             info["predicted_strong_scaling"] = pred
-            info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (mean of %d runs, like ms_per_job); speedup = "
-                                                     "mean ms_per_job / slowest shard's mean; not a multi-GPU measurement" % max(2, reps))
+            info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (median of %d runs after two warm-ups); speedup = "
+                                                     "mean ms_per_job / slowest shard's median; not a multi-GPU measurement" % max(3, reps))
         casc.close()
         return info
 

@@ -71,63 +71,33 @@ inline long long env_ll(const char* name, long long dflt) {
 // afterwards.  Nothing on the call path touches the environment.
 #define JDA_KNOBS(X)                                                                                   \
   X(handoff, "JDA_HANDOFF", 128)            /* carts of stage 0 k_scan evaluates before k_finish takes over */ \
-  X(first_phase, "JDA_FIRST_PHASE", 16)     /* carts before k_scan's first compaction */                \
-  X(cp_max, "JDA_CP_MAX", 128)              /* windows per tile at or below which a phase spreads (window, cart) pairs */ \
-  X(lds_win_max, "JDA_LDS_WIN_MAX", 100)    /* largest window that gets an LDS pixel tile */            \
-  X(tile_cglb, "JDA_TILE_CGLB", 800)        /* cost per window of the global-pixel mode (tile chooser) */ \
-  X(glb_tile_fit, "JDA_GLB_TILE_FIT", 1)                                                               \
-  X(no_global_scan, "JDA_NO_GLOBAL_SCAN", 0)                                                           \
-  X(no_lds_scan, "JDA_NO_LDS_SCAN", 0)                                                                 \
   X(no_fast_scan, "JDA_NO_FAST_SCAN", 0)                                                               \
-  X(debug_tiles, "JDA_DEBUG_TILES", 0)                                                                 \
   X(plan_cache, "JDA_PLAN_CACHE", 64)       /* scan plans kept per cascador */                          \
-  X(fin_s0, "JDA_FIN_S0", 1)                                                                           \
   X(dense, "JDA_DENSE", 1)                  /* 0 off, 1 auto, 2 always */                              \
-  X(dense_lds_max, "JDA_DENSE_LDS_MAX", 160 * 1024)                                                    \
-  X(dense_pix, "JDA_DENSE_PIX", 16 * 1024)                                                             \
-  X(dense_pct, "JDA_DENSE_PCT", 50)                                                                    \
   X(merge_blocks, "JDA_MERGE_BLOCKS", 2048) /* workgroups below which the LDS-tiled levels share one launch */ \
   X(side_small, "JDA_SIDE_SMALL", 1)                                                                   \
   X(side_stream, "JDA_SIDE_STREAM", 1)                                                                 \
-  X(side_after, "JDA_SIDE_AFTER", 0)        /* ... forked after this many LDS-tiled launches have been queued (the persistent scan takes its CUs first, the global-pixel workgroups fill what it leaves) */ \
-  X(lanes_reverse, "JDA_LANES_REVERSE", 1)                                                             \
-  X(finish_merge, "JDA_FINISH_MERGE", 4096) /* hand-off count below which one k_finish launch does all stages */ \
   X(wide_max, "JDA_WIDE_MAX", 1024)         /* ... and below which a window gets a whole workgroup (k_finish_wide) */ \
-  X(wide_busy_max, "JDA_WIDE_BUSY_MAX", 2)  /* ... unless more than this many lanes of the cascador are in use */ \
   X(wide_conc, "JDA_WIDE_CONC", 1)          /* ... in which a stage's score replay (wave 0) and its regression (waves 1..) run side by side (0: one after the other, rows through LDS) */ \
   X(h2d_stream, "JDA_H2D_STREAM", 1)        /* host frames go up on ONE stream per cascador, batch after batch, not lane by lane */ \
   X(h2d_min_bytes, "JDA_H2D_MIN_BYTES", 8 << 20) /* ... for uploads of at least this many bytes */ \
-  X(ragged_uploader, "JDA_RAGGED_UPLOADER", 1) /* ragged job from one packed host buffer: a helper thread uploads chunk after chunk */ \
-  X(ragged_stage_threads, "JDA_RAGGED_STAGE_THREADS", 4) /* ... and this many threads gather separate host arrays into its pinned buffers */ \
   X(kernel_d2h, "JDA_KERNEL_D2H", 1)        /* counters and detections -> pinned host memory by a kernel, not the copy engine */ \
   X(filter0, "JDA_FILTER0", 1)              /* large hand-off queues: k_filter0 + k_finish(survivors) instead of two k_finish passes */ \
-  X(fin_gm, "JDA_FIN_GM", 0)                /* speculative 64-cart groups per k_finish round (0: from K) */ \
-  X(fin_g1, "JDA_FIN_G1", 1)                                                                           \
-  X(fin_g2, "JDA_FIN_G2", 0)                                                                           \
-  X(fin_tile, "JDA_FIN_TILE", -1)           /* k_finish LDS window tile: -1 auto, 0 off, n pixels */    \
-  X(fin_tile1, "JDA_FIN_TILE1", 0)                                                                     \
-  X(fin_grid_div, "JDA_FIN_GRID_DIV", 4)                                                               \
   X(predict, "JDA_PREDICT", 1)              /* size the finishing launches from the previous pass (no host round trip) */ \
   X(debug_times, "JDA_DEBUG_TIMES", 0)                                                                 \
   X(test_wpf_scale, "JDA_TEST_WPF_SCALE", 1) /* test hook of the 32-bit window-id guard */             \
   X(test_throw, "JDA_TEST_THROW", 0)        /* test hook of the C ABI's exception barrier (abi.cpp): 1 = std::bad_alloc, 2 = std::runtime_error inside jdaDetectBatch */ \
   X(lanes, "JDA_LANES", 2)                  /* sub-batch lanes of one synchronous call */               \
   X(lanes_min_windows, "JDA_LANES_MIN_WINDOWS", 2000000)                                               \
-  X(host_chunk, "JDA_HOST_CHUNK", 128)      /* frames per sub-batch when the frames come from host memory */ \
   X(workspace_mb, "JDA_WORKSPACE_MB", 24 * 1024)                                                       \
   X(ws_bound, "JDA_WS_BOUND", 1)            /* queues of a pass sized from the fractions earlier passes left in them (0: for the worst case, every window in every queue) */ \
   X(ws_factor_pct, "JDA_WS_FACTOR_PCT", 400) /* ... times this safety factor, in percent */ \
   X(ws_min_entries, "JDA_WS_MIN_ENTRIES", 65536) /* ... and never fewer entries than this */ \
-  X(host_submit_thread, "JDA_HOST_SUBMIT_THREAD", 1)                                                   \
   X(ragged_chunk_windows, "JDA_RAGGED_CHUNK_WINDOWS", 4000000) /* windows per chunk of a ragged batch at most */ \
   X(ragged_chunk_windows_cpp, "JDA_RAGGED_CHUNK_WINDOWS_CPP", 8000000) /* ... of a dialect-CPP ragged batch */ \
   X(ragged_chunk_min_windows, "JDA_RAGGED_CHUNK_MIN_WINDOWS", 1500000) /* ... and at least, where a small job is cut into ragged_split chunks */ \
   X(ragged_split, "JDA_RAGGED_SPLIT", 3)    /* chunks a job smaller than that many full chunks is cut into */ \
   X(ragged_single_windows, "JDA_RAGGED_SINGLE_WINDOWS", 5000000) /* a ragged job of at most this many windows (a rank's shard of a sharded job) runs as ONE chunk, its global-pixel launch on the lane's side stream; 0: always cut into ragged_split chunks */ \
-  X(ragged_side, "JDA_RAGGED_SIDE", 1)      /* ... (0: every launch of the single chunk on the lane's own stream) */ \
-  X(ragged_lanes, "JDA_RAGGED_LANES", 3)    /* chunks of a ragged job in flight (lanes it takes), 1..8 */ \
-  X(ragged_merge, "JDA_RAGGED_MERGE", -1)   /* LDS-tiled levels of a ragged chunk: one launch per occupancy class (1) or per level (0); -1: per class for dialect CPP, per level for dialect C (k_scan_p takes single-level launches) */ \
-  X(ragged_tile_grow_pct, "JDA_RAGGED_TILE_GROW_PCT", 150)      /* pixel bytes of a re-cut tile, % of the level's nominal tile */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
   X(device_post, "JDA_DEVICE_POST", 1)      /* per-frame sort, NMS and relocation of a dialect-C batch on the device (k_post) instead of on the host (0): synchronous batch calls and tickets */ \
@@ -135,12 +105,9 @@ inline long long env_ll(const char* name, long long dflt) {
   X(w_pad, "JDA_W_PAD", 1)                  /* k_finish gathers its weight rows from a copy whose rows start on 128-byte lines (0: from the tight table) */ \
   X(lm_deep, "JDA_LM_DEEP", 1)              /* trees of five or more node levels: k_finish reads the levels from the fourth on as whole records grouped per path (0: every level from the level-major split copy) */ \
   X(w_stream_mb, "JDA_W_STREAM_MB", 8)      /* ... with non-temporal loads when one stage's rows exceed this many MB (they would only push the stage's nodes out of L2); 0: never */ \
-  X(scan_lean, "JDA_SCAN_LEAN", 1)          /* scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises */ \
   X(scan_p, "JDA_SCAN_P", 1)                /* persistent scan kernel (k_scan_p): 0 off, 1 for the levels of large uniform batches it suits, 2 whenever it fits */ \
   X(scan_p_ragged, "JDA_SCAN_P_RAGGED", 1)  /* ... also for the single-level launches of a ragged chunk (tiles from the chunk's block map, re-cut per image) */ \
   X(scan_p_block, "JDA_SCAN_P_BLOCK", 768)  /* ... threads per workgroup */                             \
-  X(scan_p_min_slots, "JDA_SCAN_P_MIN_SLOTS", 4) /* ... pixel-tile slots a level's workgroup must have room for (scan_p = 1) */ \
-  X(scan_p_wgs, "JDA_SCAN_P_WGS", 1)        /* ... workgroups per CU */                                 \
   X(scan_p_slots, "JDA_SCAN_P_SLOTS", 5)    /* ... pixel-tile slots per workgroup at most while other batches are in flight on the cascador (0: as many as fit, at most 8).  Five, not the six the 46-pixel level has room for: the 28 KB left per CU let workgroups of the other batch run next to it (submit/wait step 1.495 -> 1.45 ms) */ \
   X(scan_p_b0, "JDA_SCAN_P_B0", 32)         /* ... cart counts at which windows are re-bucketed */       \
   X(scan_p_b1, "JDA_SCAN_P_B1", 64)                                                                    \
@@ -152,13 +119,49 @@ inline long long env_ll(const char* name, long long dflt) {
   X(scan_p_lg, "JDA_SCAN_P_LG", 64)         /* ... task form per bucket, one decimal digit each: 6 lane = window, 5 / 4 / 7 / 8 pair tasks of 32 / 16 / 8 / 4 windows, 9 a pair task of 1 to 4 windows taken as soon as one waits */ \
   X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */ \
   X(scan_p_tile_kb, "JDA_SCAN_P_TILE_KB", 0) /* ... its own cut of a level's tile in y: as many rows of windows as keep the pixel tile within this many KB (0: the plan's tile) */ \
-  X(scan_p_lds_kb, "JDA_SCAN_P_LDS_KB", 160) /* ... LDS a workgroup may take: what it leaves of the CU's 160 KB is where the other batch's kernels (global-pixel scan: 23.1 KB per workgroup, k_finish: 7.5 KB) find room next to it */ \
-  X(scan_p_win_max, "JDA_SCAN_P_WIN_MAX", 100000) /* ... largest window of a level it takes */ \
-  X(scan_p_dyn, "JDA_SCAN_P_DYN", 1)        /* ... tiles dealt to the workgroups at run time (a workgroup that starts late takes fewer) instead of in fixed shares */ \
   X(scan_p_grid, "JDA_SCAN_P_GRID", 0)      /* ... workgroups of a launch (0: one per CU x scan_p_wgs) */ \
   X(scan_p_mid, "JDA_SCAN_P_MID", 1)        /* ... with scan_p_handoff >= K: windows that pass stage 0 go straight to the mid queue */
 
 struct Knobs {
+  // ---- former options, fixed at their measured values (r06 pruning): every A/B behind them is recorded as decided in
+  //      profiles/DEAD_ENDS.md / DESIGN.md; they are compile-time constants now -- not settable, not read from the
+  //      environment, the branches for other values fold away -- and keep their names where the code reads them ----
+  static constexpr long long first_phase = 16;   // carts before k_scan's first compaction
+  static constexpr long long cp_max = 128;   // windows per tile at or below which a phase spreads (window, cart) pairs
+  static constexpr long long lds_win_max = 100;   // largest window that gets an LDS pixel tile
+  static constexpr long long tile_cglb = 800;   // cost per window of the global-pixel mode (tile chooser)
+  static constexpr long long glb_tile_fit = 1;
+  static constexpr long long no_global_scan = 0;
+  static constexpr long long no_lds_scan = 0;
+  static constexpr long long debug_tiles = 0;
+  static constexpr long long fin_s0 = 1;
+  static constexpr long long dense_lds_max = 160 * 1024;
+  static constexpr long long dense_pix = 16 * 1024;
+  static constexpr long long dense_pct = 50;
+  static constexpr long long side_after = 0;   // ... forked after this many LDS-tiled launches have been queued (the persistent scan takes its CUs first, the global-pixel workgroups fill what it leaves)
+  static constexpr long long lanes_reverse = 1;
+  static constexpr long long finish_merge = 4096;   // hand-off count below which one k_finish launch does all stages
+  static constexpr long long wide_busy_max = 2;   // ... unless more than this many lanes of the cascador are in use
+  static constexpr long long ragged_uploader = 1;   // ragged job from one packed host buffer: a helper thread uploads chunk after chunk
+  static constexpr long long ragged_stage_threads = 4;   // ... and this many threads gather separate host arrays into its pinned buffers
+  static constexpr long long fin_gm = 0;   // speculative 64-cart groups per k_finish round (0: from K)
+  static constexpr long long fin_g1 = 1;
+  static constexpr long long fin_g2 = 0;
+  static constexpr long long fin_tile = -1;   // k_finish LDS window tile: -1 auto, 0 off, n pixels
+  static constexpr long long fin_tile1 = 0;
+  static constexpr long long fin_grid_div = 4;
+  static constexpr long long host_chunk = 128;   // frames per sub-batch when the frames come from host memory
+  static constexpr long long host_submit_thread = 1;
+  static constexpr long long ragged_side = 1;   // ... (0: every launch of the single chunk on the lane's own stream)
+  static constexpr long long ragged_lanes = 3;   // chunks of a ragged job in flight (lanes it takes), 1..8
+  static constexpr long long ragged_merge = -1;   // LDS-tiled levels of a ragged chunk: one launch per occupancy class (1) or per level (0); -1: per class for dialect CPP, per level for dialect C (k_scan_p takes single-level launches)
+  static constexpr long long ragged_tile_grow_pct = 150;   // pixel bytes of a re-cut tile, % of the level's nominal tile
+  static constexpr long long scan_lean = 1;   // scan kernels without the per-cart test of the normalisation flag where no cart of the scanned range normalises
+  static constexpr long long scan_p_min_slots = 4;   // ... pixel-tile slots a level's workgroup must have room for (scan_p = 1)
+  static constexpr long long scan_p_wgs = 1;   // ... workgroups per CU
+  static constexpr long long scan_p_lds_kb = 160;   // ... LDS a workgroup may take: what it leaves of the CU's 160 KB is where the other batch's kernels (global-pixel scan: 23.1 KB per workgroup, k_finish: 7.5 KB) find room next to it
+  static constexpr long long scan_p_win_max = 100000;   // ... largest window of a level it takes
+  static constexpr long long scan_p_dyn = 1;   // ... tiles dealt to the workgroups at run time (a workgroup that starts late takes fewer) instead of in fixed shares
 #define X(name, env, dflt) long long name = (dflt);
   JDA_KNOBS(X)
 #undef X
@@ -170,9 +173,10 @@ struct Knobs {
   // Values no code path can work with are refused (jdaSetOption returns -1): negative sizes and counts; the rest of
   // a knob's range is clamped where it is used.
   bool set(const char* key, long long v) {
-    static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "host_chunk", "ragged_chunk_windows", "ragged_chunk_windows_cpp",
-                                               "ragged_chunk_min_windows", "h2d_min_bytes", "merge_blocks", "finish_merge", "wide_max", "lanes_min_windows",
-                                               "ragged_stage_threads", "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls", "scan_p_tile_kb", "scan_p_grid"};
+    static const char* const non_negative[] = {"workspace_mb", "handoff", "plan_cache", "lanes", "ragged_chunk_windows", "ragged_chunk_windows_cpp",
+                                               "ragged_chunk_min_windows", "h2d_min_bytes", "merge_blocks", "wide_max", "lanes_min_windows", "ragged_single_windows",
+                                               "scan_p_handoff", "scan_p_slots", "max_lanes", "lane_idle_calls", "scan_p_tile_kb", "scan_p_grid",
+                                               "ws_min_entries", "ws_factor_pct"};
     for (const char* k : non_negative) if (std::strcmp(key, k) == 0 && v < 0) return false;
     if (std::strcmp(key, "workspace_mb") == 0 && v < 1) return false;
 #define X(name, env, dflt) if (std::strcmp(key, #name) == 0) { name = v; return true; }
@@ -341,6 +345,8 @@ struct Lane {
   }
   bool ensure_side() {
     if (side) return true;
+    // (a side stream of another PRIORITY -- a hardware queue of its own -- was tried in r06: the headline lost 8 %,
+    // 1.41 -> 1.53 ms per step, the shard job gained nothing: profiles/DEAD_ENDS.md)
     JDA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     for (auto& e : ev_side) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return true;

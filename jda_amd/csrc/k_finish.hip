@@ -4,6 +4,10 @@
 // btcart.cpp:407-424), final cut (c/jda.c:414) and emit.
 #include "finish_common.h"
 
+#ifndef FIN_ROW_BATCH
+#define FIN_ROW_BATCH 0        // (experiment builds: -DFIN_ROW_BATCH=n forces the regression's row batch)
+#endif
+
 namespace jda {
 
 // =============================================================================
@@ -183,14 +187,19 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
 #ifdef JDA_EXP_NOREG
         k = K;      // (experiment build, never the product: how long do the walks alone take?)
 #endif
-        for (; k + 32 <= K; k += 32) {          // 32 row loads in flight, then 32 ordered adds
-          Real r[32];
+        // RB row loads in flight, then RB ordered adds.  A window's stage is a chain of K / RB such round trips to L2 --
+        // the longest part of its latency when few windows are in flight (a rank's shard, a single frame).  fp32: 64 (the
+        // registers are there: 16 one-wave workgroups per CU is the LDS limit, 4 waves per SIMD); fp64, whose rows are two
+        // registers per element: 32.
+        constexpr int RB = FIN_ROW_BATCH > 0 ? FIN_ROW_BATCH : (kCpp ? 32 : 64);
+        for (; k + RB <= K; k += RB) {
+          Real r[RB];
           // (STREAM is a template parameter: as a run-time branch the optimiser merges the two forms of the load and
           // drops the non-temporal hint)
 #pragma unroll
-          for (int u = 0; u < 32; u++) { JDA_BC(Bc(0, (long long)K * leaf_n * w_pitch), (long long)lbf[k + u] + d, 1, kBcWRow); r[u] = STREAM ? __builtin_nontemporal_load(col + lbf[k + u]) : col[lbf[k + u]]; }
+          for (int u = 0; u < RB; u++) { JDA_BC(Bc(0, (long long)K * leaf_n * w_pitch), (long long)lbf[k + u] + d, 1, kBcWRow); r[u] = STREAM ? __builtin_nontemporal_load(col + lbf[k + u]) : col[lbf[k + u]]; }
 #pragma unroll
-          for (int u = 0; u < 32; u++) acc = acc + r[u];
+          for (int u = 0; u < RB; u++) acc = acc + r[u];
         }
         for (; k < K; k++) { JDA_BC(Bc(0, (long long)K * leaf_n * w_pitch), (long long)lbf[k] + d, 1, kBcWRow); acc = acc + col[lbf[k]]; }
         if (kCpp) {

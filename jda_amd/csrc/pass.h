@@ -422,17 +422,32 @@ struct Pass {
       JDA_HIP(hipEventRecord(ln->ev_side[0], st));
       JDA_HIP(hipStreamWaitEvent(ln->side, ln->ev_side[0], 0));
     }
-    for (const RaggedChunk::Launch& l : ch.launches) {
-      hipStream_t s = st;
-      if (l.mode == 2 && fork_glb) { s = ln->side; side_pending = true; }
+    // (ragged_side = 2: the closed-tile LDS launches -- the levels the persistent kernel declines -- follow the global-pixel
+    // launch on the side stream, so that the lane's own stream carries the persistent launches only)
+    auto issue = [&](const RaggedChunk::Launch& l, hipStream_t s, bool try_persistent) -> bool {
       // (the persistent form for the levels it suits, as in a uniform pass: one workgroup per CU walks the level's tiles
       // of every image of the chunk through its slots)
-      if (l.mode == 1 && l.level >= 0 && scan_persistent(l.level, s, &l)) { rs->scan_launches++; my_scan_launches++; continue; }
+      if (try_persistent && l.mode == 1 && l.level >= 0 && scan_persistent(l.level, s, &l)) { rs->scan_launches++; my_scan_launches++; return true; }
       JDA_HIP(launch_scan_ragged<Real>(l.mode, l.block, false, handoff, cp_max, opts, pe->dp, m, pe->table, w, l.pix_bytes,
                                        l.blk_base, l.blk_n, s));
       rs->scan_launches++; my_scan_launches++;
-      if (s != st) JDA_HIP(hipEventRecord(ln->ev_side[1], s));
+      return true;
+    };
+    if (fork_glb) {
+      for (const RaggedChunk::Launch& l : ch.launches)
+        if (l.mode == 2) { if (!issue(l, ln->side, false)) return false; side_pending = true; }
     }
+    for (const RaggedChunk::Launch& l : ch.launches) {
+      if (l.mode == 2 && fork_glb) continue;
+      if (fork_glb && kn().ragged_side == 2 && l.mode != 2) {
+        // would the persistent kernel take it?  (asked by trying: a declined level costs nothing)
+        if (l.mode == 1 && l.level >= 0 && scan_persistent(l.level, st, &l)) { rs->scan_launches++; my_scan_launches++; continue; }
+        if (!issue(l, ln->side, false)) return false;
+        continue;
+      }
+      if (!issue(l, st, true)) return false;
+    }
+    if (side_pending) JDA_HIP(hipEventRecord(ln->ev_side[1], ln->side));
     if (side_pending) JDA_HIP(hipStreamWaitEvent(st, ln->ev_side[1], 0));
     if (timed) JDA_HIP(hipEventRecord(ev[2], st));
     return issue_rest();

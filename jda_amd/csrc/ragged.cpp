@@ -75,6 +75,7 @@ static int ragged_prepare(Cascador* c, RaggedJob* job) {
       sx[l] += (job->widths[i] - lv.win) / lv.step + 1; sy[l] += (job->heights[i] - lv.win) / lv.step + 1; cnt[l]++;
     }
   }
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged prepare: levels of %d images counted\n", job->n);
   unsigned long long h = 1469598103934665603ull;
   for (int l = 0; l < nl; l++) {
     Level& lv = job->levels.levels[l];
@@ -511,6 +512,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     std::lock_guard<std::mutex> lk(c->mu);
     if (!ensure_device(c) || !upload_model<Real>(c)) return -1;
   }
+  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: device and model ready at %.3f ms\n", now_ms() - t_call);
   RunStats total;
   long long patch_n = 0;
   double post_ms = 0;

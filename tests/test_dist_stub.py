@@ -146,8 +146,8 @@ def test_bench_two_ranks_with_the_c_gather_in_the_loop():
     env = dict(os.environ, LD_PRELOAD=stub, JDA_BENCH_BACKEND="gloo", JDA_BENCH_ONE_GPU="1", JDA_BENCH_C_GATHER_ON_GLOO="1", JDA_DENSE="1")
     env.pop("JDA_BENCH_GATHER", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32",
-           "--no-cpu", "--no-allpass", "--no-config2"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--no-allpass", "--no-config2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -158,3 +158,9 @@ def test_bench_two_ranks_with_the_c_gather_in_the_loop():
     assert cfg["dist_selftest"].startswith("ok"), cfg["dist_selftest"]
     assert d["regimes"]["cascade"]["detections_after_nms"] > 0 and cfg["fddb_images_per_s"] > 0
     assert "falling back" not in out.stderr, out.stderr[-2000:]
+    # r06: an N-rank line carries what the one-GPU line carries -- the CPU baseline (rank 0, after the timed regions), the
+    # parity verdict on the last timed call of every leg, the dialect-CPP legs (the FDDB one sharded over the ranks)
+    assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port"), d["cpu_baseline"]
+    assert cfg["parity_checked"] in ("reference", "port"), (cfg["parity_checked"], d.get("parity"))
+    assert all(cfg["parity_legs"].values()) and {"headline", "fddb", "cpp", "fddb_cpp"} <= set(cfg["parity_legs"]), cfg["parity_legs"]
+    assert cfg["cpp_windows_per_s"] > 0 and cfg["fddb_cpp_images_per_s"] > 0 and cfg["host_frames_windows_per_s"] > 0

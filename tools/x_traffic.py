@@ -64,7 +64,7 @@ if len(sys.argv) >= 6:
     rd = max(b) if b else None
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pmc_traffic
-rec = {"source": os.environ.get("JDA_X_SOURCE", "tools/sessions/r03_x.sh") + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
+rec = {"source": os.environ.get("JDA_X_SOURCE", "tools/sessions/ARCHIVE_r02_r04.txt (r03_x.sh)") + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (and TCC_EA0_RDREQ_sum) -- python tools/x_allpass.py; calibration tools/pmc_calib.py gather",
        "kernel_sources_sha256": pmc_traffic.kernel_sources_sha256(), "stages": T, "w_bytes": T * K * 32 * 2 * L * 4,
        "windows": win, "duration_s": xd[big], "algorithmic_bytes": alg, "weight_row_bytes": rows,
        "fetch_size_bytes_as_counted": xs[big] * 1024, "gather_calibration_counted_per_useful_byte": {"w_sized_table": f[0], "1GiB_table": f[1]},
