@@ -466,7 +466,7 @@ def test_dialect_cpp_shipped_config(built, gpu, model_file):
 
 DIFF_KERNELS = {  # which finishing kernel a traced pass runs (options of DESIGN.md section 8; none changes results)
     "k_finish": dict(dense=0, wide_max=0),
-    "k_finish_wide": dict(dense=0, wide_max=10_000_000, wide_busy_max=64),
+    "k_finish_wide": dict(dense=0, wide_max=10_000_000),
     "k_stage": dict(dense=2),
 }
 
