@@ -545,14 +545,21 @@ def main():
         for _ in range(n_img):
             long_side = int(rng.integers(300, 451)); short = int(rng.integers(225, long_side + 1))
             sizes.append((long_side, short) if rng.random() < 0.5 else (short, long_side))
-        lo, hi = jdist.shard_range(n_img, rank, world)
+        # contiguous blocks of about equal WORK: an image weighs its candidate windows (c/jda.c:320-339 via jdaCountWindows);
+        # every rank computes the same boundaries (jda_amd/dist.py:shard_range_weighted)
+        weights = np.array([api.count_windows(w_, h_, call["scale"], call["min_size"], call["max_size"])[0] for (w_, h_) in sizes], np.float64)
+        private["fddb_weights"] = weights
+        lo, hi = jdist.shard_range_weighted(weights, rank, world)
         base = synth.make_frames(64, 450, 450, seed=7)          # images = crops of 64 synthetic 450x450 frames
         imgs = [np.ascontiguousarray(base[i % 64][:sizes[i][1], :sizes[i][0]]) for i in range(lo, hi)]
         offs, tot = [], 0
         for im in imgs:
             offs.append(tot); tot += im.size
         buf = np.concatenate([im.reshape(-1) for im in imgs]) if imgs else np.zeros(0, np.uint8)
-        ws, hs = [sizes[i][0] for i in range(lo, hi)], [sizes[i][1] for i in range(lo, hi)]
+        # (the job description as arrays: the binding hands int32 / uint64 arrays to the C entry as they are -- lists of
+        # thousands of Python ints cost 15 us each to convert, per call)
+        ws, hs = np.array([sizes[i][0] for i in range(lo, hi)], np.int32), np.array([sizes[i][1] for i in range(lo, hi)], np.int32)
+        offs = np.array(offs, np.uint64)
         d_buf = torch.from_numpy(buf).to(dev)
         private["fddb_set"] = (n_img, sizes, lo, hi, imgs, offs, tot, buf, ws, hs, d_buf)
         return private["fddb_set"]
@@ -585,7 +592,7 @@ def main():
         info = {"images": n_img, "images_per_s": n_img * reps / el, "windows_per_s": windows * reps / el,
                 "ms_per_job": el / reps * 1e3, "jobs_timed": reps, "windows_per_job": windows, "scaling": "strong",
                 "entry": "jdaDetectBatchRaggedDevice (images resident in HBM), one host thread per GPU",
-                "sharding": "contiguous blocks of images over %d rank(s)" % world,
+                "sharding": "contiguous blocks of images of about equal candidate-window counts over %d rank(s)" % world,
                 "data": "synthetic, FDDB-like sizes (long side 300-450, short side >= 225)"}
         if world == 1:
             job(buf)
@@ -604,14 +611,15 @@ def main():
             for nn in (2, 4, 8):
                 worst, per = 0.0, []
                 for r in range(nn):
-                    a, b = jdist.shard_range(n_img, r, nn)
-                    base_off = offs[a]
-                    so = [o - base_off for o in offs[a:b]]
-                    end = offs[b] if b < n_img else tot
+                    a, b = jdist.shard_range_weighted(private["fddb_weights"], r, nn)
+                    base_off = int(offs[a])
+                    so = offs[a:b] - np.uint64(base_off)
+                    end = int(offs[b]) if b < n_img else tot
                     d_sub = d_buf[base_off:end]
+                    ws_s, hs_s = np.ascontiguousarray(ws[a:b]), np.ascontiguousarray(hs[a:b])
 
                     def shard_job():
-                        return casc.detect_ragged_packed(d_sub, so, ws[a:b], hs[a:b], stats=True, keep_results="packed", frame_offset=a, **kw)
+                        return casc.detect_ragged_packed(d_sub, so, ws_s, hs_s, stats=True, keep_results="packed", frame_offset=a, **kw)
                     shard_job(); shard_job()
                     nrep = max(3, reps)
                     ts = []
@@ -692,7 +700,7 @@ def main():
         info = {"images": n_img, "images_per_s": n_img * reps / el, "windows_per_s": windows * reps / el,
                 "ms_per_job": el / reps * 1e3, "jobs_timed": reps, "windows_per_job": windows, "scaling": "strong", "dtype": "f64",
                 "entry": "jdaDetectBatchCppRaggedDevice (images resident in HBM), one host thread per GPU",
-                "sharding": "contiguous blocks of images over %d rank(s)" % world,
+                "sharding": "contiguous blocks of images of about equal dialect-C candidate-window counts over %d rank(s)" % world,
                 "gather": "torch.distributed (float64 rows)" if world > 1 else "none (one rank)",
                 "face_patch_n": st["face_patch_n"], "average_cart_n": st["average_cart_n"],
                 "parity": "unpinned (oracle restatement only)"}

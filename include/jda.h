@@ -238,6 +238,21 @@ JDA_API int jdaDetectBatchRaggedDevice(void *cascador, const unsigned char *d_ba
                                        int min_size, int max_size, float th, const jdaDetectOptions *opt,
                                        jdaResult *out);
 
+/* The same two jobs with the results as ONE matrix instead of n jdaResults: a row per detection,
+ *   [frame_offset + image index, x, y, size, score, shape (2L absolute coordinates)]   (5 + 2L floats),
+ * images in order, detections of an image in jdaDetect's order -- exactly what jdaResultsPack makes of the n results,
+ * and the form the multi-GPU gather ships (include/jda_dist.h).  A job of hundreds of images returns a few hundred
+ * KB of rows; three allocations per image cost more host time than that (r06: 50 us of a 1.2-ms job).  *rows is
+ * malloc'd by the library (also when *n_rows is 0) and released with jdaRowsRelease.  Returns 0 on success. */
+JDA_API int jdaDetectBatchRaggedRows(void *cascador, const unsigned char *const *images, const int *widths,
+                                     const int *heights, int n, float scale, float step, int min_size, int max_size,
+                                     float th, const jdaDetectOptions *opt, int frame_offset, float **rows, int *n_rows);
+JDA_API int jdaDetectBatchRaggedDeviceRows(void *cascador, const unsigned char *d_base, const size_t *offsets,
+                                           const int *widths, const int *heights, int n, float scale, float step,
+                                           int min_size, int max_size, float th, const jdaDetectOptions *opt,
+                                           int frame_offset, float **rows, int *n_rows);
+JDA_API void jdaRowsRelease(float *rows);
+
 /* Up to three batches in flight on one cascador, driven by ONE host thread (streams of batches, e.g. video):
  * Submit queues a batch of device-resident frames on a lane of its own (stream + workspace) and returns at once with
  * a ticket (0..2; -1 on error: every ticket in use, multi-scale model); Wait collects that batch, post-processes it
@@ -333,6 +348,21 @@ JDA_API int jdaDetectBatchCppRaggedDevice(void *cascador, const unsigned char *d
                                           const int *widths, const int *heights, int n, int minimum_size, int step,
                                           double factor, double overlap, int nms,
                                           jdaStats *stats, jdaResultD *out);
+
+/* The two dialect-CPP ragged jobs with the results as ONE matrix of rows of (6 + 2*landmark_n) doubles,
+ * [frame_offset + image index, x, y, w, h, score, shape...], images in order, an image's rows in Detect's order (after the
+ * score-ordered NMS, cascador.cpp:444-474) -- exactly what jdaResultsDPack makes of the n jdaResultDs, without building
+ * them: the FDDB-sized job keeps 32 k candidates = 15 MB of rows, and going through 2,845 results and a pack cost 4 ms
+ * of a 38-ms job.  *rows is malloc'd by the library (also when *n_rows is 0); release it with jdaRowsDRelease. */
+JDA_API int jdaDetectBatchCppRaggedRows(void *cascador, const unsigned char *const *images, const int *widths,
+                                        const int *heights, int n, int minimum_size, int step, double factor,
+                                        double overlap, int nms, jdaStats *stats, int frame_offset,
+                                        double **rows, int *n_rows);
+JDA_API int jdaDetectBatchCppRaggedDeviceRows(void *cascador, const unsigned char *d_base, const size_t *offsets,
+                                              const int *widths, const int *heights, int n, int minimum_size, int step,
+                                              double factor, double overlap, int nms, jdaStats *stats, int frame_offset,
+                                              double **rows, int *n_rows);
+JDA_API void jdaRowsDRelease(double *rows);
 
 /* Flattens n dialect-CPP results into rows of (6 + 2*landmark_n) doubles: [frame_offset + i, x, y, w, h, score, shape...]
  * (the rows reference src/test.cpp:153-163 prints per image, plus the landmarks) -- what is gathered across GPUs for the

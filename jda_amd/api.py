@@ -111,6 +111,26 @@ def _load():
       lib.jdaDetectBatchRaggedDevice.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                                                C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                                C.c_float, C.POINTER(jdaDetectOptions), C.POINTER(jdaResult)]
+    if hasattr(lib, "jdaDetectBatchRaggedDeviceRows"):     # (r06: the job's detections as one matrix of rows)
+        lib.jdaDetectBatchRaggedRows.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                 C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions),
+                                                 C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+        lib.jdaDetectBatchRaggedDeviceRows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                       C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                       C.c_float, C.POINTER(jdaDetectOptions), C.c_int,
+                                                       C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+        lib.jdaRowsRelease.restype = None
+        lib.jdaRowsRelease.argtypes = [C.POINTER(C.c_float)]
+    if hasattr(lib, "jdaDetectBatchCppRaggedDeviceRows"):
+        dpp = C.POINTER(C.POINTER(C.c_double))
+        lib.jdaDetectBatchCppRaggedRows.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                                    C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(jdaStats),
+                                                    C.c_int, dpp, C.POINTER(C.c_int)]
+        lib.jdaDetectBatchCppRaggedDeviceRows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                          C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                          C.c_int, C.POINTER(jdaStats), C.c_int, dpp, C.POINTER(C.c_int)]
+        lib.jdaRowsDRelease.restype = None
+        lib.jdaRowsDRelease.argtypes = [C.POINTER(C.c_double)]
     lib.jdaDetectBatchSubmit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float,
                                          C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(jdaDetectOptions)]
     lib.jdaDetectBatchSubmitHost.argtypes = [C.c_void_p, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_float,
@@ -228,6 +248,33 @@ def _ivec(v, ctype=C.c_int, dtype=np.int32):
     if a.size == 0:
         a = np.zeros(1, dtype)
     return a, a.ctypes.data_as(C.POINTER(ctype))
+
+
+class _RowsOwner:
+    """Keeps the library's malloc'd row matrix until the last numpy view of it is gone, then gives it back
+    (jdaRowsRelease / jdaRowsDRelease)."""
+    def __init__(self, ptr, release):
+        self._ptr, self._release = ptr, release
+
+    def __del__(self):
+        if self._ptr:
+            self._release(self._ptr)
+            self._ptr = None
+
+
+def _owned_rows(ptr, n_rows, width, release, dtype):
+    """The library's rows as a numpy array WITHOUT a copy (15 MB per dialect-CPP FDDB job): the array's base holds a
+    _RowsOwner.  (numpy arrays are not garbage-collector tracked: the owner must not point back at the array.)"""
+    owner = _RowsOwner(ptr, release)
+    if n_rows <= 0:
+        return np.empty((0, width), dtype)
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__array_interface__ = np.ctypeslib.as_array(ptr, (n_rows, width)).__array_interface__
+    h._owner = owner
+    return np.asarray(h)
 
 
 def _take(r):
@@ -405,15 +452,31 @@ class Cascador:
         n = len(offsets)
         _kw, ws = _ivec(widths)
         _kh, hs = _ivec(heights)
-        res = (jdaResult * max(n, 1))()
         o, st = self._opts(nms, stats)
-        if isinstance(buf, np.ndarray):
+        host = isinstance(buf, np.ndarray)
+        if host:
             assert buf.dtype == np.uint8 and buf.flags.c_contiguous
             _ko, ptrs = _ivec(np.asarray(offsets, np.uint64) + np.uint64(buf.ctypes.data), C.POINTER(C.c_ubyte), np.uint64)
-            rc = lib.jdaDetectBatchRagged(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o), res)
         else:
             assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
             _ko, offs = _ivec(offsets, C.c_size_t, np.uint64)
+        if keep_results == "packed" and hasattr(lib, "jdaDetectBatchRaggedDeviceRows"):
+            # rows straight from the library (jdaDetectBatchRagged[Device]Rows): no jdaResult per image in between
+            rp, nr = C.POINTER(C.c_float)(), C.c_int(0)
+            if host:
+                rc = lib.jdaDetectBatchRaggedRows(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o),
+                                                  frame_offset, C.byref(rp), C.byref(nr))
+            else:
+                rc = lib.jdaDetectBatchRaggedDeviceRows(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, scale, 0.1,
+                                                        min_size, max_size, th, C.byref(o), frame_offset, C.byref(rp), C.byref(nr))
+            if rc != 0:
+                raise JdaError(last_error())
+            out = _owned_rows(rp, nr.value, 5 + self.dim, lib.jdaRowsRelease, np.float32)
+            return (out, st.asdict()) if stats else out
+        res = (jdaResult * max(n, 1))()
+        if host:
+            rc = lib.jdaDetectBatchRagged(self.h, ptrs, ws, hs, n, scale, 0.1, min_size, max_size, th, C.byref(o), res)
+        else:
             rc = lib.jdaDetectBatchRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, scale, 0.1,
                                                 min_size, max_size, th, C.byref(o), res)
         if rc != 0:
@@ -588,16 +651,32 @@ class Cascador:
         n = len(offsets)
         _kw, ws = _ivec(widths)
         _kh, hs = _ivec(heights)
-        res = (jdaResultD * max(n, 1))()
         st = jdaStats()
         sp = C.byref(st) if stats else None
-        if isinstance(buf, np.ndarray):
+        host = isinstance(buf, np.ndarray)
+        if host:
             assert buf.dtype == np.uint8 and buf.flags.c_contiguous
             _ko, ptrs = _ivec(np.asarray(offsets, np.uint64) + np.uint64(buf.ctypes.data), C.POINTER(C.c_ubyte), np.uint64)
-            rc = lib.jdaDetectBatchCppRagged(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0, sp, res)
         else:
             assert buf.is_cuda and buf.dtype.itemsize == 1 and buf.is_contiguous()
             _ko, offs = _ivec(offsets, C.c_size_t, np.uint64)
+        if keep_results == "packed" and hasattr(lib, "jdaDetectBatchCppRaggedDeviceRows"):
+            # rows straight from the library: no jdaResultD per image, no second copy of 15 MB of rows
+            rp, nr = C.POINTER(C.c_double)(), C.c_int(0)
+            if host:
+                rc = lib.jdaDetectBatchCppRaggedRows(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0, sp,
+                                                     frame_offset, C.byref(rp), C.byref(nr))
+            else:
+                rc = lib.jdaDetectBatchCppRaggedDeviceRows(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, minimum_size, step,
+                                                           factor, overlap, 1 if nms else 0, sp, frame_offset, C.byref(rp), C.byref(nr))
+            if rc != 0:
+                raise JdaError(last_error())
+            out = _owned_rows(rp, nr.value, 6 + self.dim, lib.jdaRowsDRelease, np.float64)
+            return (out, st.asdict()) if stats else out
+        res = (jdaResultD * max(n, 1))()
+        if host:
+            rc = lib.jdaDetectBatchCppRagged(self.h, ptrs, ws, hs, n, minimum_size, step, factor, overlap, 1 if nms else 0, sp, res)
+        else:
             rc = lib.jdaDetectBatchCppRaggedDevice(self.h, C.c_void_p(buf.data_ptr()), offs, ws, hs, n, minimum_size, step,
                                                    factor, overlap, 1 if nms else 0, sp, res)
         if rc != 0:

@@ -248,6 +248,54 @@ int jdaDetectBatchRaggedDevice(void* cascador, const unsigned char* d_base, cons
   return detect_ragged(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, out);
 } JDA_ABI_CATCH_SYNC(-1)
 
+namespace {
+// rows of a job -> the caller: the buffer itself, not a copy
+int ragged_rows_out_f(Cascador* c, int rc, RowsOut<float>& v, float** rows, int* n_rows) {
+  *rows = nullptr; *n_rows = 0;
+  if (rc != 0) return rc;
+  *n_rows = (int)(v.n / ((size_t)5 + c->hm.dim()));
+  *rows = v.release();
+  if (!*rows) { *n_rows = 0; fail("out of memory for the detection rows"); return -1; }
+  return 0;
+}
+int ragged_rows_out_d(Cascador* c, int rc, RowsOut<double>& v, double** rows, int* n_rows) {
+  *rows = nullptr; *n_rows = 0;
+  if (rc != 0) return rc;
+  *n_rows = (int)(v.n / ((size_t)6 + c->hm.dim()));
+  *rows = v.release();
+  if (!*rows) { *n_rows = 0; fail("out of memory for the detection rows"); return -1; }
+  return 0;
+}
+}  // namespace
+
+int jdaDetectBatchRaggedRows(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
+                             float scale, float step, int min_size, int max_size, float th, const jdaDetectOptions* opt,
+                             int frame_offset, float** rows, int* n_rows) try {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !images || !widths || !heights || !rows || !n_rows || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedRows runs dialect C"); return -1; }
+  RowsOut<float> v;
+  const int rc = detect_ragged_rows(c, images, nullptr, nullptr, widths, heights, n, scale, min_size, max_size, th, opt, frame_offset, &v);
+  return ragged_rows_out_f(c, rc, v, rows, n_rows);
+} JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchRaggedDeviceRows(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
+                                   const int* heights, int n, float scale, float step, int min_size, int max_size, float th,
+                                   const jdaDetectOptions* opt, int frame_offset, float** rows, int* n_rows) try {
+  (void)step;
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_base || !offsets || !widths || !heights || !rows || !n_rows || n < 0) { fail("bad arguments"); return -1; }
+  if (opt && opt->dialect != JDA_DIALECT_C) { fail("jdaDetectBatchRaggedDeviceRows runs dialect C"); return -1; }
+  RowsOut<float> v;
+  const int rc = detect_ragged_rows(c, nullptr, d_base, offsets, widths, heights, n, scale, min_size, max_size, th, opt, frame_offset, &v);
+  return ragged_rows_out_f(c, rc, v, rows, n_rows);
+} JDA_ABI_CATCH_SYNC(-1)
+
+void jdaRowsRelease(float* rows) { std::free(rows); }
+
 jdaResult jdaDetect(void* cascador, unsigned char* data, int width, int height,
                     float scale, float step, int min_size, int max_size, float th) {
   Cascador* c = (Cascador*)cascador;
@@ -640,6 +688,30 @@ int jdaDetectBatchCppRaggedDevice(void* cascador, const unsigned char* d_base, c
   if (!c || !d_base || !offsets || !widths || !heights || !out || n < 0) { fail("bad arguments"); return -1; }
   return detect_ragged_cpp(c, nullptr, d_base, offsets, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, out);
 } JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppRaggedRows(void* cascador, const unsigned char* const* images, const int* widths, const int* heights, int n,
+                                int minimum_size, int step, double factor, double overlap, int nms, jdaStats* stats,
+                                int frame_offset, double** rows, int* n_rows) try {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !images || !widths || !heights || !rows || !n_rows || n < 0) { fail("bad arguments"); return -1; }
+  RowsOut<double> v;
+  const int rc = detect_ragged_cpp_rows(c, images, nullptr, nullptr, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, frame_offset, &v);
+  return ragged_rows_out_d(c, rc, v, rows, n_rows);
+} JDA_ABI_CATCH_SYNC(-1)
+
+int jdaDetectBatchCppRaggedDeviceRows(void* cascador, const unsigned char* d_base, const size_t* offsets, const int* widths,
+                                      const int* heights, int n, int minimum_size, int step, double factor, double overlap, int nms,
+                                      jdaStats* stats, int frame_offset, double** rows, int* n_rows) try {
+  g_err.clear();
+  Cascador* c = (Cascador*)cascador;
+  if (!c || !d_base || !offsets || !widths || !heights || !rows || !n_rows || n < 0) { fail("bad arguments"); return -1; }
+  RowsOut<double> v;
+  const int rc = detect_ragged_cpp_rows(c, nullptr, d_base, offsets, widths, heights, n, CppCall{minimum_size, step, factor, overlap, nms}, stats, frame_offset, &v);
+  return ragged_rows_out_d(c, rc, v, rows, n_rows);
+} JDA_ABI_CATCH_SYNC(-1)
+
+void jdaRowsDRelease(double* rows) { std::free(rows); }
 
 int jdaResultsDPack(const jdaResultD* results, int n, int frame_offset, double* rows, int capacity_rows) try {
   if (!results || n < 0) return -1;

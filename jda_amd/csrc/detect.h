@@ -45,6 +45,30 @@ int wait_c_device(Cascador* c, int slot, jdaStats* stats, jdaResult* out);
 int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
                   const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
                   const jdaDetectOptions* opt, jdaResult* out);
+// Detection rows of a job, grown with realloc and handed to the caller as they are (jdaRowsRelease / jdaRowsDRelease = free).
+template <typename T>
+struct RowsOut {
+  T* p = nullptr; size_t n = 0, cap = 0;          // n, cap in elements
+  T* grow(size_t add) {                            // room for `add` more elements; returns where they start
+    if (n + add > cap) {
+      size_t nc = std::max<size_t>(std::max<size_t>(cap * 2, n + add), 1024);
+      T* q = (T*)std::realloc(p, nc * sizeof(T));
+      if (!q) throw std::bad_alloc();
+      p = q; cap = nc;
+    }
+    T* at = p + n; n += add;
+    return at;
+  }
+  T* release() { T* q = p ? p : (T*)std::malloc(sizeof(T)); p = nullptr; n = cap = 0; return q; }   // (never NULL on success)
+  ~RowsOut() { std::free(p); }
+  RowsOut() = default; RowsOut(const RowsOut&) = delete; RowsOut& operator=(const RowsOut&) = delete;
+};
+int detect_ragged_rows(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                       const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
+                       const jdaDetectOptions* opt, int frame_offset, RowsOut<float>* rows);
+int detect_ragged_cpp_rows(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                           const int* widths, const int* heights, int n, const CppCall& call, jdaStats* stats, int frame_offset,
+                           RowsOut<double>* rows);
 int detect_ragged_cpp(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
                       const int* widths, const int* heights, int n, const CppCall& call, jdaStats* stats, jdaResultD* out);
 

@@ -60,6 +60,13 @@ inline double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// LDS of a gfx950 CU is handed out in granules of 1,280 bytes, 128 of them (160 KB): a workgroup of 54,272 bytes takes 43
+// granules and only TWO of them fit, although 3 x 54,272 < 163,840 and hipOccupancyMaxActiveBlocksPerMultiprocessor says
+// three (measured: tools/experiments/lds_occupancy.hip, profiles/r06_lds_granule.txt).
+constexpr int kLdsGranule = 1280, kLdsGranules = 128;
+inline int lds_wgs_per_cu(long long lds_bytes) { return lds_bytes <= 0 ? kLdsGranules : (int)(kLdsGranules / ((lds_bytes + kLdsGranule - 1) / kLdsGranule)); }
+inline int lds_bytes_for_wgs(int wgs_per_cu) { return (kLdsGranules / std::max(1, wgs_per_cu)) * kLdsGranule; }   // the largest workgroup that still fits that many times
+
 inline long long env_ll(const char* name, long long dflt) {
   const char* v = std::getenv(name);
   return v && *v ? std::atoll(v) : dflt;
@@ -120,6 +127,7 @@ inline long long env_ll(const char* name, long long dflt) {
   X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */ \
   X(scan_p_tile_kb, "JDA_SCAN_P_TILE_KB", 0) /* ... its own cut of a level's tile in y: as many rows of windows as keep the pixel tile within this many KB (0: the plan's tile) */ \
   X(scan_p_grid, "JDA_SCAN_P_GRID", 0)      /* ... workgroups of a launch (0: one per CU x scan_p_wgs) */ \
+  X(exp_a, "JDA_EXP_A", 0) X(exp_b, "JDA_EXP_B", 0) X(exp_c, "JDA_EXP_C", 0) /* (session experiments; removed before the round ends) */ \
   X(scan_p_mid, "JDA_SCAN_P_MID", 1)        /* ... with scan_p_handoff >= K: windows that pass stage 0 go straight to the mid queue */
 
 struct Knobs {
@@ -580,6 +588,9 @@ struct RaggedChunk {
   std::vector<Launch> launches;
   int n_segs = 0, n_blk = 0;
   size_t off_segs = 0, off_blk = 0, off_imgoff = 0, off_rimg = 0, off_gidbase = 0, table_bytes = 0;   // layout of the table buffer
+  size_t images_bytes = 0;              // ... whose first bytes are the image records (RagImg, image offsets, gid ranges)
+  bool images_issued = false;           // the image records' upload and k_repack are already on the lane's stream (device-resident
+                                        // images: queued before the block map was built, ragged.cpp); the pass uploads the rest
   const unsigned char* const* host_imgs = nullptr;   // the chunk's images in host memory (tight), or
   const uint8_t* d_raw = nullptr;                    // the base their RagImg::src_off refer to on the device
   const int* widths = nullptr; const int* heights = nullptr;      // of the chunk's images

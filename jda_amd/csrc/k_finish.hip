@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
   }
 #ifdef JDA_SCAN_TIMING
   JDA_FSTAMP();
-  if (lane == 0 && w.dbg && blockIdx.x < 65536 && t_begin > 0 && blockIdx.x < n) {
+  if (lane == 0 && w.dbg && blockIdx.x < 65536 && (t_begin > 0 || survivors) && blockIdx.x < n) {
     unsigned long long* o = w.dbg + (size_t)blockIdx.x * 32;
     o[0] = (unsigned long long)n_stamp | (0x7777ull << 32);
     for (int i = 0; i < n_stamp; i++) o[1 + i] = stamps[i];

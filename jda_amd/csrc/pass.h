@@ -4,6 +4,63 @@
 
 namespace jda {
 
+// ---- the persistent scan's configuration, the parts that do not depend on the pass (k_scan_p.hip) ----
+// Cart ranges (buckets), task forms, rings, workgroup size of a cascador's persistent scan launches; returns the carts
+// it evaluates (the hand-off).
+inline int scan_p_base_cfg(const Cascador* c, PScanCfg* cfg, int* block, int* wgs) {
+  const Knobs& kn = c->kn;
+  const int K = std::min(c->hm.K, (int)(kn.scan_p_handoff > 0 ? kn.scan_p_handoff : kn.handoff));
+  const long long bs[5] = {kn.scan_p_b0, kn.scan_p_b1, kn.scan_p_b2, kn.scan_p_b3, kn.scan_p_b4};
+  int digits[kPScanMaxBuckets] = {6, 6, 6, 6, 6, 6}, nd = 0;
+  { long long v = std::max<long long>(0, kn.scan_p_lg); int tmp[16]; int n = 0; while (v > 0 && n < 16) { tmp[n++] = (int)(v % 10); v /= 10; }
+    for (int i = n - 1; i >= 0 && nd < kPScanMaxBuckets; i--) digits[nd++] = tmp[i]; }
+  int last = 0;
+  for (int i = 0; i < 5 && cfg->nb < kPScanMaxBuckets; i++) {
+    const int b = (int)bs[i];
+    if (b <= last || b >= K) continue;
+    cfg->bound[cfg->nb] = b;
+    const int d = digits[cfg->nb];
+    cfg->lg[cfg->nb] = ((d == 4 || d == 5 || d == 7 || d == 8 || d == 9) && c->hm.leaf_n() <= 256) || d == 2 || d == 3 ? d : 6;
+    cfg->nb++;
+    last = b;
+  }
+  cfg->bound[cfg->nb] = K;
+  cfg->bound_last = K;
+  cfg->any_norm = stage0_any_norm(c->hm, K, true) ? 1 : 0;
+  *block = (int)std::max<long long>(64, std::min<long long>(1024, kn.scan_p_block)) & ~63;
+  *wgs = (int)std::max<long long>(1, std::min<long long>(8, kn.scan_p_wgs));
+  cfg->ring_cap[0] = (int)std::max<long long>(64, std::min<long long>(4096, kn.scan_p_ring));
+  scan_p_ring_caps(cfg, *block / 64);
+  return K;
+}
+// Pixel-tile slots a persistent workgroup gets for tiles of cfg->slot_bytes, or 0 when the level is left to k_scan's closed
+// tiles: fewer than scan_p_min_slots slots (few resident windows per wave) or too few tiles to keep the workgroups fed.
+// capped: other kernels are in flight next to the pass (scan_p_slots).  The answer for "will it take the level at all" does
+// not depend on `capped` (scan_p_slots >= scan_p_min_slots) -- ragged_build_chunk asks it ahead of the pass.
+inline long long scan_p_slots_for(const Cascador* c, const PScanCfg& cfg_in, int K, int block, int wgs, long long n_tiles, bool capped) {
+  const Knobs& kn = c->kn;
+  PScanCfg cfg = cfg_in;
+  cfg.slots = 0;
+  const long long fixed = (long long)scan_p_lds_bytes(cfg, K, c->hm.node_n(), c->hm.leaf_n(), block / 64);
+  const long long budget = std::max<long long>(16, std::min<long long>(160, kn.scan_p_lds_kb)) * 1024 / wgs;
+  long long slots = (budget - fixed) / std::max(1, cfg.slot_bytes);
+  if (kn.scan_p_slots > 0 && capped) slots = std::min<long long>(slots, kn.scan_p_slots);
+  slots = std::min<long long>(slots, 8);
+  if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return 0;
+  if (kn.scan_p == 1 && slots < kn.scan_p_min_slots) return 0;     // few resident windows per wave: k_scan's closed tiles do better there
+  if (kn.scan_p == 1 && n_tiles < (long long)c->n_cus * wgs * 4) return 0;   // too few tiles to keep persistent workgroups fed
+  return slots;
+}
+// Will the persistent scan take a single-level launch of a ragged chunk (tiles of at most pix_bytes, n_tiles of them)?
+inline bool scan_p_takes_ragged(const Cascador* c, int pix_bytes, long long n_tiles) {
+  if (!c->kn.scan_p || !c->kn.scan_p_ragged) return false;
+  PScanCfg cfg{};
+  int block = 0, wgs = 1;
+  const int K = scan_p_base_cfg(c, &cfg, &block, &wgs);
+  cfg.slot_bytes = (pix_bytes + 15) & ~15;
+  return scan_p_slots_for(c, cfg, K, block, wgs, n_tiles, false) > 0;
+}
+
 // One sub-batch of frames going through the device pipeline on one lane (stream + workspace).
 // The pipeline has four host-visible waits (hand-off count, mid-queue count, counters, results);
 // the methods are the pieces between them, so that run_device can interleave two lanes: while
@@ -163,32 +220,12 @@ struct Pass {
       const DevModelT<Real>& m = model();
       const DevLevel& lv = pe->hp.lv[level];
       if (lv.win > kn().scan_p_win_max) return false;
-      const int K = std::min(m.K, (int)(kn().scan_p_handoff > 0 ? kn().scan_p_handoff : kn().handoff));
       PScanCfg cfg{};
+      int block = 0, wgs = 1;
+      const int K = scan_p_base_cfg(c, &cfg, &block, &wgs);
       // all of stage 0 in this kernel: its survivors are what k_filter0 would leave in the mid queue (launch_finishers
       // then takes the k_filter0 + k_finish(survivors) form whatever the size of the hand-off queue)
       cfg.to_mid = (K == m.K && kn().scan_p_mid && filter0_ok()) ? 1 : 0;
-      const long long bs[5] = {kn().scan_p_b0, kn().scan_p_b1, kn().scan_p_b2, kn().scan_p_b3, kn().scan_p_b4};
-      int digits[kPScanMaxBuckets] = {6, 6, 6, 6, 6, 6}, nd = 0;
-      { long long v = std::max<long long>(0, kn().scan_p_lg); int tmp[16]; int n = 0; while (v > 0 && n < 16) { tmp[n++] = (int)(v % 10); v /= 10; }
-        for (int i = n - 1; i >= 0 && nd < kPScanMaxBuckets; i--) digits[nd++] = tmp[i]; }
-      int last = 0;
-      for (int i = 0; i < 5 && cfg.nb < kPScanMaxBuckets; i++) {
-        const int b = (int)bs[i];
-        if (b <= last || b >= K) continue;
-        cfg.bound[cfg.nb] = b;
-        const int d = digits[cfg.nb];
-        cfg.lg[cfg.nb] = ((d == 4 || d == 5 || d == 7 || d == 8 || d == 9) && m.leaf_n <= 256) || d == 2 || d == 3 ? d : 6;
-        cfg.nb++;
-        last = b;
-      }
-      cfg.bound[cfg.nb] = K;
-      cfg.bound_last = K;
-      cfg.any_norm = stage0_any_norm(c->hm, K, true) ? 1 : 0;
-      const int block = (int)std::max<long long>(64, std::min<long long>(1024, kn().scan_p_block)) & ~63;
-      const int wgs = (int)std::max<long long>(1, std::min<long long>(8, kn().scan_p_wgs));
-      cfg.ring_cap[0] = (int)std::max<long long>(64, std::min<long long>(4096, kn().scan_p_ring));
-      scan_p_ring_caps(&cfg, block / 64);
       if (!rl) { const unsigned mg = ((1u << 20) + (unsigned)lv.tw - 1u) / (unsigned)lv.tw; bool ok = true;
         for (unsigned i = 0; i < (unsigned)(lv.tw * lv.th + 64) && ok; i++) ok = ((i * mg) >> 20) == i / (unsigned)lv.tw;
         cfg.tw_magic = ok ? (int)mg : 0; }
@@ -213,19 +250,12 @@ struct Pass {
       }
       cfg.tiles_y = (lv.ny + cfg.th - 1) / cfg.th;
       cfg.slot_bytes = rl ? ((rl->pix_bytes + 15) & ~15) : ((lv.pitch * (lv.win + (cfg.th - 1) * lv.step) + 15) & ~15);
-      cfg.slots = 0;
-      const long long fixed = (long long)scan_p_lds_bytes(cfg, K, m.node_n, m.leaf_n, block / 64);
-      const long long budget = std::max<long long>(16, std::min<long long>(160, kn().scan_p_lds_kb)) * 1024 / wgs;
-      long long slots = (budget - fixed) / std::max(1, cfg.slot_bytes);
       // (the cap only where another batch's kernels are in flight next to this pass -- a second lane of this call,
       // other tickets or callers; alone, the workgroup takes every slot that fits)
-      if (kn().scan_p_slots > 0 && (!solo || busy_lanes > 1)) slots = std::min<long long>(slots, kn().scan_p_slots);
-      slots = std::min<long long>(slots, 8);
-      if (slots < 2 || fixed + slots * cfg.slot_bytes >= (1 << 18)) return false;
-      if (kn().scan_p == 1 && slots < kn().scan_p_min_slots) return false;     // few resident windows per wave: k_scan's closed tiles do better there
-      cfg.slots = (int)slots;
       const long long n_tiles = rl ? (long long)rl->blk_n : (long long)lv.tiles_x * cfg.tiles_y * nf;
-      if (kn().scan_p == 1 && n_tiles < (long long)c->n_cus * wgs * 4) return false;   // too few tiles to keep persistent workgroups fed
+      const long long slots = scan_p_slots_for(c, cfg, K, block, wgs, n_tiles, !solo || busy_lanes > 1);
+      if (slots <= 0) return false;
+      cfg.slots = (int)slots;
       cfg.dyn_slot = (kn().scan_p_dyn && p_launches < kCntMidScan - kCntTotal) ? p_launches : -1;
       const int grid = kn().scan_p_grid > 0 ? (int)std::min<long long>(kn().scan_p_grid, 1 << 16) : c->n_cus * wgs;
       const hipError_t e = rl ? launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s, rl->blk_base, rl->blk_n)
@@ -243,7 +273,7 @@ struct Pass {
     constexpr int dialect = Sel<Real>::dialect;
     const DevModelT<Real>& m = model();
     a_hbuf = hbuf; a_hs = hs; a_qbuf = qbuf; a_qs = qs;
-    if (timed) JDA_HIP(hipEventRecord(ev[0], st));
+    if (timed && !(rag && rag->images_issued)) JDA_HIP(hipEventRecord(ev[0], st));     // (else: recorded in front of the images' repack, ragged.cpp)
     if (rag) return issue_scan_ragged();
     if (host_frames && !upload_frames(const_cast<uint8_t*>(w.frames), w.frame_stride, host_frames, nf, host_fbytes)) return false;
     if (multi && w.patch_hs > 0) {             // method 0: every window's ROI -> its half_size / quarter_size patches (cascador.cpp:243-245)
@@ -387,18 +417,23 @@ struct Pass {
     const DevModelT<Real>& m = model();
     const RaggedChunk& ch = *rag;
     uint8_t* tab = (uint8_t*)ln->rag_tab.p;
-    JDA_HIP(hipMemcpyAsync(tab, ln->h_tab.p, ch.table_bytes, hipMemcpyHostToDevice, st));
-    const uint8_t* raw = ch.d_raw;
-    if (ch.d_uploaded) {
-      raw = ch.d_uploaded;              // (detect_ragged waited for the upload on the host before it called this)
-    } else if (ch.host_imgs) {
-      // tight images -> device: one copy when they lie back to back in the caller's memory, else through the lane's
-      // pinned staging buffer (filled by build_chunk)
-      const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : ln->h_raw.p;
-      JDA_HIP(hipMemcpyAsync(ln->rag_raw.p, src, ch.raw_bytes, hipMemcpyHostToDevice, st));
-      raw = (const uint8_t*)ln->rag_raw.p;
+    if (ch.images_issued) {
+      // (the image records and k_repack are on the stream already: segments and block map follow)
+      JDA_HIP(hipMemcpyAsync(tab + ch.images_bytes, (const uint8_t*)ln->h_tab.p + ch.images_bytes, ch.table_bytes - ch.images_bytes, hipMemcpyHostToDevice, st));
+    } else {
+      JDA_HIP(hipMemcpyAsync(tab, ln->h_tab.p, ch.table_bytes, hipMemcpyHostToDevice, st));
+      const uint8_t* raw = ch.d_raw;
+      if (ch.d_uploaded) {
+        raw = ch.d_uploaded;              // (detect_ragged waited for the upload on the host before it called this)
+      } else if (ch.host_imgs) {
+        // tight images -> device: one copy when they lie back to back in the caller's memory, else through the lane's
+        // pinned staging buffer (filled by build_chunk)
+        const void* src = ch.host_contiguous ? (const void*)ch.host_imgs[0] : ln->h_raw.p;
+        JDA_HIP(hipMemcpyAsync(ln->rag_raw.p, src, ch.raw_bytes, hipMemcpyHostToDevice, st));
+        raw = (const uint8_t*)ln->rag_raw.p;
+      }
+      JDA_HIP(launch_repack(raw, (uint8_t*)ln->rag_frames.p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
     }
-    JDA_HIP(launch_repack(raw, (uint8_t*)ln->rag_frames.p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, st));
     w.frames = (const uint8_t*)ln->rag_frames.p; w.frame_stride = 0; w.n_frames = ch.n;
 #ifdef JDA_BOUNDS_CHECK
     w.bc_lo = w.frames; w.bc_hi = w.frames + ch.frame_bytes;       // (bounds-check build: the staged images of the chunk)

@@ -24,6 +24,12 @@ struct RaggedJob {
   int pitch = 0;                    // common row pitch of the staged images (multiple of 16)
   ScanPlan levels;                  // global level list; nx, ny = nominal (mean) grids, width = pitch
   std::vector<int> n_lv;            // levels image i has (a prefix of the global list)
+  // the window grid of every (image, level), counted ONCE (ragged_prepare): image i's levels at [geo_first[i], geo_first[i + 1]).
+  // (r06: a 356-image shard's tables were 93 us of integer divisions on the host, in front of the GPU's first kernel --
+  // the same quotients four times over; now 25)
+  std::vector<uint32_t> geo_first;
+  std::vector<uint16_t> gnx, gny;
+  std::vector<long long> wins;      // candidate windows of image i
   PlanEntry* pe = nullptr;
   bool cpp = false;                 // dialect CPP (call: its parameters), else dialect C (scale, min_size, max_size)
   CppCall call{};
@@ -34,6 +40,13 @@ struct RaggedJob {
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// n / d for n < 65536 and 1 <= d < 65536 by one multiply: m = ceil(2^32 / d) overshoots n / d by less than 2^-16 < 1 / d.
+struct Div16 {
+  uint64_t m = 0; bool one = false;
+  explicit Div16(int d = 1) { one = d <= 1; m = one ? 0 : (0xffffffffull / (uint64_t)d) + 1; }
+  int operator()(int n) const { return one ? n : (int)(((uint64_t)(uint32_t)n * m) >> 32); }
+};
+static thread_local double t_prep_marks[3];       // debug_times = 2: ragged_prepare's pieces (levels planned, grids counted, plan fetched)
 
 // Levels of image (w, h): the prefix of the job's global list whose windows fit (c/jda.c:321-322,332).
 static int ragged_levels_of(const RaggedJob& job, int w, int h) {
@@ -57,6 +70,7 @@ static int ragged_prepare(Cascador* c, RaggedJob* job) {
   std::string err;
   if (job->cpp ? !plan_dialect_cpp(max_min, max_min, job->call.minimum_size, job->call.step, job->call.factor, &job->levels, &err)
                : !plan_dialect_c(max_min, max_min, scale, min_size, max_size, &job->levels, &err)) { fail(err); return -1; }
+  t_prep_marks[0] = now_ms();
   const int nl = (int)job->levels.levels.size();
   if (nl > kMaxLevels) return 1;
   int pitch = (max_w + 15) & ~15;
@@ -67,15 +81,31 @@ static int ragged_prepare(Cascador* c, RaggedJob* job) {
   std::vector<double> sx(nl, 0.0), sy(nl, 0.0);
   std::vector<long long> cnt(nl, 0);
   job->n_lv.resize(job->n);
-  for (int i = 0; i < job->n; i++) {
-    const int k = ragged_levels_of(*job, job->widths[i], job->heights[i]);
-    job->n_lv[i] = k;
-    for (int l = 0; l < k; l++) {
-      const Level& lv = job->levels.levels[l];
-      sx[l] += (job->widths[i] - lv.win) / lv.step + 1; sy[l] += (job->heights[i] - lv.win) / lv.step + 1; cnt[l]++;
+  job->geo_first.resize((size_t)job->n + 1);
+  job->wins.resize((size_t)job->n);
+  {
+    Div16 by_step[kMaxLevels];
+    for (int l = 0; l < nl; l++) by_step[l] = Div16(job->levels.levels[l].step);
+    size_t tot = 0;
+    for (int i = 0; i < job->n; i++) { job->n_lv[i] = ragged_levels_of(*job, job->widths[i], job->heights[i]); job->geo_first[i] = (uint32_t)tot; tot += (size_t)job->n_lv[i]; }
+    job->geo_first[job->n] = (uint32_t)tot;
+    job->gnx.resize(tot); job->gny.resize(tot);
+    for (int i = 0; i < job->n; i++) {
+      const int k = job->n_lv[i], W = job->widths[i], H = job->heights[i];
+      uint16_t* gx = job->gnx.data() + job->geo_first[i]; uint16_t* gy = job->gny.data() + job->geo_first[i];
+      long long wi = 0;
+      for (int l = 0; l < k; l++) {
+        const Level& lv = job->levels.levels[l];
+        const int nx = by_step[l](W - lv.win) + 1, ny = by_step[l](H - lv.win) + 1;      // c/jda.c:335-336
+        gx[l] = (uint16_t)nx; gy[l] = (uint16_t)ny;
+        sx[l] += nx; sy[l] += ny; cnt[l]++;
+        wi += (long long)nx * ny;
+      }
+      job->wins[(size_t)i] = wi;
     }
   }
-  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged prepare: levels of %d images counted\n", job->n);
+  t_prep_marks[1] = now_ms();
+  if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged prepare: levels of %d images counted\n", job->n);
   unsigned long long h = 1469598103934665603ull;
   for (int l = 0; l < nl; l++) {
     Level& lv = job->levels.levels[l];
@@ -96,6 +126,7 @@ static int ragged_prepare(Cascador* c, RaggedJob* job) {
   }
   std::unique_lock<std::mutex> lk(c->mu);
   if (!get_plan(c, lk, key, job->levels, job->cpp ? JDA_DIALECT_CPP : JDA_DIALECT_C, &job->pe, true)) return -1;      // (pinned; detect_ragged unpins)
+  t_prep_marks[2] = now_ms();
   if (job->pe->dense_hint && !c->last_dense) job->pe->dense_hint = false;   // the per-image passes since then rejected most windows again
   if (!job->pe->fast_scan || job->pe->any_untiled || job->pe->dense_hint || c->kn.dense == 2) return 1;
   for (int l = 0; l < nl; l++) if (job->pe->hp.lv[l].tw * job->pe->hp.lv[l].th > 512) return 1;
@@ -121,67 +152,41 @@ static int ragged_th_lds(const DevLevel& d, int pix_budget) {
 }
 
 // Tables of images [i0, i0 + n) into the lane's pinned table buffer (and, for host images that do not lie back to
-// back, the images into the lane's pinned staging buffer).
-static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
-  const DevPlan& hp = job.pe->hp;
-  const int nl = hp.n_levels;
+// back, the images into the lane's pinned staging buffer).  Two steps, so that the pass can put the images' repack on the
+// stream before the (longer) block map is built: ragged_build_images -- the image records, the front of the table buffer
+// [0, ch->images_bytes) -- and ragged_build_chunk, the rest.
+static bool ragged_build_images(const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
   ch->i0 = i0; ch->n = n; ch->pitch = job.pitch;
   ch->widths = job.widths + i0; ch->heights = job.heights + i0;
   ch->host_imgs = job.host_imgs ? job.host_imgs + i0 : nullptr;
   ch->d_raw = job.d_base;
-  // ---- counts ----
-  // How far a re-cut tile's pixels may outgrow the level's nominal tile (taller, narrower tiles for narrow images): as
-  // far as the workgroups per CU stay what the nominal tile allows -- measured, a flat 1.4x took the 71/88-pixel levels
-  // from 2 workgroups per CU to 1 and cost more than the fuller first phase gained.
-  int th_lds[kMaxLevels];
-  {
-    const HostModel& hm = c->hm;
-    const int rb = job.real_bytes();
-    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), rb));
-    for (int l = 0; l < nl; l++) {
-      const DevLevel& d = hp.lv[l];
-      if (d.tiled == 2) { th_lds[l] = d.th; continue; }
-      const int nominal = d.pitch * (d.win + (d.th - 1) * d.step);
-      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), rb, false, d.tw * d.th > 256 ? 512 : 256);
-      const int per_cu = std::max(1, (160 * 1024) / (fixed + nominal));
-      const int room = (160 * 1024) / per_cu - fixed - 64;
-      th_lds[l] = ragged_th_lds(d, std::max(nominal, std::min(room, nominal * (int)c->kn.ragged_tile_grow_pct / 100)));
-    }
-  }
-  int n_segs = 0;
-  long long n_blk = 0;
-  for (int i = 0; i < n; i++) {
-    const int W = job.widths[i0 + i], H = job.heights[i0 + i];
-    n_segs += job.n_lv[i0 + i];
-    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
-      const DevLevel& d = hp.lv[l];
-      const int nx = (W - d.win) / d.step + 1, ny = (H - d.win) / d.step + 1;
-      int tw, th;
-      ragged_tile(d, nx, ny, th_lds[l], &tw, &th);
-      n_blk += (long long)((nx + tw - 1) / tw) * ((ny + th - 1) / th);
-    }
-  }
-  if (n_blk > 0x7fffffffLL) { fail("ragged chunk has too many tiles"); return false; }
-  ch->n_segs = n_segs; ch->n_blk = (int)n_blk;
+  const uint32_t geo0 = job.geo_first[i0];
+  const int n_segs = (int)(job.geo_first[i0 + n] - geo0);
+  // layout: image records first (what k_repack and k_post read), then segments and the block map; the block map's size is
+  // only known after the tile cuts, so it comes last
   size_t o = 0;
-  ch->off_segs = o; o = align_up(o + (size_t)n_segs * sizeof(RagSeg), 256);
-  ch->off_blk = o; o = align_up(o + (size_t)n_blk * sizeof(RagBlk), 256);
-  ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
   ch->off_rimg = o; o = align_up(o + (size_t)n * sizeof(RagImg), 256);
+  ch->off_imgoff = o; o = align_up(o + (size_t)n * sizeof(unsigned long long), 256);
   ch->off_gidbase = o; o = align_up(o + ((size_t)n + 1) * sizeof(uint32_t), 256);      // (k_post: an image's gid range)
-  ch->table_bytes = o;
-  if (!ln->h_tab.reserve(o) || !ln->rag_tab.reserve(o)) return false;
+  ch->images_bytes = o;
+  ch->off_segs = o; o = align_up(o + (size_t)n_segs * sizeof(RagSeg), 256);
+  ch->off_blk = o;
+  ch->n_segs = n_segs;
+  ch->images_issued = false;
+  {
+    // (room for the block map as well, so that neither buffer moves between the two steps: about a tile per 200 windows)
+    long long wsum = 0;
+    for (int i = 0; i < n; i++) wsum += job.wins[(size_t)(i0 + i)];
+    const size_t guess = o + ((size_t)(wsum / 96) + (size_t)n_segs * 2 + 1024) * sizeof(RagBlk);
+    if (!ln->h_tab.reserve(guess) || !ln->rag_tab.reserve(guess)) return false;
+  }
   uint8_t* tab = (uint8_t*)ln->h_tab.p;
-  RagSeg* segs = (RagSeg*)(tab + ch->off_segs);
-  RagBlk* blk = (RagBlk*)(tab + ch->off_blk);
   unsigned long long* img_off = (unsigned long long*)(tab + ch->off_imgoff);
   RagImg* rimg = (RagImg*)(tab + ch->off_rimg);
-  // ---- images and segments ----
   ch->gid_base.assign(n + 1, 0);
-  std::vector<int> seg_first(n + 1, 0);
   size_t dst = 0, src = 0;
   long long gid = 0;
-  int max_h = 0, si = 0;
+  int max_h = 0;
   bool contiguous = job.host_imgs != nullptr;
   for (int i = 0; i < n; i++) {
     const int W = job.widths[i0 + i], H = job.heights[i0 + i];
@@ -198,23 +203,8 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     }
     dst += align_up((size_t)H * job.pitch, 256);
     ch->gid_base[i] = (uint32_t)gid;
-    seg_first[i] = si;
-    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
-      const DevLevel& d = hp.lv[l];
-      RagSeg& sg = segs[si++];
-      sg.img_off = img_off[i]; sg.gid_base = (uint32_t)gid;
-      sg.nx = (uint16_t)((W - d.win) / d.step + 1); sg.ny = (uint16_t)((H - d.win) / d.step + 1);
-      int tw, th;
-      ragged_tile(d, sg.nx, sg.ny, th_lds[l], &tw, &th);
-      sg.tw = (uint16_t)tw; sg.th = (uint16_t)th;
-      sg.tiles_x = (uint16_t)((sg.nx + tw - 1) / tw);
-      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = 0;
-      sg.win = d.win; sg.step = d.step; sg.pitch = d.pitch; sg.s0_table = d.s0_table; sg.tiled = d.tiled;
-      sg.pad2 = sg.pad3 = sg.pad4 = 0;
-      gid += (long long)sg.nx * sg.ny;
-    }
+    gid += job.wins[(size_t)(i0 + i)];
   }
-  seg_first[n] = si;
   ch->gid_base[n] = (uint32_t)gid;
   std::memcpy(tab + ch->off_gidbase, ch->gid_base.data(), ((size_t)n + 1) * sizeof(uint32_t));
   if (gid > 0x7fffffffLL) { fail("ragged chunk has too many windows"); return false; }
@@ -230,6 +220,114 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
       for (int i = 0; i < n; i++) std::memcpy(hr + rimg[i].src_off, job.host_imgs[i0 + i], (size_t)rimg[i].w * rimg[i].h);
     }
   }
+  return true;
+}
+
+static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n, Lane* ln, RaggedChunk* ch) {
+  const DevPlan& hp = job.pe->hp;
+  const int nl = hp.n_levels;
+  // ---- counts ----
+  // How far a re-cut tile's pixels may outgrow the level's nominal tile (taller, narrower tiles for narrow images): as
+  // far as the workgroups per CU stay what the nominal tile allows -- measured, a flat 1.4x took the 71/88-pixel levels
+  // from 2 workgroups per CU to 1 and cost more than the fuller first phase gained.
+  int th_lds[kMaxLevels];
+  {
+    const HostModel& hm = c->hm;
+    const int rb = job.real_bytes();
+    const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), rb));
+    for (int l = 0; l < nl; l++) {
+      const DevLevel& d = hp.lv[l];
+      if (d.tiled == 2) { th_lds[l] = d.th; continue; }
+      const int nominal = d.pitch * (d.win + (d.th - 1) * d.step);
+      const int fixed = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), rb, false, d.tw * d.th > 256 ? 512 : 256);
+      // (workgroups per CU in LDS granules, host.h: a tile grown to 160 KB / 3 takes 43 granules and fits twice, not three times)
+      const int per_cu = std::max(1, lds_wgs_per_cu(fixed + nominal));
+      const int room = lds_bytes_for_wgs(per_cu) - fixed - 64;
+      th_lds[l] = ragged_th_lds(d, std::max(nominal, std::min(room, nominal * (int)c->kn.ragged_tile_grow_pct / 100)));
+    }
+  }
+  // ---- the tile cut of every (image, level) of the chunk, once: the level's tile re-cut for the image's grid.  The cut in x
+  //      depends on (level, nx) only, the cut in y on (level, tw, ny): both memoised per chunk. ----
+  struct Cut { uint16_t tw, th, tiles_x, tiles_y; };
+  static thread_local std::vector<Cut> cuts;
+  static thread_local std::vector<uint32_t> memo_x[kMaxLevels];        // [nx] -> tw | tiles_x << 16 (0: not yet)
+  struct MemoY { uint32_t key; uint16_t th, tiles_y; };
+  static thread_local MemoY memo_y[kMaxLevels][64];                    // direct-mapped on (tw, ny)
+  const uint32_t geo0 = job.geo_first[i0];
+  const int n_segs = (int)(job.geo_first[i0 + n] - geo0);
+  cuts.resize((size_t)n_segs);
+  for (int l = 0; l < nl; l++) { memo_x[l].clear(); for (auto& e : memo_y[l]) e.key = 0xffffffffu; }
+  long long n_blk = 0;
+  int th_max[kMaxLevels], win_max[kMaxLevels];       // rows / windows of the largest tile any image of the chunk cut from level l
+  for (int l = 0; l < nl; l++) { th_max[l] = 1; win_max[l] = 1; }
+  long long lds_blocks = 0;
+  for (int i = 0; i < n; i++) {
+    const uint32_t gi = job.geo_first[i0 + i];
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      const int nx = job.gnx[gi + l], ny = job.gny[gi + l];
+      Cut& cu = cuts[gi - geo0 + l];
+      if ((size_t)nx >= memo_x[l].size()) memo_x[l].resize((size_t)nx + 64, 0u);
+      uint32_t mx = memo_x[l][nx];
+      int tw, th, tiles_y;
+      if (mx) tw = (int)(mx & 0xffffu);
+      else {
+        ragged_tile(d, nx, ny, th_lds[l], &tw, &th);
+        mx = (uint32_t)tw | ((uint32_t)((nx + tw - 1) / tw) << 16);
+        memo_x[l][nx] = mx;
+      }
+      const uint32_t ykey = ((uint32_t)tw << 16) | (uint32_t)ny;
+      MemoY& my = memo_y[l][(ny * 7 + tw) & 63];
+      if (my.key == ykey) { th = my.th; tiles_y = my.tiles_y; }
+      else {
+        int tw2;
+        ragged_tile(d, nx, ny, th_lds[l], &tw2, &th);
+        tiles_y = (ny + th - 1) / th;
+        my.key = ykey; my.th = (uint16_t)th; my.tiles_y = (uint16_t)tiles_y;
+      }
+      cu.tw = (uint16_t)tw; cu.th = (uint16_t)th; cu.tiles_x = (uint16_t)(mx >> 16); cu.tiles_y = (uint16_t)tiles_y;
+      const long long tiles = (long long)cu.tiles_x * tiles_y;
+      n_blk += tiles;
+      th_max[l] = std::max<int>(th_max[l], th); win_max[l] = std::max<int>(win_max[l], tw * th);
+      if (d.tiled == 1) lds_blocks += tiles;
+    }
+  }
+  if (n_blk > 0x7fffffffLL) { fail("ragged chunk has too many tiles"); return false; }
+  ch->n_blk = (int)n_blk;
+  ch->table_bytes = align_up(ch->off_blk + (size_t)n_blk * sizeof(RagBlk), 256);
+  if (ch->table_bytes > ln->h_tab.bytes || ch->table_bytes > ln->rag_tab.bytes) {
+    // (more tiles than ragged_build_images left room for: the buffers move.  What has been queued from / into them
+    // finishes first, the pinned copy keeps its image records, and the pass uploads everything again)
+    if (ch->images_issued) { if (hipStreamSynchronize(ln->stream) != hipSuccess) { fail("hipStreamSynchronize failed"); return false; } }
+    ch->images_issued = false;
+    if (!ln->h_tab.reserve(ch->table_bytes, ch->off_segs) || !ln->rag_tab.reserve(ch->table_bytes)) return false;
+  }
+  uint8_t* tab = (uint8_t*)ln->h_tab.p;
+  RagSeg* segs = (RagSeg*)(tab + ch->off_segs);
+  RagBlk* blk = (RagBlk*)(tab + ch->off_blk);
+  const unsigned long long* img_off = (const unsigned long long*)(tab + ch->off_imgoff);
+  // ---- segments ----
+  std::vector<int> seg_first(n + 1, 0);
+  int si = 0;
+  for (int i = 0; i < n; i++) {
+    long long gid = ch->gid_base[i];
+    seg_first[i] = si;
+    const uint32_t gi = job.geo_first[i0 + i];
+    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
+      const DevLevel& d = hp.lv[l];
+      const Cut& cu = cuts[gi - geo0 + l];
+      RagSeg& sg = segs[si++];
+      sg.img_off = img_off[i]; sg.gid_base = (uint32_t)gid;
+      sg.nx = job.gnx[gi + l]; sg.ny = job.gny[gi + l];
+      sg.tw = cu.tw; sg.th = cu.th;
+      sg.tiles_x = cu.tiles_x;
+      sg.level = (uint16_t)l; sg.image = (uint16_t)i; sg.pad0 = 0; sg.pad1 = 0;
+      sg.win = d.win; sg.step = d.step; sg.pitch = d.pitch; sg.s0_table = d.s0_table; sg.tiled = d.tiled;
+      sg.pad2 = sg.pad3 = sg.pad4 = 0;
+      gid += (long long)sg.nx * sg.ny;
+    }
+  }
+  seg_first[n] = si;
   // ---- block map and launches: one launch per LDS-tiled level (all of them in one when the chunk is small), one for
   //      the big-window LDS levels, one for the global-pixel levels.  Inside a launch the tiles of 8 images interleave,
   //      so that an image's tiles mostly land on one XCD's L2 (block b -> XCD b % 8). ----
@@ -242,8 +340,8 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
       for (int i = g0; i < ge; i++) {
         tiles[i - g0] = 0; seg[i - g0] = -1;
         if (l < job.n_lv[i0 + i]) {
-          const RagSeg& sg = segs[seg_first[i] + l];
-          tiles[i - g0] = (int)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
+          const Cut& cu = cuts[seg_first[i] + l];
+          tiles[i - g0] = (int)cu.tiles_x * cu.tiles_y;
           seg[i - g0] = seg_first[i] + l;
           most = std::max(most, tiles[i - g0]);
         }
@@ -254,16 +352,6 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     }
   };
   auto emit_level = [&](int l) { for (int g0 = 0; g0 < n; g0 += 8) emit_group(l, g0); };
-  // pixel bytes / windows of the largest tile any image of the chunk cut from level l
-  int th_max[kMaxLevels], win_max[kMaxLevels];
-  for (int l = 0; l < nl; l++) { th_max[l] = 1; win_max[l] = 1; }
-  long long lds_blocks = 0;
-  for (int i = 0; i < n; i++)
-    for (int l = 0; l < job.n_lv[i0 + i]; l++) {
-      const RagSeg& sg = segs[seg_first[i] + l];
-      th_max[l] = std::max<int>(th_max[l], sg.th); win_max[l] = std::max<int>(win_max[l], (int)sg.tw * sg.th);
-      if (hp.lv[l].tiled == 1) lds_blocks += (long long)sg.tiles_x * ((sg.ny + sg.th - 1) / sg.th);
-    }
   auto pix_of = [&](int l) { const DevLevel& d = hp.lv[l]; return d.pitch * (d.win + (th_max[l] - 1) * d.step); };
   const bool small = lds_blocks <= c->kn.merge_blocks;
   auto merged = [&](int mode) {
@@ -284,8 +372,22 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
   // (its single-level launches are what k_scan_p takes).
   const long long merge_knob = c->kn.ragged_merge;
   const bool merge_classes = merge_knob < 0 ? job.cpp : merge_knob != 0;
+  // Dialect C: the levels the persistent scan will take stay launches of their own; what it leaves to k_scan's closed
+  // tiles (the 71- and 88-pixel levels: too few slots) shares launches per occupancy class like dialect CPP's levels do.
+  bool own_launch[kMaxLevels];
+  for (int l = 0; l < nl; l++) own_launch[l] = false;
+  const bool merge_rest = !merge_classes && !job.cpp;        // (r06, a 356-image job: two closed-tile launches 176 -> one of 156 us; the 2,845-image job equal)
+  if (merge_rest) {
+    long long tiles_of[kMaxLevels];
+    for (int l = 0; l < nl; l++) tiles_of[l] = 0;
+    for (int i = 0; i < n; i++) {
+      const uint32_t gi = job.geo_first[i0 + i] - geo0;
+      for (int l = 0; l < job.n_lv[i0 + i]; l++) tiles_of[l] += (long long)cuts[gi + l].tiles_x * cuts[gi + l].tiles_y;
+    }
+    for (int l = 0; l < nl; l++) own_launch[l] = hp.lv[l].tiled == 1 && scan_p_takes_ragged(c, pix_of(l), tiles_of[l]);
+  }
   if (small) merged(1);
-  else if (merge_classes) {
+  else if (merge_classes || merge_rest) {
     const HostModel& hm = c->hm;
     const int rb = job.real_bytes();
     const int chunk = std::min(std::min(hm.K, (int)c->kn.handoff), scan_handoff_cap(hm.node_n(), hm.leaf_n(), rb));
@@ -294,8 +396,16 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
     for (int l = 0; l < nl; l++) {
       cls[l] = -1; any[l] = false;
       if (hp.lv[l].tiled != 1) continue;
+      if (own_launch[l]) {
+        RaggedChunk::Launch L{1, win_max[l] > 256 ? 512 : 256, pix_of(l), bi, 0};
+        L.level = l;
+        emit_level(l);
+        L.blk_n = bi - L.blk_base;
+        if (L.blk_n > 0) ch->launches.push_back(L);
+        continue;
+      }
       const int lds = (int)scan_lds_bytes(pix_of(l), chunk, hm.node_n(), hm.leaf_n(), rb, false, win_max[l] > 256 ? 512 : 256);
-      cls[l] = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
+      cls[l] = std::max(1, std::min(8, lds_wgs_per_cu(lds)));
     }
     for (int i = 0; i < n; i++) for (int l = 0; l < job.n_lv[i0 + i]; l++) any[l] = true;
     for (int k = 8; k >= 1; k--) {
@@ -327,8 +437,12 @@ static bool ragged_build_chunk(Cascador* c, const RaggedJob& job, int i0, int n,
 }
 
 // NMS, relocation and the jdaResult of every image of a ragged chunk (dets sorted by gid = image, level, y, x).
+// rows != nullptr (jdaDetectBatchRagged[Device]Rows): no jdaResult per image -- three allocations each, 1,065 for a
+// 355-image job whose 1,170 detections are 270 KB -- but one row [frame_offset + image index, x, y, size, score, shape]
+// per detection appended to *rows, images in order (what jdaResultsPack makes of the jdaResults, what the multi-GPU
+// gather ships).
 static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets,
-                          const jdaDetectOptions* opt, jdaResult* out) {
+                          const jdaDetectOptions* opt, jdaResult* out, RowsOut<float>* rows = nullptr, int frame_offset = 0) {
   const double t0 = now_ms();
   const int L = c->hm.L, dim = c->hm.dim();
   const bool do_nms = !opt || opt->nms;
@@ -344,10 +458,9 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
     first[ch.n] = i;
   }
   const bool some_posted = dets.p_n.size() == (size_t)ch.n;
-  parallel_for(ch.n, [&](int f) {
+  auto one = [&](int f, jdaResult& r) {
     if (some_posted && dets.p_n[f] >= 0) {           // post-processed on the device (k_post)
       const size_t k = (size_t)dets.p_n[f], r0 = (size_t)dets.p_first[f];
-      jdaResult& r = out[f];
       r.n = (int)k; r.landmark_n = L;
       r.bboxes = (int*)std::malloc(std::max<size_t>(1, k * 3) * sizeof(int));
       r.scores = (float*)std::malloc(std::max<size_t>(1, k) * sizeof(float));
@@ -381,7 +494,6 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
     }
     if (do_nms) nms_dialect_c_into(bb.data(), dets.score.data() + a, (int)cnt, overlap, &keep);
     else { keep.resize(cnt); std::iota(keep.begin(), keep.end(), 0); }
-    jdaResult& r = out[f];
     r.n = (int)keep.size(); r.landmark_n = L;
     r.bboxes = (int*)std::malloc(std::max<size_t>(1, keep.size() * 3) * sizeof(int));
     r.scores = (float*)std::malloc(std::max<size_t>(1, keep.size()) * sizeof(float));
@@ -394,14 +506,41 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
       std::memcpy(sh, &dets.shape[(a + k) * dim], dim * sizeof(float));
       relocate_dialect_c(sh, L, bb[3 * k], bb[3 * k + 1], bb[3 * k + 2]);
     }
-  }, dets.gid.size() < 6000);
+  };
+  if (rows) {
+    const size_t rw = (size_t)5 + dim;
+    for (int f = 0; f < ch.n; f++) {
+      const float fr = (float)(frame_offset + ch.i0 + f);
+      if (some_posted && dets.p_n[f] >= 0) {         // straight from what k_post left in pinned memory
+        const size_t k = (size_t)dets.p_n[f], r0 = (size_t)dets.p_first[f];
+        float* o = rows->grow(k * rw);
+        for (size_t j = 0; j < k; j++, o += rw) {
+          o[0] = fr; o[1] = (float)dets.p_bb[(r0 + j) * 3]; o[2] = (float)dets.p_bb[(r0 + j) * 3 + 1]; o[3] = (float)dets.p_bb[(r0 + j) * 3 + 2];
+          o[4] = dets.p_sc[r0 + j];
+          std::memcpy(o + 5, &dets.p_sh[(r0 + j) * dim], dim * sizeof(float));
+        }
+        continue;
+      }
+      jdaResult r{};
+      one(f, r);
+      float* o = rows->grow((size_t)r.n * rw);
+      for (int j = 0; j < r.n; j++, o += rw) {
+        o[0] = fr; o[1] = (float)r.bboxes[3 * j]; o[2] = (float)r.bboxes[3 * j + 1]; o[3] = (float)r.bboxes[3 * j + 2];
+        o[4] = r.scores[j];
+        std::memcpy(o + 5, r.shapes + (size_t)j * dim, dim * sizeof(float));
+      }
+      std::free(r.bboxes); std::free(r.scores); std::free(r.shapes);
+    }
+    return now_ms() - t0;
+  }
+  parallel_for(ch.n, [&](int f) { one(f, out[f]); }, dets.gid.size() < 6000);
   return now_ms() - t0;
 }
 
 // The same for dialect CPP: candidates of an image in scan order -> Rect(x, y, win, win) (cascador.cpp:339), NMS by score
 // (cascador.cpp:387-429), relocation (462-474), jdaResultD.
 static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<double>& dets,
-                          const CppCall& call, jdaResultD* out) {
+                          const CppCall& call, jdaResultD* out, RowsOut<double>* rows = nullptr, int frame_offset = 0) {
   const double t0 = now_ms();
   const int L = c->hm.L, dim = c->hm.dim();
   const DevPlan& hp = job.pe->hp;
@@ -414,9 +553,9 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
     }
     first[ch.n] = i;
   }
-  parallel_for(ch.n, [&](int f) {
+  // candidates of image f in scan order -> Rect(x, y, win, win) (cascador.cpp:339)
+  auto rects_of = [&](int f, std::vector<int>& rc) {
     const size_t a = first[f], cnt = first[f + 1] - a;
-    static thread_local std::vector<int> rc;
     rc.resize(cnt * 4);
     const int W = ch.widths[f], H = ch.heights[f];
     int l = 0;
@@ -436,6 +575,39 @@ static double post_ragged(Cascador* c, const RaggedJob& job, const RaggedChunk& 
       rc[4 * i] = (int)(rel % (uint32_t)nx) * d.step; rc[4 * i + 1] = (int)(rel / (uint32_t)nx) * d.step;
       rc[4 * i + 2] = d.win; rc[4 * i + 3] = d.win;
     }
+  };
+  if (rows) {
+    // rows mode: NMS per image in parallel (the picks), then every image's rows written in place, in parallel
+    std::vector<std::vector<int>> rcs((size_t)ch.n), picks((size_t)ch.n);
+    parallel_for(ch.n, [&](int f) {
+      const size_t a = first[f], cnt = first[f + 1] - a;
+      rects_of(f, rcs[(size_t)f]);
+      if (call.nms != 0) picks[(size_t)f] = nms_dialect_cpp(rcs[(size_t)f].data(), dets.score.data() + a, (int)cnt, call.overlap);   // cascador.cpp:444-446
+      else { picks[(size_t)f].resize(cnt); std::iota(picks[(size_t)f].begin(), picks[(size_t)f].end(), 0); }                         // cascador.cpp:447-451
+    }, dets.gid.size() < 6000);
+    std::vector<size_t> row0((size_t)ch.n + 1, 0);
+    for (int f = 0; f < ch.n; f++) row0[(size_t)f + 1] = row0[(size_t)f] + picks[(size_t)f].size();
+    const size_t rw = (size_t)6 + dim;
+    double* base = rows->grow(row0[(size_t)ch.n] * rw);
+    parallel_for(ch.n, [&](int f) {
+      const size_t a = first[f];
+      const std::vector<int>& rc = rcs[(size_t)f];
+      double* o = base + row0[(size_t)f] * rw;
+      for (int k : picks[(size_t)f]) {
+        o[0] = (double)(frame_offset + ch.i0 + f);
+        for (int q = 0; q < 4; q++) o[1 + q] = (double)rc[4 * (size_t)k + q];
+        o[5] = dets.score[a + k];
+        std::memcpy(o + 6, dets.shape.data() + (a + k) * dim, dim * sizeof(double));
+        relocate_dialect_cpp(o + 6, L, rc[4 * (size_t)k], rc[4 * (size_t)k + 1], rc[4 * (size_t)k + 2], rc[4 * (size_t)k + 3]);   // cascador.cpp:462-474
+        o += rw;
+      }
+    }, row0[(size_t)ch.n] < 2000);
+    return now_ms() - t0;
+  }
+  parallel_for(ch.n, [&](int f) {
+    const size_t a = first[f], cnt = first[f + 1] - a;
+    static thread_local std::vector<int> rc;
+    rects_of(f, rc);
     emit_cpp_result(rc.data(), dets.score.data() + a, dets.shape.data() + a * dim, (int)cnt, L, call.overlap, call.nms != 0, &out[f]);
   }, dets.gid.size() < 6000);
   return now_ms() - t0;
@@ -453,6 +625,8 @@ static void add_stats(RunStats* a, const RunStats& b) {
 struct RagSideC {
   using Real = float; using Result = jdaResult;
   float scale; int min_size, max_size; float th; const jdaDetectOptions* opt; jdaResult* out;
+  RowsOut<float>* rows = nullptr; int frame_offset = 0;      // rows mode (post_ragged): `out` is the caller's scratch, left blank
+  bool rows_mode() const { return rows != nullptr; }
   jdaStats* stats() const { return opt ? opt->stats : nullptr; }
   bool apply_th() const { return true; }
   Real final_th() const { return th; }
@@ -470,7 +644,7 @@ struct RagSideC {
     return host ? detect_c_device(c, nullptr, 0, 1, W, H, scale, min_size, max_size, th, &o1, out + i, one)
                 : detect_c_device(c, dev, (size_t)W * H, 1, W, H, scale, min_size, max_size, th, &o1, out + i);
   }
-  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets) const { return post_ragged(c, job, ch, dets, opt, out + ch.i0); }
+  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<float>& dets) const { return post_ragged(c, job, ch, dets, opt, out + ch.i0, rows, frame_offset); }
   bool device_post(Cascador* c, int n_imgs) const { return c->kn.device_post >= 1 && n_imgs >= c->kn.device_post_min_frames; }
   bool post_nms() const { return !opt || opt->nms; }
   float post_overlap() const { return opt ? opt->nms_overlap : 0.3f; }
@@ -485,13 +659,15 @@ struct RagSideCpp {
   bool filled(int i) const { return out[i].rects != nullptr; }
   void set_empty(int i, int L) const { out[i] = empty_result_d(L); }
   void describe(RaggedJob* job) const { job->cpp = true; job->call = call; }
+  RowsOut<double>* rows = nullptr; int frame_offset = 0;     // rows mode (post_ragged): `out` is the caller's scratch, left blank
+  bool rows_mode() const { return rows != nullptr; }
   bool usable(Cascador* c) const { return cpp_model_complete(c); }
   int one_image(Cascador* c, const unsigned char* host, const uint8_t* dev, int W, int H, jdaStats* st1, int i) const {
     const unsigned char* one[1] = {host};
     return host ? detect_cpp_device(c, nullptr, 0, 1, W, H, call, st1, out + i, one)
                 : detect_cpp_device(c, dev, (size_t)W * H, 1, W, H, call, st1, out + i);
   }
-  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<double>& dets) const { return post_ragged(c, job, ch, dets, call, out + ch.i0); }
+  double post(Cascador* c, const RaggedJob& job, const RaggedChunk& ch, const RawDets<double>& dets) const { return post_ragged(c, job, ch, dets, call, out + ch.i0, rows, frame_offset); }
   bool device_post(Cascador*, int) const { return false; }  // (k_post is dialect C's NMS; the multimap NMS runs on the host)
   bool post_nms() const { return call.nms != 0; }
   float post_overlap() const { return (float)call.overlap; }
@@ -512,7 +688,8 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     std::lock_guard<std::mutex> lk(c->mu);
     if (!ensure_device(c) || !upload_model<Real>(c)) return -1;
   }
-  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: device and model ready at %.3f ms\n", now_ms() - t_call);
+  if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged job: device and model ready at %.3f ms\n", now_ms() - t_call);
+  double tm[6] = {now_ms() - t_call, 0, 0, 0, 0, 0};     // debug_times = 2: one line at the end (prints cost tens of microseconds each)
   RunStats total;
   long long patch_n = 0;
   double post_ms = 0;
@@ -545,11 +722,12 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   side.describe(&job);
   const int prep = ragged_prepare(c, &job);
   PlanPin pin{c, job.pe};
-  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: prepared at %.3f ms\n", now_ms() - t_call);
+  tm[1] = now_ms() - t_call;
+  if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged job: prepared at %.3f ms\n", now_ms() - t_call);
   if (prep < 0) return -1;
   if (prep > 0) return fallback();
   if (job.levels.levels.empty()) {                                // no image holds a window: n empty results
-    for (int i = 0; i < n; i++) side.set_empty(i, L);
+    for (int i = 0; i < n && !side.rows_mode(); i++) side.set_empty(i, L);
     return finish();
   }
 
@@ -571,14 +749,11 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
   std::vector<int> starts;
   {
     long long wsum = 0; int cnt = 0;
-    std::vector<long long> wins((size_t)n);
+    const std::vector<long long>& wins = job.wins;
     long long total = 0;
     for (int i = 0; i < n; i++) {
-      long long wi = 0;
-      for (int l = 0; l < job.n_lv[i]; l++)
-        wi += (long long)((widths[i] - hp.lv[l].win) / hp.lv[l].step + 1) * ((heights[i] - hp.lv[l].win) / hp.lv[l].step + 1);
-      if (wi > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
-      wins[(size_t)i] = wi; total += wi;
+      if (wins[(size_t)i] > 0x7fffffffLL) { fail("image has too many windows"); return -1; }
+      total += wins[(size_t)i];
     }
     // A chunk is at most ragged_chunk_windows; a job of fewer than three such chunks is cut into three (down to
     // ragged_chunk_min_windows each), so that its lanes overlap too: the scan of one chunk next to the latency-bound
@@ -730,8 +905,23 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     sl.dets = RawDets<Real>(); sl.rs = RunStats(); sl.rs.timed = side.stats() != nullptr;
     Lane* ln = held.v[lane];
     const double t_b = now_ms();
+    if (!ragged_build_images(job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
+    if (sl.ch.windows > 0 && !job.host_imgs) {
+      // images resident on the device: their records go up and k_repack starts NOW, the segments and the block map --
+      // most of the table-building time -- are built while it runs (r06: 35 us off a 356-image job's critical path)
+      const bool timed = side.stats() != nullptr || c->kn.debug_times;
+      const RaggedChunk& ch = sl.ch;
+      uint8_t* tab = (uint8_t*)ln->rag_tab.p;
+      if ((timed && hipEventRecord(ln->ev[0], ln->stream) != hipSuccess) ||
+          hipMemcpyAsync(tab, ln->h_tab.p, ch.images_bytes, hipMemcpyHostToDevice, ln->stream) != hipSuccess ||
+          launch_repack(ch.d_raw, (uint8_t*)ln->rag_frames.p, (const RagImg*)(tab + ch.off_rimg), ch.n, ch.max_h, ch.pitch, ln->stream) != hipSuccess) {
+        fail(std::string("queueing the images of a ragged chunk failed: ") + hipGetErrorString(hipGetLastError())); ok = false; break;
+      }
+      sl.ch.images_issued = true;
+    }
     if (!ragged_build_chunk(c, job, starts[ci], starts[ci + 1] - starts[ci], ln, &sl.ch)) { ok = false; break; }
-    if (c->kn.debug_times) fprintf(stderr, "[jda] ragged chunk %d: tables built %.3f..%.3f ms (%d blocks, %d segments)\n", ci, t_b - t_call, now_ms() - t_call, sl.ch.n_blk, sl.ch.n_segs);
+    tm[2] = now_ms() - t_call;
+    if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged chunk %d: tables built %.3f..%.3f ms (%d blocks, %d segments)\n", ci, t_b - t_call, now_ms() - t_call, sl.ch.n_blk, sl.ch.n_segs);
     if (sl.ch.windows == 0) {                        // images too small for any window
       post_ms += side.post(c, job, sl.ch, sl.dets);
       continue;
@@ -767,7 +957,8 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     if (!p.issue_scan(nullptr, 0, nullptr, 0, nullptr)) { ok = false; break; }
     sl.busy = true;
   }
-  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: all chunks issued at %.3f ms\n", now_ms() - t_call);
+  tm[3] = now_ms() - t_call;
+  if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged job: all chunks issued at %.3f ms\n", now_ms() - t_call);
   // drain in chunk order
   for (int k = 0; k < lanes && ok; k++) {
     Slot& sl = slots[(n_chunks + k) % lanes];
@@ -777,9 +968,11 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
     for (Lane* l : held.v) (void)hipStreamSynchronize(l->stream);
     return -1;
   }
-  for (int i = 0; i < n; i++)
+  for (int i = 0; i < n && !side.rows_mode(); i++)
     if (!side.filled(i)) side.set_empty(i, L);     // (chunks fill every image; belt and braces)
-  if (c->kn.debug_times) fprintf(stderr, "[jda] ragged job: done at %.3f ms (post-processing %.3f ms of it)\n", now_ms() - t_call, post_ms);
+  if (c->kn.debug_times == 1) fprintf(stderr, "[jda] ragged job: done at %.3f ms (post-processing %.3f ms of it)\n", now_ms() - t_call, post_ms);
+  if (c->kn.debug_times >= 2) fprintf(stderr, "[jda] ragged job: ready %.3f prepared %.3f last tables %.3f issued %.3f done %.3f ms (post %.3f; prepare: levels %.3f grids %.3f plan %.3f)\n", tm[0], tm[1], tm[2], tm[3], now_ms() - t_call, post_ms,
+                                       t_prep_marks[0] - t_call, t_prep_marks[1] - t_call, t_prep_marks[2] - t_call);
   return finish();
 }
 
@@ -787,6 +980,66 @@ int detect_ragged(Cascador* c, const unsigned char* const* host_imgs, const uint
                   const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
                   const jdaDetectOptions* opt, jdaResult* out) {
   return detect_ragged_t(c, host_imgs, d_base, d_offsets, widths, heights, n, RagSideC{scale, min_size, max_size, th, opt, out});
+}
+
+// The same job with the results as one matrix of rows (jdaDetectBatchRagged[Device]Rows).  Jobs that run image by image
+// inside (multi-scale models, dense cascades) fill the scratch results; they are packed here.
+int detect_ragged_rows(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                       const int* widths, const int* heights, int n, float scale, int min_size, int max_size, float th,
+                       const jdaDetectOptions* opt, int frame_offset, RowsOut<float>* rows) {
+  std::vector<jdaResult> scratch((size_t)std::max(n, 1));
+  RagSideC side{scale, min_size, max_size, th, opt, scratch.data()};
+  side.rows = rows; side.frame_offset = frame_offset;
+  rows->n = 0;
+  const int rc = detect_ragged_t(c, host_imgs, d_base, d_offsets, widths, heights, n, side);
+  bool any = false;
+  for (int i = 0; i < n; i++) any = any || scratch[(size_t)i].bboxes != nullptr;
+  if (any && rc == 0) {                              // (the per-image fallback ran: nothing has been appended yet)
+    rows->n = 0;
+    const int dim = c->hm.dim();
+    for (int i = 0; i < n; i++) {
+      const jdaResult& r = scratch[(size_t)i];
+      for (int j = 0; j < r.n && r.bboxes; j++) {
+        float* o = rows->grow(5 + (size_t)dim);
+        o[0] = (float)(frame_offset + i); o[1] = (float)r.bboxes[3 * j]; o[2] = (float)r.bboxes[3 * j + 1]; o[3] = (float)r.bboxes[3 * j + 2];
+        o[4] = r.scores[j];
+        std::memcpy(o + 5, r.shapes + (size_t)j * dim, dim * sizeof(float));
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) { std::free(scratch[(size_t)i].bboxes); std::free(scratch[(size_t)i].shapes); std::free(scratch[(size_t)i].scores); }
+  return rc;
+}
+
+// Dialect CPP (jdaDetectBatchCppRagged[Device]Rows): rows [frame, x, y, w, h, score, shape] of doubles -- a job of 2,845
+// FDDB-sized images keeps 32 k candidates, 15 MB of rows: through n jdaResultDs and jdaResultsDPack they were copied
+// three times and cost the binding 4.3 ms of a 38-ms job.
+int detect_ragged_cpp_rows(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,
+                           const int* widths, const int* heights, int n, const CppCall& call, jdaStats* stats, int frame_offset,
+                           RowsOut<double>* rows) {
+  std::vector<jdaResultD> scratch((size_t)std::max(n, 1));
+  RagSideCpp side{call, stats, scratch.data()};
+  side.rows = rows; side.frame_offset = frame_offset;
+  rows->n = 0;
+  const int rc = detect_ragged_t(c, host_imgs, d_base, d_offsets, widths, heights, n, side);
+  bool any = false;
+  for (int i = 0; i < n; i++) any = any || scratch[(size_t)i].rects != nullptr;
+  if (any && rc == 0) {                              // (the per-image fallback ran)
+    rows->n = 0;
+    const int dim = c->hm.dim();
+    for (int i = 0; i < n; i++) {
+      const jdaResultD& r = scratch[(size_t)i];
+      for (int j = 0; j < r.n && r.rects; j++) {
+        double* o = rows->grow(6 + (size_t)dim);
+        o[0] = (double)(frame_offset + i);
+        for (int k = 0; k < 4; k++) o[1 + k] = (double)r.rects[4 * j + k];
+        o[5] = r.scores[j];
+        std::memcpy(o + 6, r.shapes + (size_t)j * dim, dim * sizeof(double));
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) { std::free(scratch[(size_t)i].rects); std::free(scratch[(size_t)i].shapes); std::free(scratch[(size_t)i].scores); }
+  return rc;
 }
 
 int detect_ragged_cpp(Cascador* c, const unsigned char* const* host_imgs, const uint8_t* d_base, const size_t* d_offsets,

@@ -21,6 +21,36 @@ def shard_range(n_items, rank, world):
     return lo, hi
 
 
+def shard_range_weighted(weights, rank, world):
+    """Contiguous block of items owned by `rank` when item i costs weights[i] (candidate windows of image i): the
+    boundaries sit where the running sum crosses rank / world of the total, so every rank gets about the same work and
+    the blocks still partition [0, n) in order.  Every rank computes the same boundaries from the same weights.
+    (Images of a ragged job differ in size: equal COUNTS gave the eight shards of the FDDB-shaped job 4.09 M to 4.40 M
+    windows; the job takes as long as its slowest shard.)"""
+    w = np.asarray(weights, np.float64)
+    n = len(w)
+    if n == 0 or world <= 1:
+        return (0, n) if rank == 0 else (n, n)
+    cs = np.cumsum(w)
+    total = float(cs[-1])
+    if total <= 0:
+        return shard_range(n, rank, world)
+
+    def bound(r):
+        if r <= 0:
+            return 0
+        if r >= world:
+            return n
+        # first item whose END lies beyond the target: the item that straddles a boundary goes to the side holding more of it
+        t = total * r / world
+        i = int(np.searchsorted(cs, t, side="left"))
+        if i < n and (cs[i] - t) < (t - (cs[i] - w[i])):
+            i += 1
+        return min(i, n)
+    lo, hi = bound(rank), bound(rank + 1)
+    return lo, max(lo, hi)
+
+
 def pack_detections(results, landmark_n, frame_offset=0):
     """Per-frame result dicts -> one float32 matrix, a row per detection:
     [frame, x, y, size, score, shape(2L)].  Integers up to 2^24 are exact in

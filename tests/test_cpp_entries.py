@@ -185,3 +185,60 @@ def test_cpp_ragged_fddb_shaped_job_on_the_shipped_dimensions(built, gpu):
     for i in (0, 41, 95):
         _eq(got[i], o.detect_cpp(imgs[i]), i)
     assert sum(len(g["scores"]) for g in got) > 0
+
+
+def _pack_d(results, L, frame_offset=0):
+    """What jdaResultsDPack makes of per-image results: rows [frame, x, y, w, h, score, shape...] of doubles."""
+    rows = []
+    for i, r in enumerate(results):
+        n = len(r["scores"])
+        if n:
+            m = np.empty((n, 6 + 2 * L), np.float64)
+            m[:, 0] = frame_offset + i; m[:, 1:5] = r["rects"]; m[:, 5] = r["scores"]; m[:, 6:] = r["shapes"]
+            rows.append(m)
+    return np.concatenate(rows) if rows else np.empty((0, 6 + 2 * L), np.float64)
+
+
+def test_cpp_ragged_rows_entries_equal_the_packed_results(built, gpu, model_file):
+    """jdaDetectBatchCppRagged[Device]Rows: the job's rows, written in place by the library (per-image NMS in parallel,
+    rows of an image at its prefix offset), must be bit for bit what the per-image jdaResultDs pack to -- several
+    chunks, NMS on and off, a frame offset, host and device images, an empty job, images below the minimum window, and
+    a multi-scale model (per-image fallback inside)."""
+    import torch
+    from jda_amd import api
+    p, _ = model_file((3, 70, 9, 5), 8, seed=71, cart_th=-0.9, norm_every=9)
+    rng = np.random.default_rng(14)
+    sizes = [(int(rng.integers(15, 260)), int(rng.integers(15, 200))) for _ in range(43)]
+    imgs = _images(sizes, seed=21)
+    offs, tot = [], 0
+    for im in imgs:
+        offs.append(tot); tot += im.size
+    buf = np.concatenate([im.reshape(-1) for im in imgs])
+    d_buf = torch.from_numpy(buf).to(gpu)
+    ws, hs = np.array([s[0] for s in sizes], np.int32), np.array([s[1] for s in sizes], np.int32)
+    offs = np.array(offs, np.uint64)
+    c = api.Cascador(p)
+    assert hasattr(api.lib, "jdaDetectBatchCppRaggedDeviceRows")
+    n_rows = 0
+    for chunk in (6000000, 50000):
+        c.set_option("ragged_chunk_windows_cpp", chunk)
+        for nms in (True, False):
+            want = _pack_d(c.detect_ragged_cpp_packed(buf, offs, ws, hs, nms=nms), c.L, frame_offset=11)
+            for src in (buf, d_buf):
+                rows = c.detect_ragged_cpp_packed(src, offs, ws, hs, nms=nms, keep_results="packed", frame_offset=11)
+                assert rows.dtype == np.float64 and same(np.array(rows), want), (chunk, nms, rows.shape, want.shape)
+            n_rows = max(n_rows, len(want))
+    assert n_rows > 0
+    kept = c.detect_ragged_cpp_packed(d_buf, offs, ws, hs, keep_results="packed")      # the array owns the library's buffer
+    view = kept[len(kept) // 2:]
+    ref = np.array(kept, copy=True)
+    del kept
+    assert same(np.array(view), ref[len(ref) // 2:])
+    assert c.detect_ragged_cpp_packed(d_buf, offs[:0], ws[:0], hs[:0], keep_results="packed").shape == (0, 6 + 2 * c.L)
+    tiny = _images([(19, 60), (12, 12)])
+    tb = np.concatenate([t.reshape(-1) for t in tiny])
+    assert c.detect_ragged_cpp_packed(tb, [0, 19 * 60], [19, 12], [60, 12], keep_results="packed").shape == (0, 6 + 2 * c.L)
+    pm, _ = model_file((2, 8, 5, 3), 8, seed=9, cart_th=-0.5, multi_scale=True)
+    cm = api.Cascador(pm)
+    want = _pack_d(cm.detect_ragged_cpp_packed(buf, offs, ws, hs), cm.L, frame_offset=3)
+    assert same(np.array(cm.detect_ragged_cpp_packed(buf, offs, ws, hs, keep_results="packed", frame_offset=3)), want)

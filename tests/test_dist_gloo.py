@@ -25,6 +25,26 @@ def test_shard_range_partitions_everything():
     assert sum(sizes) == 2845 and max(sizes) - min(sizes) <= 1
 
 
+def test_shard_range_weighted_partitions_everything_and_balances():
+    from jda_amd import dist as jd
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 7, 256, 2845):
+        w = rng.integers(1, 1000, n)
+        for world in (1, 2, 3, 8):
+            covered, sums = [], []
+            for r in range(world):
+                lo, hi = jd.shard_range_weighted(w, r, world)
+                assert 0 <= lo <= hi <= n
+                covered += list(range(lo, hi)); sums.append(int(w[lo:hi].sum()))
+            assert covered == list(range(n))
+            if n >= 256:                                  # no block is further from the mean than one item's weight
+                assert max(sums) - min(sums) <= 2 * int(w.max())
+    # all-zero weights fall back to equal counts; a single heavy item does not lose the others
+    assert [jd.shard_range_weighted([0, 0, 0, 0], r, 2) for r in range(2)] == [(0, 2), (2, 4)]
+    b = [jd.shard_range_weighted([1, 1, 100, 1, 1], r, 2) for r in range(2)]
+    assert b[0][0] == 0 and b[0][1] == b[1][0] and b[1][1] == 5
+
+
 def test_pack_unpack_roundtrip():
     from jda_amd import dist as jd
     rng = np.random.default_rng(0)

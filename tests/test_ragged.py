@@ -205,3 +205,47 @@ def test_ragged_chunks_through_the_persistent_scan(built, gpu, model_file, monke
     # second job (the finishing launches are sized by prediction now), NMS off
     for x, y in zip(on.detect_ragged(imgs, nms=False), off.detect_ragged(imgs, nms=False)):
         _eq(x, y, "second job")
+
+
+def test_ragged_rows_entries_equal_the_packed_results(built, gpu, model_file, monkeypatch):
+    """jdaDetectBatchRagged[Device]Rows: the job's detections as one matrix of rows must be, bit for bit, what
+    jdaResultsPack makes of the n jdaResults of the same job -- device-post-processed chunks (k_post), chunks too
+    small for it (host NMS), several chunks, NMS off, a frame offset, an empty job, images without a window."""
+    import torch
+    from jda_amd import api, dist as jd
+    p, _ = model_file((3, 70, 9, 5), 8, seed=71, cart_th=-0.9, norm_every=9)
+    rng = np.random.default_rng(8)
+    sizes = [(int(rng.integers(30, 260)), int(rng.integers(30, 200))) for _ in range(45)]
+    imgs = _images(sizes, seed=13)
+    offs, tot = [], 0
+    for im in imgs:
+        offs.append(tot); tot += im.size
+    buf = np.concatenate([im.reshape(-1) for im in imgs])
+    ws, hs = np.array([s[0] for s in sizes], np.int32), np.array([s[1] for s in sizes], np.int32)
+    offs = np.array(offs, np.uint64)
+    d_buf = torch.from_numpy(buf).to(gpu)
+    c = api.Cascador(p)
+    assert hasattr(api.lib, "jdaDetectBatchRaggedDeviceRows")
+    for chunk in (6000000, 30000):
+        c.set_option("ragged_chunk_windows", chunk)
+        for nms in (True, False):
+            res = c.detect_ragged_packed(buf, offs, ws, hs, nms=nms)                       # n jdaResults
+            want = jd.pack_detections(res, c.L, frame_offset=100)
+            for src in (buf, d_buf):
+                rows, st = c.detect_ragged_packed(src, offs, ws, hs, nms=nms, keep_results="packed", frame_offset=100, stats=True)
+                assert rows.dtype == np.float32 and same(rows, want), (chunk, nms, rows.shape, want.shape)
+                assert st["patch_n"] == sum(api.count_windows(w, h)[0] for w, h in sizes)
+    assert len(want) > 0
+    # few images: below device_post_min_frames the host post-processes; none: an empty matrix
+    few = c.detect_ragged_packed(d_buf, offs[:5], ws[:5], hs[:5], keep_results="packed")
+    assert same(few, jd.pack_detections(c.detect_ragged_packed(d_buf, offs[:5], ws[:5], hs[:5]), c.L))
+    none = c.detect_ragged_packed(d_buf, offs[:0], ws[:0], hs[:0], keep_results="packed")
+    assert none.shape == (0, 5 + 2 * c.L)
+    tiny = _images([(20, 20), (30, 39)])
+    tb = np.concatenate([t.reshape(-1) for t in tiny])
+    assert c.detect_ragged_packed(tb, [0, 400], [20, 30], [20, 39], keep_results="packed").shape == (0, 5 + 2 * c.L)
+    # a model the ragged scan does not cover (multi-scale split nodes) runs image by image inside: same rows
+    pm, _ = model_file((2, 12, 5, 3), 8, seed=9, cart_th=-0.8, multi_scale=True)
+    cm = api.Cascador(pm)
+    res = cm.detect_ragged_packed(buf, offs, ws, hs)
+    assert same(cm.detect_ragged_packed(buf, offs, ws, hs, keep_results="packed", frame_offset=7), jd.pack_detections(res, cm.L, frame_offset=7))

@@ -33,4 +33,7 @@ for _ in range(reps):
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / reps
 print("CPP ragged job, %d images resident: %.2f ms, %.0f images/s, %.3e windows/s, gpu_ms %.2f scan_ms %.2f host_ms %.2f launches %d handoff %d faces %d"
       % (n_img, el * 1e3, n_img / el, st["patch_n"] / el, st["gpu_ms"], st["scan_ms"], st["host_ms"], st["scan_launches"], st["handoff_n"], st["face_patch_n"]))
+print("C call %.2f ms of the %.2f ms per job (the rest: the binding packs %d rows of %d doubles)" % (st["call_ms"], el * 1e3, len(out), out.shape[1] if len(out) else 0))
+c.set_option("debug_times", 2)
+job()
 print("stage_done", st["stage_done_n"][:5], "cart_total", st["cart_total_n"], "scan_cart", st["scan_cart_n"])

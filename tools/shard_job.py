@@ -18,14 +18,16 @@ sizes = []
 for _ in range(2845):
     long_side = int(rng.integers(300, 451)); short = int(rng.integers(225, long_side + 1))
     sizes.append((long_side, short) if rng.random() < 0.5 else (short, long_side))
-lo, hi = jdist.shard_range(2845, rank, world)
+weights = [api.count_windows(w_, h_)[0] for (w_, h_) in sizes]
+lo, hi = jdist.shard_range_weighted(weights, rank, world) if not os.environ.get("SHARD_BY_COUNT") else jdist.shard_range(2845, rank, world)
 base = synth.make_frames(64, 450, 450, seed=7)
 imgs = [np.ascontiguousarray(base[i % 64][:sizes[i][1], :sizes[i][0]]) for i in range(lo, hi)]
 offs, tot = [], 0
 for im in imgs:
     offs.append(tot); tot += im.size
 d_buf = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).cuda()
-ws, hs = [sizes[i][0] for i in range(lo, hi)], [sizes[i][1] for i in range(lo, hi)]
+ws, hs = np.array([sizes[i][0] for i in range(lo, hi)], np.int32), np.array([sizes[i][1] for i in range(lo, hi)], np.int32)
+offs = np.array(offs, np.uint64)          # (the job description as arrays: the binding passes them on as they are)
 job = lambda: c.detect_ragged_packed(d_buf, offs, ws, hs, stats=True, keep_results="packed", frame_offset=lo)
 for _ in range(3):
     job()
