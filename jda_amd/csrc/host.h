@@ -127,7 +127,6 @@ inline long long env_ll(const char* name, long long dflt) {
   X(scan_p_opts, "JDA_SCAN_P_OPTS", 0)      /* ... bit 0 / 1: 8 trees in flight per lane in fresh / bucket tasks */ \
   X(scan_p_tile_kb, "JDA_SCAN_P_TILE_KB", 0) /* ... its own cut of a level's tile in y: as many rows of windows as keep the pixel tile within this many KB (0: the plan's tile) */ \
   X(scan_p_grid, "JDA_SCAN_P_GRID", 0)      /* ... workgroups of a launch (0: one per CU x scan_p_wgs) */ \
-  X(exp_a, "JDA_EXP_A", 0) X(exp_b, "JDA_EXP_B", 0) X(exp_c, "JDA_EXP_C", 0) /* (session experiments; removed before the round ends) */ \
   X(scan_p_mid, "JDA_SCAN_P_MID", 1)        /* ... with scan_p_handoff >= K: windows that pass stage 0 go straight to the mid queue */
 
 struct Knobs {

@@ -150,8 +150,10 @@ void k_scan(const DevPlan* __restrict__ plan, DevModelT<Real> m,
     trel_ = r >> 3;
     if (frame_ >= w.n_frames) return;
     if (level < 0) {
-      level_ = 0;
-      for (int i = 0; i < plan->n_levels; i++) {
+      // (a merged launch may cover a range of levels only: blk_base = first | (last + 1) << 8, 0 = every level)
+      const int lv_lo = blk_base & 0xff, lv_hi = blk_base ? (blk_base >> 8) & 0xff : plan->n_levels;
+      level_ = lv_lo;
+      for (int i = lv_lo; i < lv_hi; i++) {
         const DevLevel* c = &plan->lv[i];
         if (c->tiled != MODE) continue;
         const int cnt = c->tiles_x * c->tiles_y;
@@ -590,13 +592,14 @@ namespace {
 template <typename Real, bool TRACE, int MODE, int BLOCK>
 hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const DevModelT<Real>& m,
                             const S0Node* table, const WorkT<Real>& w, int level, int handoff, int cp_max, int opts,
-                            hipStream_t stream) {
+                            hipStream_t stream, int lv_lo, int lv_hi) {
+  lv_lo = std::max(0, lv_lo); lv_hi = std::min(lv_hi, h_plan.n_levels);
   // level >= 0: that level; level < 0: every level of pixel mode MODE in one launch, sized for the
   // largest tile (small batches, where one launch per level would only add launch latency)
   int tiles = 0, pix_bytes = 0;
   for (int i = 0; i < h_plan.n_levels; i++) {
     const DevLevel& lv = h_plan.lv[i];
-    if (lv.tiled != MODE || (level >= 0 && i != level)) continue;
+    if (lv.tiled != MODE || (level >= 0 && i != level) || (level < 0 && (i < lv_lo || i >= lv_hi))) continue;
     tiles += lv.tiles_x * lv.tiles_y;
     if (MODE != 2) pix_bytes = std::max(pix_bytes, lv.pitch * (lv.win + (lv.th - 1) * lv.step));
   }
@@ -610,8 +613,9 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
   auto go = [&](auto kern) {
     if (lds_req > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+    const bool ranged = level < 0 && (lv_lo > 0 || lv_hi < h_plan.n_levels);
     hipLaunchKernelGGL(kern, grid, block, lds_req, stream, d_plan, m, table, w, level < 0 ? -1 : level, tiles,
-                       pix_bytes, handoff, chunk, cp_max, opts, 0);
+                       pix_bytes, handoff, chunk, cp_max, opts, ranged ? (lv_lo | (lv_hi << 8)) : 0);
   };
   // (opts bit 1: no cart of [0, handoff) normalises -- the lean instantiation, passes without trace only)
   if constexpr (!TRACE) {
@@ -633,22 +637,22 @@ hipError_t launch_scan_mode(const DevPlan* d_plan, const DevPlan& h_plan, const 
 template <typename Real>
 hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
                        const DevPlan& h_plan, const DevModelT<Real>& m, const S0Node* table,
-                       const WorkT<Real>& w, hipStream_t stream) {
+                       const WorkT<Real>& w, hipStream_t stream, int lv_lo, int lv_hi) {
   if (w.n_frames == 0) return hipSuccess;
   if (level >= 0 && h_plan.lv[level].tiled != mode) return hipSuccess;
   // 512-thread workgroups where a level's tiles hold more than 256 windows (one window per lane in
   // phase 0, twice the waves per LDS byte); a merged launch when any of its levels does
   bool big = false;
   for (int i = 0; i < h_plan.n_levels && mode == 1; i++)
-    if (h_plan.lv[i].tiled == 1 && (level < 0 || i == level)) big = big || h_plan.lv[i].tw * h_plan.lv[i].th > 256;
+    if (h_plan.lv[i].tiled == 1 && (level < 0 ? (i >= lv_lo && i < lv_hi) : i == level)) big = big || h_plan.lv[i].tw * h_plan.lv[i].th > 256;
   auto pick = [&](auto trace_tag) {
     constexpr bool TR = decltype(trace_tag)::value;
     switch (mode) {
       case 1:
-        return big ? launch_scan_mode<Real, TR, 1, 512>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream)
-                   : launch_scan_mode<Real, TR, 1, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
-      case 2: return launch_scan_mode<Real, TR, 2, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
-      case 3: return launch_scan_mode<Real, TR, 3, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream);
+        return big ? launch_scan_mode<Real, TR, 1, 512>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream, lv_lo, lv_hi)
+                   : launch_scan_mode<Real, TR, 1, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream, lv_lo, lv_hi);
+      case 2: return launch_scan_mode<Real, TR, 2, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream, lv_lo, lv_hi);
+      case 3: return launch_scan_mode<Real, TR, 3, 256>(d_plan, h_plan, m, table, w, level, handoff, cp_max, opts, stream, lv_lo, lv_hi);
       default: return hipErrorInvalidValue;
     }
   };
@@ -711,11 +715,11 @@ hipError_t launch_scan_ragged<JDA_RAGGED_REAL>(int mode, int block, bool trace, 
 #endif
 #ifdef JDA_SCAN_TU_DOUBLE
 template hipError_t launch_scan<double>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<double>&,
-                                        const S0Node*, const WorkT<double>&, hipStream_t);
+                                        const S0Node*, const WorkT<double>&, hipStream_t, int, int);
 #endif
 #ifdef JDA_SCAN_TU_MAIN
 template hipError_t launch_scan<float>(int, int, bool, int, int, int, const DevPlan*, const DevPlan&, const DevModelT<float>&,
-                                       const S0Node*, const WorkT<float>&, hipStream_t);
+                                       const S0Node*, const WorkT<float>&, hipStream_t, int, int);
 #endif
 
 #ifdef JDA_SCAN_TU_MAIN

@@ -248,7 +248,8 @@ hipError_t launch_enqueue(const DevPlan* d_plan, const DevPlan& h_plan, bool all
 template <typename Real>
 hipError_t launch_scan(int mode, int level, bool trace, int handoff, int cp_max, int opts, const DevPlan* d_plan,
                        const DevPlan& h_plan, const DevModelT<Real>& m, const S0Node* table,
-                       const WorkT<Real>& w, hipStream_t stream);
+                       const WorkT<Real>& w, hipStream_t stream, int lv_lo = 0, int lv_hi = kMaxLevels);
+// (level < 0: ONE launch for every level of pixel mode `mode` among levels [lv_lo, lv_hi))
 
 // The same for a ragged batch: one launch over blocks [blk_base, blk_base + blk_n) of WorkT::blk, all of pixel mode
 // `mode` with workgroups of `block` threads and pixel tiles of at most pix_bytes.

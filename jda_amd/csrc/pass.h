@@ -212,8 +212,9 @@ struct Pass {
   // The persistent form of an LDS-tiled level's scan (k_scan_p.hip): dialect C, no trace.  false = not applicable
   // (the caller launches k_scan).
   // rl: a launch of a ragged chunk (all of ONE level): its tiles come from the chunk's block map, re-cut per image
-  bool scan_persistent(int level, hipStream_t s, const RaggedChunk::Launch* rl = nullptr) {
-    if constexpr (sizeof(Real) != 4) { (void)level; (void)s; (void)rl; return false; }
+  // dry: only say whether the level would be taken (nothing is launched, no state changes)
+  bool scan_persistent(int level, hipStream_t s, const RaggedChunk::Launch* rl = nullptr, bool dry = false) {
+    if constexpr (sizeof(Real) != 4) { (void)level; (void)s; (void)rl; (void)dry; return false; }
     else {
       if (!kn().scan_p || want_trace() || no_scan_p) return false;
       if (rl && (!kn().scan_p_ragged || level < 0)) return false;
@@ -256,6 +257,7 @@ struct Pass {
       const long long slots = scan_p_slots_for(c, cfg, K, block, wgs, n_tiles, !solo || busy_lanes > 1);
       if (slots <= 0) return false;
       cfg.slots = (int)slots;
+      if (dry) return true;
       cfg.dyn_slot = (kn().scan_p_dyn && p_launches < kCntMidScan - kCntTotal) ? p_launches : -1;
       const int grid = kn().scan_p_grid > 0 ? (int)std::min<long long>(kn().scan_p_grid, 1 << 16) : c->n_cus * wgs;
       const hipError_t e = rl ? launch_scan_persistent(level, cfg, block, grid, pe->dp, pe->hp, m, pe->table, w, s, rl->blk_base, rl->blk_n)
@@ -365,12 +367,35 @@ struct Pass {
         int fork_in = side ? (int)std::max<long long>(0, kn().side_after) : -1;
         if (fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
         if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
+        // The LDS-tiled levels the persistent kernel leaves to k_scan's closed tiles (the 71- and 88-pixel levels of
+        // 640x480: too few slots) share ONE launch when they lie next to each other: a launch of ~1,800 workgroups is
+        // three and a half rounds of the 512 resident ones, two of them back to back pay the partial round twice.
+        int rest_lo = -1, rest_hi = -1, rest_n = 0;
+        bool rest_done = false;
+        {
+          for (int l = 0; l < pe->hp.n_levels; l++)
+            if (pe->hp.lv[l].tiled == 1 && !scan_persistent(l, st, nullptr, true)) { if (rest_n++ == 0) rest_lo = l; rest_hi = l; }
+          for (int l = rest_lo; rest_n >= 2 && l <= rest_hi; l++)
+            if (pe->hp.lv[l].tiled == 1 && scan_persistent(l, st, nullptr, true)) rest_n = 0;      // (a level of the persistent kernel in between: no merge)
+          if (want_trace()) rest_n = 0;
+        }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
           const int mode = pe->hp.lv[l].tiled;
           if (mode != 1 && mode != 3) continue;
           // big-window levels of a batch are short launches: merge all of them into one (at the first one met)
           if (mode == 3) { if (any_wide) { if (!scan(3, -1, st)) return false; any_wide = false; } continue; }
+          if (rest_n >= 2 && l >= rest_lo && l <= rest_hi) {
+            if (!rest_done) {
+              const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
+                               (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
+              JDA_HIP(launch_scan<Real>(1, -1, false, handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, st, rest_lo, rest_hi + 1));
+              rs->scan_launches++; my_scan_launches++;
+              rest_done = true;
+              if (fork_in > 0 && --fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
+            }
+            continue;
+          }
           if (!scan(1, l, st)) return false;
           if (fork_in > 0 && --fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
         }

@@ -36,9 +36,8 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
     }
   }
   TileChoice best;
-  static const long long granule_mode = env_ll("JDA_TILE_GRANULE", 0);   // (r06 A/B: 1 = workgroups per CU counted in LDS granules; 2 = and the LDS of the launches that run, without the trace arrays)
-  const int fixed256 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, granule_mode < 2, 256);
-  const int fixed512 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, granule_mode < 2, 512);
+  const int fixed256 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, true, 256);
+  const int fixed512 = (int)scan_lds_bytes(0, chunk, hm.node_n(), hm.leaf_n(), real_bytes, true, 512);
   const int tw_hi = std::min(s.nx, 128), th_hi = std::min(s.ny, 128);
   for (int th = 1; th <= th_hi; th++) {
     for (int tw = 1; tw <= tw_hi; tw++) {
@@ -68,7 +67,9 @@ static TileChoice choose_tile(const Level& s, int width, const HostModel& hm, in
       const long long max_off = (long long)(s.win - 1) * pitch + s.win - 1 + 15;
       if (max_off >= (1LL << kS0GlobalOffBits)) continue;
       const int mode = max_off <= 65535 ? 1 : 3;
-      const int wgs = (int)std::min<long long>(granule_mode ? lds_wgs_per_cu(lds) : lds_cu / lds, 32 / (block / 64));
+      // (workgroups per CU in LDS granules, host.h.  r06 A/B against lds_cu / lds, also with the LDS of the untraced launch:
+      // headline, configs[2] and the FDDB-shaped job equal within noise -- the shapes chosen sit away from the boundaries)
+      const int wgs = (int)std::min<long long>(lds_wgs_per_cu(lds), 32 / (block / 64));
       const double waves = (double)wgs * (block / 64);
       int slots = (n_tile + 63) & ~63;
       if (n_tile <= cp_max) { slots = 16; while (slots < n_tile) slots *= 2; }
@@ -106,8 +107,7 @@ void assign_tiles(const ScanPlan& sp, const HostModel& hm, const Knobs& kn, bool
     const bool glb_ok = kn.no_global_scan == 0 &&
                         (long long)(s.win - 1) * sp.width + s.win - 1 < (1LL << kS0GlobalOffBits);
     if (fast_scan) {
-      const long long win_max = (real_bytes == 8 && kn.exp_c > 0) ? kn.exp_c : kn.lds_win_max;
-      const TileChoice t = (kn.no_lds_scan || s.win > win_max) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max, ragged);
+      const TileChoice t = (kn.no_lds_scan || s.win > kn.lds_win_max) ? TileChoice() : choose_tile(s, sp.width, hm, real_bytes, chunk, cp_max, ragged);
       if (t.mode && (!glb_ok || t.cost <= glb_per_window * (double)s.nx * s.ny)) {
         d.tiled = t.mode; d.tw = t.tw; d.th = t.th; d.pitch = t.pitch;
       } else if (glb_ok) {
