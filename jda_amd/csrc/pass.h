@@ -370,14 +370,27 @@ struct Pass {
         // The LDS-tiled levels the persistent kernel leaves to k_scan's closed tiles (the 71- and 88-pixel levels of
         // 640x480: too few slots) share ONE launch when they lie next to each other: a launch of ~1,800 workgroups is
         // three and a half rounds of the 512 resident ones, two of them back to back pay the partial round twice.
-        int rest_lo = -1, rest_hi = -1, rest_n = 0;
-        bool rest_done = false;
-        {
-          for (int l = 0; l < pe->hp.n_levels; l++)
-            if (pe->hp.lv[l].tiled == 1 && !scan_persistent(l, st, nullptr, true)) { if (rest_n++ == 0) rest_lo = l; rest_hi = l; }
-          for (int l = rest_lo; rest_n >= 2 && l <= rest_hi; l++)
-            if (pe->hp.lv[l].tiled == 1 && scan_persistent(l, st, nullptr, true)) rest_n = 0;      // (a level of the persistent kernel in between: no merge)
-          if (want_trace()) rest_n = 0;
+        // Only levels of one occupancy class (workgroups per CU by their LDS, workgroup size) merge: a launch takes the LDS of its
+        // largest tile, and dialect CPP's ten closed-tile levels in ONE launch ran the small-window levels at the big ones'
+        // occupancy (uniform 256-frame batch 10.4 -> 11.5-12.2 ms, r06).  run_first[l] / run_last[l]: the run level l belongs to.
+        int run_first[kMaxLevels], run_last[kMaxLevels];
+        for (int l = 0; l < pe->hp.n_levels; l++) run_first[l] = run_last[l] = -1;
+        // (dialect C only: the fp64 batch's thirteen closed-tile levels in three class launches measured no shorter on the
+        // device and 4 % longer per call -- its two lanes interleave their per-level launches better, session r06_s20)
+        if (!want_trace() && sizeof(Real) == 4) {
+          const int chunk = std::min(std::min(m.K, handoff), scan_handoff_cap(m.node_n, m.leaf_n, (int)sizeof(Real)));
+          int cur_first = -1, cur_key = -1, prev = -1;
+          auto close = [&](int last) { for (int l = cur_first; cur_first >= 0 && l <= last; l++) if (run_first[l] == cur_first) run_last[l] = last; };
+          for (int l = 0; l < pe->hp.n_levels; l++) {
+            const DevLevel& lv = pe->hp.lv[l];
+            if (lv.tiled != 1) continue;
+            if (scan_persistent(l, st, nullptr, true)) { close(prev); cur_first = -1; cur_key = -1; prev = -1; continue; }
+            const int block = lv.tw * lv.th > 256 ? 512 : 256;
+            const int key = lds_wgs_per_cu((long long)scan_lds_bytes(lv.pitch * (lv.win + (lv.th - 1) * lv.step), chunk, m.node_n, m.leaf_n, (int)sizeof(Real), false, block)) * 1024 + block;
+            if (key != cur_key) { close(prev); cur_first = l; cur_key = key; }
+            run_first[l] = cur_first; prev = l;
+          }
+          close(prev);
         }
         for (int li = 0; li < pe->hp.n_levels; li++) {
           const int l = rev ? pe->hp.n_levels - 1 - li : li;
@@ -385,13 +398,14 @@ struct Pass {
           if (mode != 1 && mode != 3) continue;
           // big-window levels of a batch are short launches: merge all of them into one (at the first one met)
           if (mode == 3) { if (any_wide) { if (!scan(3, -1, st)) return false; any_wide = false; } continue; }
-          if (rest_n >= 2 && l >= rest_lo && l <= rest_hi) {
-            if (!rest_done) {
+          if (run_first[l] >= 0 && run_last[l] > run_first[l]) {
+            // (the run's launch goes where its first member -- in this lane's order -- stands)
+            const int lead = rev ? run_last[l] : run_first[l];
+            if (l == lead) {
               const int opts = ((int)(std::max<long long>(4, std::min<long long>(64, kn().first_phase)) & ~3LL) << 8) |
                                (kn().scan_lean && !stage0_any_norm(c->hm, handoff, sizeof(Real) == 4) ? 2 : 0);
-              JDA_HIP(launch_scan<Real>(1, -1, false, handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, st, rest_lo, rest_hi + 1));
+              JDA_HIP(launch_scan<Real>(1, -1, false, handoff, cp_max, opts, pe->dp, pe->hp, m, pe->table, w, st, run_first[l], run_last[l] + 1));
               rs->scan_launches++; my_scan_launches++;
-              rest_done = true;
               if (fork_in > 0 && --fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
             }
             continue;

@@ -35,14 +35,19 @@ find $O -name "*.db" -delete; rm -rf $O/kt1 $O/kt2 $O/pmc_f $O/pmc_w $O/cal_f $O
 # (configs[4] all-pass regime and the W-beyond-the-Infinity-Cache variant: tools/sessions/r06_x.sh, run on its own)
 # dialect CPP: the FDDB-shaped ragged job, kernel trace with its launches alone on one lane and as the product runs it
 cd /tmp
-JDA_RAGGED_LANES=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktc1 -- python $R/tools/cpp_job.py 5 > $O/cpp_job_one_lane.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktc3 -- python $R/tools/cpp_job.py 5 > $O/cpp_job.txt 2>&1
 cd $R
-python tools/rocpd_summary.py $(db ktc1) > $O/cpp_job_kernel_trace_one_lane_stats.txt
 python tools/rocpd_summary.py $(db ktc3) > $O/cpp_job_kernel_trace_stats.txt
-rm -rf $O/ktc1 $O/ktc3
+python tools/job_overlap.py $(db ktc3) > $O/cpp_job_overlap.txt 2>&1
+rm -rf $O/ktc3
 timeout 300 python tools/cpp_bench.py 256 > $O/cpp_bench.txt 2>&1
-for r in 0 3 7; do timeout 120 python tools/shard_job.py 20 8 $r | tail -1; done > $O/shard_jobs.txt 2>&1
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace -d $O/kts -- python $R/tools/shard_job.py 10 8 0 > /dev/null 2>&1
+cd $R
+python tools/shard_timeline.py $(db kts) > $O/shard_timeline.txt 2>&1
+rm -rf $O/kts
+for r in 0 1 2 3 4 5 6 7; do timeout 120 python tools/shard_job.py 20 8 $r 2>&1 | tail -1; done > $O/shard_jobs.txt 2>&1
+timeout 60 tools/experiments/lds_occ.bin > $O/lds_granule.txt 2>&1
 timeout 300 python tools/ws_mem.py > $O/ws_mem.txt 2>&1
 # single-frame latency, ragged job
 timeout 300 python tools/latency.py > $O/latency.txt 2>&1
