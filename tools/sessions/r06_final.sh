@@ -1,0 +1,7 @@
+#!/bin/bash
+# what the driver runs at round end, on the final tree: smoke(), the GPU suite, bench.py with its arguments
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06_final; mkdir -p $O; cd $R
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+timeout 1500 python -m pytest tests/ -x -q -m gpu > $O/suite.txt 2>&1; grep -E "passed|failed|error" $O/suite.txt | tail -3
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench.err ) 2>&1 | grep real
+tail -1 $O/bench_driver_args.json | cut -c1-400
