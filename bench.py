@@ -621,7 +621,7 @@ def main():
                     def shard_job():
                         return casc.detect_ragged_packed(d_sub, so, ws_s, hs_s, stats=True, keep_results="packed", frame_offset=a, **kw)
                     shard_job(); shard_job()
-                    nrep = max(3, reps)
+                    nrep = max(11, reps)
                     ts = []
                     for _ in range(nrep):
                         t1 = time.perf_counter()
@@ -633,7 +633,7 @@ def main():
                                  "shard_ms": [round(t * 1e3, 4) for t in per]}
             info["predicted_strong_scaling"] = pred
             info["predicted_strong_scaling_note"] = ("each rank's shard of the job timed alone on this GPU (median of %d runs after two warm-ups); speedup = "
-                                                     "mean ms_per_job / slowest shard's median; not a multi-GPU measurement" % max(3, reps))
+                                                     "mean ms_per_job / slowest shard's median; not a multi-GPU measurement" % max(11, reps))
         casc.close()
         return info
 

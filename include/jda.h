@@ -149,6 +149,11 @@ JDA_API int jdaSetDevice(void *cascador, int device);
  *   "predict"       size the finishing launches from the previous pass instead of a host round trip (1)
  *   "scan_p"        the persistent form of the stage-0 scan for large uniform batches: 0 off, 1 where it suits, 2 wherever it fits (1)
  *   "device_post"   per-frame sort, NMS and relocation of batches of 16 frames or more on the device instead of on the host (1)
+ *   "hwq_place"     the cascador's streams are placed on the device's hardware queues: the HIP runtime deals a process's streams
+ *                   to four queues in creation order, so whether two lanes share one (and run one after the other) depends on
+ *                   the streams the host program created before; the library probes which of its streams share a queue and
+ *                   hands them out by queue.  0: wherever the runtime puts them (1).  Read-only, what the pool found:
+ *                   "hwq_queues", "hwq_streams", "hwq_probes", "hwq_max_mains" (most lanes whose main streams share a queue)
  * (the other keys of DESIGN.md section 8 are accepted as well; they are experiment switches).
  * Returns 0, or -1 for an unknown key / a running call or pending batch.  jdaGetOption returns the value (-1: unknown key). */
 JDA_API int jdaSetOption(void *cascador, const char *key, long long value);

@@ -93,8 +93,8 @@ void jdaCascadorRelease(void* cascador) try {
   if (c->dev_init) {
     (void)hipSetDevice(c->device);
     for (auto& l : c->lanes) l->destroy();
-    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
-    if (c->h2d) { (void)hipStreamSynchronize(c->h2d); (void)hipStreamDestroy(c->h2d); }
+    c->streams.destroy();        // (aux, the upload stream and the lanes' streams are the pool's)
+    c->aux = c->h2d = nullptr;
     for (auto& kv : c->plans) { if (kv.second.dp) (void)hipFree(kv.second.dp); if (kv.second.table) (void)hipFree(kv.second.table); }
     for (auto& b : c->plan_pool) { if (b.dp) (void)hipFree(b.dp); if (b.table) (void)hipFree(b.table); }
     c->mf.buf.release(); c->md.buf.release();
@@ -154,6 +154,15 @@ int jdaSetOption(void* cascador, const char* key, long long value) try {
 long long jdaGetOption(void* cascador, const char* key) try {
   Cascador* c = (Cascador*)cascador;
   long long v = 0;
+  if (c && key && std::strncmp(key, "hwq_", 4) == 0 && std::strcmp(key, "hwq_place") != 0) {
+    // read-only: what the stream pool found (host.h: StreamPool) -- hardware queues known, streams created, probes run,
+    // and the most main streams of busy-or-free lanes that share one queue
+    std::lock_guard<std::mutex> lk(c->streams.mu);
+    if (std::strcmp(key, "hwq_queues") == 0) return (long long)c->streams.rep.size();
+    if (std::strcmp(key, "hwq_streams") == 0) return c->streams.created;
+    if (std::strcmp(key, "hwq_probes") == 0) return c->streams.probes;
+    if (std::strcmp(key, "hwq_max_mains") == 0) { int m = 0; for (int x : c->streams.mains) m = std::max(m, x); return m; }
+  }
   if (!c || !key || !c->kn.get(key, &v)) { fail("jdaGetOption: unknown option"); return -1; }
   return v;
 } JDA_ABI_CATCH(-1)

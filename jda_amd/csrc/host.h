@@ -105,6 +105,7 @@ inline long long env_ll(const char* name, long long dflt) {
   X(ragged_chunk_min_windows, "JDA_RAGGED_CHUNK_MIN_WINDOWS", 1500000) /* ... and at least, where a small job is cut into ragged_split chunks */ \
   X(ragged_split, "JDA_RAGGED_SPLIT", 3)    /* chunks a job smaller than that many full chunks is cut into */ \
   X(ragged_single_windows, "JDA_RAGGED_SINGLE_WINDOWS", 5000000) /* a ragged job of at most this many windows (a rank's shard of a sharded job) runs as ONE chunk, its global-pixel launch on the lane's side stream; 0: always cut into ragged_split chunks */ \
+  X(hwq_place, "JDA_HWQ_PLACE", 1)          /* the cascador's streams are placed on the hardware queues by probing which of them share one (StreamPool); 0: where the runtime deals them */ \
   X(max_lanes, "JDA_MAX_LANES", 16)         /* lanes (stream + workspace + staging) a cascador creates at most; further concurrent callers wait for one */ \
   X(lane_idle_calls, "JDA_LANE_IDLE_CALLS", 256) /* lane hand-outs a free lane sits out before its workspace and staging buffers are released (0: never) */ \
   X(device_post, "JDA_DEVICE_POST", 1)      /* per-frame sort, NMS and relocation of a dialect-C batch on the device (k_post) instead of on the host (0): synchronous batch calls and tickets */ \
@@ -315,6 +316,40 @@ struct HostPinned {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
 };
 
+// The streams of a cascador, placed on the device's hardware queues (lanes.cpp).
+// The HIP runtime deals the streams of a process to GPU_MAX_HW_QUEUES (four) hardware queues -- the queue that has the
+// fewest streams so far, the last such -- and the packets of one queue run strictly one after the other.  Where a new
+// stream lands therefore depends on every stream the process has created before, and lanes that land on one queue do not
+// overlap at all: the same FDDB-sized ragged job takes 7.4 or 8.7 ms (dialect CPP: 30.1 or 35.7 ms) depending on how
+// many streams the host program happened to create first (profiles/r06_hwq.txt).  The pool finds out which of its
+// streams share a queue by PROBING (k_hwq_spin on the streams it knows, k_hwq_stamp on the new one) and hands them out
+// by queue: the main streams of the lanes spread over the queues, a lane's side stream and the upload stream on queues
+// that carry as few main streams as possible (never the lane's own).  Streams that landed where nothing was needed stay
+// in the pool for later requests.  hwq_place = 0: plain hipStreamCreate, the runtime's deal.
+struct StreamPool {
+  enum Role { kMain, kSide, kAux };
+  static constexpr int kNone = -2;           // "no queue to keep away from"; class -1 = a queue of the stream's own
+  struct Item { hipStream_t s; int cls; bool used; Role role; };
+  std::mutex mu;
+  std::vector<Item> items;
+  std::vector<hipStream_t> rep;              // the first stream seen on every known queue
+  std::vector<int> mains, others;            // per queue: main streams / side and upload streams handed out
+  unsigned long long* stamps = nullptr;      // mapped pinned memory the probes write to, kSlots x kRow
+  unsigned probe_no = 0;
+  int dry = 0;                               // streams created in a row that found no new queue (4: all queues known)
+  bool place = true;                         // hwq_place
+  int hw_queues = 4;                         // hardware queues the runtime deals streams to (its GPU_MAX_HW_QUEUES)
+  int created = 0, probes = 0;               // (jdaGetOption "hwq_streams" / "hwq_probes")
+  static constexpr int kMaxCls = 8, kRow = 16, kSlots = 32;
+  hipStream_t take(Role role, int avoid, int* cls_out);
+  void give_back(hipStream_t s);
+  void destroy();
+ private:
+  bool create_one(int* cls);
+  int classify(hipStream_t s);
+  int best_class(Role role, int avoid) const;
+};
+
 // One caller's share of the device: a stream with its events, a workspace and the staging buffers of a pass.
 // A call takes lanes from the cascador's pool for as long as it runs (a big synchronous batch takes two, a ragged job
 // up to three, a submitted batch holds one until its Wait) and gives them back; the pool grows with the number of
@@ -325,6 +360,8 @@ struct Lane {
   unsigned idle = 0;                         // lane hand-outs since this one was last used (free lanes only)
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;                // global-pixel scan launch of a lone lane, next to its LDS-tiled launches
+  StreamPool* pool_ = nullptr;               // the cascador's: where both streams come from
+  int q_main = -2, q_side = -2;              // hardware-queue class of either stream (StreamPool)
   hipEvent_t ev[5] = {};
   hipEvent_t ev_side[2] = {};
   hipEvent_t ev_user = nullptr;
@@ -342,8 +379,9 @@ struct Lane {
   // ragged passes: images at the common pitch, tight images, tables (segments, block map, image records)
   DevBuf rag_frames, rag_raw, rag_tab;
   HostPinned h_tab, h_raw;
-  bool create() {
-    JDA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  bool create(StreamPool* pool) {
+    pool_ = pool;
+    if (!pool_ || !(stream = pool_->take(StreamPool::kMain, StreamPool::kNone, &q_main))) return false;
     for (auto& e : ev) JDA_HIP(hipEventCreate(&e));
     JDA_HIP(hipEventCreateWithFlags(&ev_user, hipEventDisableTiming));
     for (auto& e : ev_h2d) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -352,9 +390,10 @@ struct Lane {
   }
   bool ensure_side() {
     if (side) return true;
-    // (a side stream of another PRIORITY -- a hardware queue of its own -- was tried in r06: the headline lost 8 %,
-    // 1.41 -> 1.53 ms per step, the shard job gained nothing: profiles/DEAD_ENDS.md)
-    JDA_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    // a hardware queue that is not the lane's own and, where there is one, carries no other lane's main stream either
+    // (StreamPool).  (A side stream of another PRIORITY was tried in r06: the headline lost 8 %, 1.41 -> 1.53 ms per
+    // step, the shard job gained nothing: profiles/DEAD_ENDS.md)
+    if (!(side = pool_->take(StreamPool::kSide, q_main, &q_side))) return false;
     for (auto& e : ev_side) JDA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return true;
   }
@@ -388,8 +427,8 @@ struct Lane {
     for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
     if (ev_user) (void)hipEventDestroy(ev_user);
     for (auto& e : ev_h2d) if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
-    if (side) (void)hipStreamDestroy(side);
+    if (pool_) { pool_->give_back(stream); pool_->give_back(side); }     // (the pool destroys its streams with the cascador)
+    stream = side = nullptr;
   }
 };
 
@@ -407,6 +446,7 @@ struct Cascador {
   int device = -1;
   int n_cus = 256;             // compute units of the device
   bool dev_init = false;
+  StreamPool streams;          // every stream of the cascador, placed on the hardware queues
   hipStream_t aux = nullptr;   // stage-0 table builds (under mu)
   // Frame uploads of every lane, in the order they are issued (under h2d_mu).  Uploads issued lane by lane run
   // CONCURRENTLY on the copy engines, each at a fraction of the link: two batches then both arrive late, and their

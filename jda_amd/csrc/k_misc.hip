@@ -339,5 +339,27 @@ hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, uns
 template hipError_t launch_trace_fill<float>(const DevModelT<float>&, const WorkT<float>&, unsigned, hipStream_t);
 template hipError_t launch_trace_fill<double>(const DevModelT<double>&, const WorkT<double>&, unsigned, hipStream_t);
 
+// =============================================================================
+// Hardware-queue probe (lanes.cpp: StreamPool).  The runtime deals a process's streams to FOUR hardware queues and the
+// packets of one queue run one after the other, so two lanes whose streams share a queue do not overlap at all
+// (profiles/r06_hwq.txt).  A one-wave spin of `ticks` of the 100-MHz wall clock on the streams already placed, a time
+// stamp on the new stream right behind them: the stamp lands before a spin's end unless it sits in that spin's queue.
+__global__ void k_hwq_spin(long long ticks, unsigned long long* out) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  __hip_atomic_store(out, (unsigned long long)wall_clock64(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_hwq_stamp(unsigned long long* out) {
+  __hip_atomic_store(out, (unsigned long long)wall_clock64(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_hwq_spin(long long ticks, unsigned long long* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_hwq_spin, dim3(1), dim3(1), 0, stream, ticks, out);
+  return hipGetLastError();
+}
+hipError_t launch_hwq_stamp(unsigned long long* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_hwq_stamp, dim3(1), dim3(1), 0, stream, out);
+  return hipGetLastError();
+}
+
 
 }  // namespace jda

@@ -350,4 +350,9 @@ template <typename Real>
 hipError_t launch_trace_fill(const DevModelT<Real>& m, const WorkT<Real>& w, unsigned n_windows,
                              hipStream_t stream);
 
+// Hardware-queue probe (k_misc.hip): a one-wave spin of `ticks` wall-clock ticks (100 MHz) that leaves its end time in
+// *out (mapped pinned host memory), and a kernel that leaves the time it ran.
+hipError_t launch_hwq_spin(long long ticks, unsigned long long* out, hipStream_t stream);
+hipError_t launch_hwq_stamp(unsigned long long* out, hipStream_t stream);
+
 }  // namespace jda

@@ -3,6 +3,124 @@
 
 namespace jda {
 
+// ---------------------------------------------------------------- streams on hardware queues (StreamPool, host.h)
+
+namespace {
+// spin lengths in ticks of the 100-MHz wall clock: 200 us for the first known queue, 50 us more for every further one, so
+// that the spins end in a known order, well apart, and well after the stamp of a stream that waits for none of them
+constexpr long long kSpinBase = 20000, kSpinStep = 5000;
+}
+
+// The known queue `s` shares -- its packets run behind that queue's -- or -1: none of them (-3: a HIP call failed).
+int StreamPool::classify(hipStream_t s) {
+  const int m = (int)rep.size();
+  if (m == 0) return -1;
+  if (!stamps) {
+    if (hipHostMalloc((void**)&stamps, sizeof(unsigned long long) * kSlots * kRow, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; return -3; }
+    std::memset(stamps, 0, sizeof(unsigned long long) * kSlots * kRow);
+  }
+  // (a row per probe, in turn: a spin that sits behind a busy lane's work may write long after its probe has been read)
+  volatile unsigned long long* h = stamps + (size_t)(probe_no++ % kSlots) * kRow;
+  for (int k = 0; k <= m; k++) h[k] = 0;
+  for (int k = 0; k < m; k++)
+    if (launch_hwq_spin(kSpinBase + k * kSpinStep, (unsigned long long*)(h + k), rep[k]) != hipSuccess) return -3;
+  if (launch_hwq_stamp((unsigned long long*)(h + m), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -3;
+  probes++;
+  // Only the new stream is waited for.  A spin that has not ended by now (its stamp still zero) cannot be in front of
+  // the new stream's kernel; of those that have, the one that ended last before it ran is the queue it waited in.
+  const unsigned long long t = h[m];
+  int best = -1;
+  unsigned long long best_d = ~0ull;
+  for (int k = 0; k < m; k++) {
+    const unsigned long long e = h[k];
+    if (e != 0 && e <= t && t - e < best_d) { best = k; best_d = t - e; }
+  }
+  return best;
+}
+
+// One more stream, probed and filed (unused) under its queue; a queue not seen before becomes a class of its own.
+bool StreamPool::create_one(int* cls_out) {
+  hipStream_t s = nullptr;
+  JDA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  int cls = classify(s);
+  if (cls == -3) { (void)hipGetLastError(); cls = -1; dry = 4; }      // (no probing on this device: the runtime's deal)
+  else if (cls == -1 && (int)rep.size() < kMaxCls) {
+    rep.push_back(s); mains.push_back(0); others.push_back(0);
+    cls = (int)rep.size() - 1;
+    dry = 0;
+  } else if (cls >= 0) dry++;
+  items.push_back(Item{s, cls, false, kAux});
+  created++;
+  *cls_out = cls;
+  return true;
+}
+
+// The known queue a stream of this role should go to: fewest main streams, then fewest other streams (side, upload,
+// table builds), then one the pool holds an unused stream of.
+int StreamPool::best_class(Role, int avoid) const {
+  // (side / upload streams by the TOTAL number of streams on a queue instead of main streams first: the same rates,
+  // profiles/r06_hwq.txt)
+  int best = -1, best_free = 0;
+  for (int q = 0; q < (int)rep.size(); q++) {
+    if (q == avoid) continue;
+    int free_q = 0;
+    for (const Item& it : items) if (!it.used && it.cls == q) { free_q = 1; break; }
+    if (best < 0 || mains[q] < mains[best] || (mains[q] == mains[best] && (others[q] < others[best] || (others[q] == others[best] && free_q > best_free)))) { best = q; best_free = free_q; }
+  }
+  return best;
+}
+
+hipStream_t StreamPool::take(Role role, int avoid, int* cls_out) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto hand_out = [&](Item& it) {
+    it.used = true; it.role = role;
+    if (it.cls >= 0) { if (role == kMain) mains[it.cls]++; else others[it.cls]++; }
+    if (cls_out) *cls_out = it.cls;
+    return it.s;
+  };
+  if (!place) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { fail(std::string("hipStreamCreateWithFlags failed: ") + hipGetErrorString(hipGetLastError())); return nullptr; }
+    items.push_back(Item{s, kNone, false, role}); created++;
+    return hand_out(items.back());
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    const int b = best_class(role, avoid);
+    const bool all_known = dry >= 4 || (int)rep.size() >= std::min(kMaxCls, hw_queues);
+    if (b >= 0 && (all_known || (mains[b] == 0 && others[b] == 0)))
+      for (Item& it : items) if (!it.used && it.cls == b) return hand_out(it);
+    // nothing of that queue at hand (or a queue nobody uses may still be out there): one more stream, wherever it lands
+    int cls = kNone;
+    if (!create_one(&cls)) return nullptr;
+    if (cls == -1) return hand_out(items.back());          // a queue of its own
+  }
+  // the runtime would not give us the queue we wanted: the least loaded of what is at hand
+  Item* pick = nullptr;
+  auto load = [&](const Item& it) { return it.cls < 0 ? 0 : (it.cls == avoid ? 1000 : 0) + 10 * mains[it.cls] + others[it.cls]; };
+  for (Item& it : items) if (!it.used && (!pick || load(it) < load(*pick))) pick = &it;
+  if (pick) return hand_out(*pick);
+  fail("no stream to be had");
+  return nullptr;
+}
+
+void StreamPool::give_back(hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(mu);
+  for (Item& it : items)
+    if (it.s == s && it.used) {
+      it.used = false;
+      if (it.cls >= 0) { if (it.role == kMain) mains[it.cls]--; else others[it.cls]--; }
+    }
+}
+
+void StreamPool::destroy() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (Item& it : items) { (void)hipStreamSynchronize(it.s); (void)hipStreamDestroy(it.s); }
+  items.clear(); rep.clear(); mains.clear(); others.clear();
+  if (stamps) (void)hipHostFree(stamps);
+  stamps = nullptr;
+}
+
 // ---------------------------------------------------------------- device init, lanes
 
 // Makes the cascador's device current for the calling thread; first use picks the device (caller holds c->mu then).
@@ -26,7 +144,9 @@ bool ensure_device(Cascador* c) {
   if (c->device >= n) { fail("device ordinal out of range"); return false; }
   JDA_HIP(hipSetDevice(c->device));
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cus = v; }
-  JDA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  c->streams.place = c->kn.hwq_place != 0;
+  c->streams.hw_queues = (int)std::max<long long>(1, env_ll("GPU_MAX_HW_QUEUES", 4));   // (the runtime's own setting, default four)
+  if (!(c->aux = c->streams.take(StreamPool::kAux, StreamPool::kNone, nullptr))) return false;
   c->dev_init = true;
   return true;
 }
@@ -48,7 +168,7 @@ Lane* acquire_lane_locked(Cascador* c, size_t want_cap, bool* exhausted, Lane::B
   if (!best) {
     if ((long long)c->lanes.size() >= std::max<long long>(1, c->kn.max_lanes)) { if (exhausted) *exhausted = true; return nullptr; }
     std::unique_ptr<Lane> l(new (std::nothrow) Lane());
-    if (!l || !l->create()) { if (l) l->destroy(); return nullptr; }
+    if (!l || !l->create(&c->streams)) { if (l) l->destroy(); return nullptr; }
     best = l.get();
     c->lanes.push_back(std::move(l));
   }

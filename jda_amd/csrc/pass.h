@@ -194,7 +194,7 @@ struct Pass {
       std::lock_guard<std::mutex> lk(c->h2d_mu);
       // (created by the first upload: HIP spreads its streams over four hardware queues in creation order, and a stream
       // that callers with resident frames never use would still shift which lanes share a queue)
-      if (!c->h2d) JDA_HIP(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
+      if (!c->h2d && !(c->h2d = c->streams.take(StreamPool::kSide, StreamPool::kNone, nullptr))) return false;
       JDA_HIP(hipEventRecord(ln->ev_h2d[0], st));                // (whatever read the staging buffer before is done)
       JDA_HIP(hipStreamWaitEvent(c->h2d, ln->ev_h2d[0], 0));
       if (!copy_frames_h2d(dst, stride, frames, n, fbytes, c->h2d)) return false;

@@ -861,7 +861,7 @@ static int detect_ragged_t(Cascador* c, const unsigned char* const* host_imgs, c
           if (k > 0 && !packed) { drain(); publish(k); }           // chunk k-1 has arrived while this one was gathered
           {
             std::lock_guard<std::mutex> lk(c->h2d_mu);
-            if (!c->h2d) good = hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking) == hipSuccess;
+            if (!c->h2d) good = (c->h2d = c->streams.take(StreamPool::kSide, StreamPool::kNone, nullptr)) != nullptr;
             good = good && hipMemcpyAsync(job.d_job_raw + job.raw_off[k], src, bytes, hipMemcpyHostToDevice, c->h2d) == hipSuccess;
           }
           if (packed || k == n_chunks - 1) { drain(); publish(k + 1); }

@@ -132,7 +132,7 @@ def test_options_round_trip_and_start_from_the_environment(built, model_file, mo
                   "kernel_d2h": 1, "h2d_stream": 1, "h2d_min_bytes": 8 << 20,
                   "ragged_chunk_min_windows": 1500000, "ragged_split": 3, "ragged_single_windows": 5000000,
                   "scan_p": 1, "scan_p_slots": 5, "device_post": 1, "device_post_min_frames": 16,
-                  "w_pad": 1, "w_stream_mb": 8, "lm_deep": 1, "max_lanes": 16, "ws_bound": 1, "ws_factor_pct": 400, "ws_min_entries": 65536}
+                  "w_pad": 1, "w_stream_mb": 8, "lm_deep": 1, "max_lanes": 16, "hwq_place": 1, "ws_bound": 1, "ws_factor_pct": 400, "ws_min_entries": 65536}
     for k in list(os.environ):
         if k.startswith("JDA_") and k not in ("JDA_LIB_PATH",):
             monkeypatch.delenv(k)

@@ -1,6 +1,7 @@
 """jdaDetect is re-entrant on ONE cascador, like the reference's (no globals, no locks: c/jda.c:443-480, SURVEY 8b
 "Threading"): concurrent callers each take a lane (stream + workspace) from the cascador's pool; the model and the
 scan plans are shared."""
+import os
 import threading
 import time
 
@@ -312,3 +313,41 @@ def test_bounded_queues_overflow_is_noticed_and_the_pass_rerun(built, model_file
     for a, b in zip(ga, wa):
         for k in ("bboxes", "scores", "shapes"):
             assert same(a[k], b[k]), k
+
+
+def test_lanes_get_hardware_queues_of_their_own(built, gpu, model_file, monkeypatch):
+    """The runtime deals a process's streams to four hardware queues -- which one depends on every stream the host program
+    created before -- and the kernels of one queue run one after the other (tools/experiments/hwq_probe.hip).  The
+    cascador probes where its streams landed and hands them out by queue (host.h: StreamPool): however many streams the
+    program made first, three lanes in flight have three queues.  hwq_place = 0 is the runtime's deal; results are the
+    same either way."""
+    import torch
+    from jda_amd import api, synth
+    p, _ = model_file((3, 20, 5, 4), 8, seed=3, cart_th=-1.0, norm_every=5)
+    batch = synth.make_frames(6, 200, 150, seed=6)
+    hw = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    outs = []
+    for dummies in (0, 1, 2):
+        keep = [torch.cuda.Stream() for _ in range(dummies)]           # the host program's own streams, used once
+        for s_ in keep:
+            with torch.cuda.stream(s_):
+                torch.zeros(16, device="cuda").add_(1)
+        torch.cuda.synchronize()
+        c = api.Cascador(p)
+        tickets = [c.submit_batch_host(batch) for _ in range(3)]       # three lanes held at once
+        outs.append([c.wait_batch(t) for t in tickets])
+        queues, streams, probes, worst = (c.get_option(k) for k in ("hwq_queues", "hwq_streams", "hwq_probes", "hwq_max_mains"))
+        assert queues >= min(3, hw), (dummies, queues)
+        assert worst == 1 or hw < 3, (dummies, "two lanes share a hardware queue", queues, streams, probes)
+        assert probes >= 2 and streams <= 24, (streams, probes)
+        c.close()
+    monkeypatch.setenv("JDA_HWQ_PLACE", "0")
+    c = api.Cascador(p)
+    tickets = [c.submit_batch_host(batch) for _ in range(3)]
+    plain = [c.wait_batch(t) for t in tickets]
+    assert c.get_option("hwq_queues") == 0 and c.get_option("hwq_probes") == 0
+    c.close()
+    for o in outs:
+        for got, want in zip(o, plain):
+            for a, b in zip(got, want):
+                _eq(a, b, "placed vs plain streams")

@@ -10,6 +10,7 @@ n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 2845
 mp = os.path.join(synth.cache_dir(), "model_5_540_27_4_cascade_s1.model")
 if not os.path.exists(mp):
     m = synth.make_model(5, 540, 27, 4, seed=1); synth.calibrate_thresholds(m, synth.make_frames(8, 640, 480, seed=0, first=10_000_000)); m.save(mp, 8)
+import _dummy_streams; _dummy_streams.make()
 c = api.Cascador(mp)
 rng = np.random.default_rng(0)
 sizes = []

@@ -27,6 +27,7 @@ for spec in (sys.argv[2:] or [""]):
     os.environ.clear(); os.environ.update(base_env)
     for kv in spec.split():
         k, v = kv.split("=", 1); os.environ[k] = v
+    import _dummy_streams; _dummy_streams.make()
     c = api.Cascador(mp)
     for _ in range(2):
         rows, st = c.detect_ragged_packed(d_buf, offs, ws, hs, stats=True, keep_results="packed")

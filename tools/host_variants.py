@@ -19,6 +19,7 @@ for spec in (sys.argv[1:] or [""]):
     for name, frames in (("pageable", src), ("pinned", [p.numpy() for p in pin])):
         if os.environ.get("HOST_ONLY", name) != name:
             continue
+        import _dummy_streams; _dummy_streams.make()
         c = api.Cascador(mp)
         ahead = int(os.environ.get("AHEAD", "2"))
         def run(steps):

@@ -9,6 +9,7 @@ calib = synth.make_frames(8, 640, 480, seed=0, first=10_000_000)
 mp = bench.model_path((5, 540, 27, 4), "cascade", 1, calib)
 R = 4
 ds = [torch.from_numpy(synth.make_frames(256, 640, 480, seed=0, first=i * 256)).cuda() for i in range(R)]
+import _dummy_streams; _dummy_streams.make()
 c = api.Cascador(mp)
 K = int(os.environ.get("PIPE_STEPS", "40"))
 for rep in range(2):
