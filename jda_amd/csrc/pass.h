@@ -363,7 +363,10 @@ struct Pass {
         // odd lanes go through the levels in the opposite order (big windows first): the launches of
         // one lane then run next to different ones of the other instead of next to their twins
         const bool rev = (lane & 1) && kn().lanes_reverse;
-        const bool side = any_glb && solo && kn().side_stream && ln->ensure_side();
+        // (... and only while this is the cascador's only pass in flight: next to another ticket's pass the other pass is
+        // the mix, and the fork costs -- submit/wait step 1.41 -> 1.36 ms with three tickets, 1.47 -> 1.34 with two, once
+        // every lane has a hardware queue of its own; r06, profiles/r06_hwq.txt section 6)
+        const bool side = any_glb && solo && kn().side_stream && busy_lanes <= 1 && ln->ensure_side();
         int fork_in = side ? (int)std::max<long long>(0, kn().side_after) : -1;
         if (fork_in == 0) { if (!fork_glb()) return false; fork_in = -1; }
         if (rev && any_glb) { if (!scan(2, -1, st)) return false; any_glb = false; }
