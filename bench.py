@@ -22,8 +22,10 @@ call jdaDetect(.., 1.25, 0.1, 40, -1, -0.5) (reference c/main.cpp:25), in the
 finish).  The all-pass regime is measured as a secondary line in "regimes".
 
 The K timed steps go through the library's submit/wait entry points (jdaDetectBatchSubmit /
-jdaDetectBatchWait): steps i+1 and i+2 are queued before step i is collected (--depth 3, the library's three tickets),
-so up to three batches are in flight per GPU from ONE host thread and the GPU works while the host parts of a step run.  Every step is a complete
+jdaDetectBatchWait): step i+1 is queued before step i is collected (--depth 2; --depth 3 queues two ahead, the library
+has three tickets), so two batches are in flight per GPU from ONE host thread and the GPU works while the host parts of a step
+run (r06, on streams that each have a hardware queue: two in flight 1.34-1.36 ms per step in steady state, three 1.36-1.37; over 20
+timed steps from an empty pipeline 1.37-1.39 against 1.40-1.41 -- three passes started at once ramp up slower).  Every step is a complete
 pass over one batch and all K finish inside the timed region.  --depth 1 uses one synchronous
 jdaDetectBatchDevice call per step instead; that figure is reported next to the headline in "config" and
 "regimes".
@@ -198,8 +200,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--dims", type=str, default="5,540,27,4")
-    ap.add_argument("--depth", type=int, default=3,
-                    help="batches in flight per rank: 2 / 3 = submit/wait pipeline from one host thread, one / two batches queued ahead (default 3), "
+    ap.add_argument("--depth", type=int, default=2,
+                    help="batches in flight per rank: 2 / 3 = submit/wait pipeline from one host thread, one / two batches queued ahead (default 2), "
                          "1 = one synchronous call per step")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allpass", action="store_true")
