@@ -1,6 +1,7 @@
 // libjda.so, host side: the model's device copies (split nodes in the layouts the kernels read, leaf scores, cart
 // parameters, regression weights).  File layout: reference c/jda.c:114-180, 499-560.
 #include "host.h"
+#include <limits>
 
 namespace jda {
 
@@ -82,6 +83,36 @@ bool upload_model(Cascador* c) {
   if (sizeof(Real) == 8) {
     const volatile double zero = 0.;
     for (auto& v : ms) v = (Real)((double)v + zero);   // RandomShape with zero shift, data.cpp:225-236
+  }
+  if (sizeof(Real) == 8 && h.hdr_stage >= 0 && h.hdr_stage < h.T) {
+    // A trainer file of a model STILL IN TRAINING: the reference's Validate runs stages [0, current_stage_idx) in full and
+    // then carts [0, current_cart_idx] of the stage in training without that stage's regression (cascador.cpp:177-209;
+    // header ints 5 and 6, cascador.cpp:84-104).  Dialect C does not: c/jda.c reads the two ints and drops them
+    // (c/jda.c:499-505) -- it always runs T x K, and so does the fp32 copy above.  The fp64 copy gets the same RESULTS as
+    // Validate from tables of unchanged shape: every cart Validate would not run becomes a pass-through (leaf scores +0,
+    // mean 0, std 1: score + 0 and (score - 0) / 1 are exact; threshold -inf: never rejects) and the weight rows of the
+    // stage in training and of every later stage are zero (shape + 0 is exact).  Reject lengths of rejected windows, scores,
+    // shapes and face decisions are Validate's; only the work counters see the padding.  (Found by the second reading of
+    // src/jda, oracle/cpp_reading2.py; the oracle runs Validate's literal loop bounds, tests/test_cpp_second_reading.py
+    // and tests/test_cpp_entries.py compare.)
+    if (c->similarity) {
+      // (the stage in training walks with the PREVIOUS stage's similarity parameter, cascador.cpp:178-200: a value the padded
+      // tables cannot give it)
+      fail("dialect CPP with the similarity transform on a model still in training (header stage " + std::to_string(h.hdr_stage) +
+           " of " + std::to_string(h.T) + ") is not supported");
+      return false;
+    }
+    const int full = h.hdr_stage;
+    const int part = std::min(h.K, std::max(0, h.hdr_cart + 1));
+    const Real ninf = -std::numeric_limits<Real>::infinity();
+    for (int t = full; t < h.T; t++) {
+      for (int k = (t == full ? part : 0); k < h.K; k++) {
+        const size_t ck = (size_t)t * h.K + k;
+        for (int l = 0; l < leaf_n; l++) leaf[ck * leaf_n + l] = (Real)0;
+        cth[ck] = ninf; cmean[ck] = (Real)0; cstd[ck] = (Real)1;
+      }
+      std::fill(w.begin() + (size_t)t * h.K * leaf_n * dim, w.begin() + (size_t)(t + 1) * h.K * leaf_n * dim, (Real)0);
+    }
   }
   std::vector<uint8_t> cnorm(carts);
   for (size_t i = 0; i < carts; i++) cnorm[i] = !(cmean[i] == (Real)0 && cstd[i] == (Real)1);

@@ -1,0 +1,235 @@
+"""TEST INFRASTRUCTURE, not product: a SECOND, independent restatement of the reference's fp64 detect path (dialect CPP),
+written from the reference's C++ alone -- not from oracle/jda_oracle.c -- in plain Python on IEEE doubles, for small cases.
+
+Why: src/jda cannot be compiled in this image (OpenCV, jsmnpp and liblinear are absent), so dialect CPP is PARITY UNPINNED:
+the HIP kernels are bit-exact against jda_oracle.c's restatement only.  Two restatements made independently of each other
+from the same source that agree bit for bit (tests/test_cpp_second_reading.py) narrow the room for a misreading; they do
+not pin anything -- a detail both readers got wrong the same way, or one that only the real OpenCV decides (cv::resize for
+multi-scale models, cv::norm inside the similarity transform), stays open.  Covered here: single-scale models
+(Feature::ORIGIN), detect method 1, the identity similarity transform.
+
+What it follows, line by line:
+  model file       JoinCascador::SerializeFrom  src/jda/cascador.cpp:127-164, Cart::SerializeFrom src/jda/cart.cpp:404-423
+  Validate         src/jda/cascador.cpp:166-211   (shape = mean_shape: RandomShape with shift_size 0, src/jda/data.cpp:225-236,
+                                                   src/test.cpp:17,75)
+  Cart::Forward    src/jda/cart.cpp:392-404
+  feature value    Feature::CalcFeatureValue src/jda/data.cpp:18-58, checkBoundaryOfImage include/jda/common.hpp:227-232
+  STParameter      identity when face.similarity_transform is off, src/jda/data.cpp:64-70; Apply include/jda/data.hpp:42-45
+  GenDeltaShape    src/jda/btcart.cpp:407-424
+  detectMultiScale1 src/jda/cascador.cpp:310-376
+  nms              src/jda/cascador.cpp:387-429 (std::multimap: ascending keys, equal keys in insertion order)
+  Detect           src/jda/cascador.cpp:431-477
+"""
+import bisect
+import math
+import struct
+
+
+def c_round(x):
+    """C round(): to nearest, halves away from zero (data.cpp:45-48 calls ::round on doubles)."""
+    a = abs(x)
+    f = math.floor(a)
+    if a - f >= 0.5:          # (exact: a - f is representable)
+        f += 1.0
+    return -f if x < 0 else f
+
+
+class Cart2:
+    __slots__ = ("scale", "lm1", "lm2", "o1x", "o1y", "o2x", "o2y", "nth", "scores", "th", "mean", "std")
+
+
+class Model2:
+    """The trainer's double file (jdaCascadorCreateDouble's input): cascador.cpp:127-164."""
+
+    def __init__(self, path):
+        b = open(path, "rb").read()
+        self.pos = 0
+
+        def take(fmt):
+            v = struct.unpack_from("<" + fmt, b, self.pos)
+            self.pos += struct.calcsize("<" + fmt)
+            return v
+        (_yo,) = take("i")
+        self.T, self.K, self.L, self.D = take("iiii")
+        self.stage_idx, self.cart_idx = take("ii")
+        self.mean_shape = list(take("%dd" % (2 * self.L)))
+        nodes_n = 1 << self.D                       # cart.hpp: nodes_n = 2^depth, features[1 .. nodes_n/2 - 1]
+        self.leaf_n = nodes_n // 2
+        self.carts = []
+        self.w = []
+        for t in range(self.T):
+            row = []
+            for k in range(self.K):
+                c = Cart2()
+                n = nodes_n // 2
+                c.scale = [0] * n; c.lm1 = [0] * n; c.lm2 = [0] * n
+                c.o1x = [0.0] * n; c.o1y = [0.0] * n; c.o2x = [0.0] * n; c.o2y = [0.0] * n; c.nth = [0] * n
+                for i in range(1, n):               # cart.cpp:406-416
+                    c.scale[i], c.lm1[i], c.lm2[i] = take("iii")
+                    c.o1x[i], c.o1y[i], c.o2x[i], c.o2y[i] = take("dddd")
+                    (c.nth[i],) = take("i")
+                c.scores = list(take("%dd" % n))    # cart.cpp:418-420
+                c.th, c.mean, c.std = take("ddd")   # cart.cpp:421-423
+                row.append(c)
+            self.carts.append(row)
+            rows = self.K * (1 << (self.D - 1))     # cascador.cpp:156-161
+            self.w.append([list(take("%dd" % (2 * self.L))) for _ in range(rows)])
+        take("i")
+        assert self.pos == len(b), "trailing bytes in the model file"
+
+
+IDENTITY = (1.0, 1.0, 0.0, 0.0, 1.0)        # scale, rot00, rot01, rot10, rot11 (data.hpp: STParameter's default)
+
+
+def st_apply(stp, x1, y1):
+    s, r00, r01, r10, r11 = stp                 # data.hpp:42-45
+    return s * (r00 * x1 + r01 * y1), s * (r10 * x1 + r11 * y1)
+
+
+def feature_value(c, i, img, x0, y0, width, height, shape, stp):
+    """Feature::CalcFeatureValue on the patch img[y0:y0+height, x0:x0+width] (a cv::Mat ROI: at<uchar>(y, x) is relative
+    to the ROI's origin); only Feature::ORIGIN."""
+    if c.scale[i] != 0:
+        raise NotImplementedError("multi-scale feature (needs cv::resize)")
+    o1x, o1y = st_apply(stp, c.o1x[i], c.o1y[i])
+    o2x, o2y = st_apply(stp, c.o2x[i], c.o2y[i])
+    x1 = (shape[2 * c.lm1[i]] + o1x) * width
+    y1 = (shape[2 * c.lm1[i] + 1] + o1y) * height
+    x2 = (shape[2 * c.lm2[i]] + o2x) * width
+    y2 = (shape[2 * c.lm2[i] + 1] + o2y) * height
+    x1_, y1_, x2_, y2_ = int(c_round(x1)), int(c_round(y1)), int(c_round(x2)), int(c_round(y2))
+
+    def clamp(x, y):                            # common.hpp:227-232
+        if x < 0: x = 0
+        if y < 0: y = 0
+        if x >= width: x = width - 1
+        if y >= height: y = height - 1
+        return x, y
+    x1_, y1_ = clamp(x1_, y1_)
+    x2_, y2_ = clamp(x2_, y2_)
+    return int(img[y0 + y1_][x0 + x1_]) - int(img[y0 + y2_][x0 + x2_])
+
+
+def forward(m, c, img, x0, y0, width, height, shape, stp):
+    node = 1                                    # cart.cpp:394-403
+    for _ in range(m.D - 1):
+        val = feature_value(c, node, img, x0, y0, width, height, shape, stp)
+        node = 2 * node if val <= c.nth[node] else 2 * node + 1
+    return node - (1 << (m.D - 1))
+
+
+FNV_SEED, FNV_MUL = 2166136261, 16777619        # the trace's leaf-path hash (a convention of this repo's checkers, not the reference's)
+
+
+def validate(m, img, x0, y0, width, height):
+    """JoinCascador::Validate -> (is_face, score, shape, n, path_hash)."""
+    shape = list(m.mean_shape)
+    score = 0.0
+    n = 0
+    h = FNV_SEED
+    base = 1 << (m.D - 1)
+    stp = IDENTITY
+    for t in range(m.stage_idx):
+        stp = IDENTITY                          # STParameter::Calc with the transform off (data.cpp:68-70)
+        lbf = [0] * m.K
+        offset = 0
+        for k in range(m.K):
+            c = m.carts[t][k]
+            idx = forward(m, c, img, x0, y0, width, height, shape, stp)
+            h = ((h ^ idx) * FNV_MUL) & 0xffffffff
+            score += c.scores[idx]
+            score = (score - c.mean) / c.std
+            n += 1
+            if score < c.th:
+                return False, score, shape, n, h
+            lbf[k] = offset + idx
+            offset += base
+        # GenDeltaShape (btcart.cpp:407-424): rows summed from zero in cart order, Apply, then shape += delta
+        delta = [0.0] * (2 * m.L)
+        for k in range(m.K):
+            row = m.w[t][lbf[k]]
+            for j in range(2 * m.L):
+                delta[j] += row[j]
+        for i in range(m.L):
+            delta[2 * i], delta[2 * i + 1] = st_apply(stp, delta[2 * i], delta[2 * i + 1])
+        for j in range(2 * m.L):
+            shape[j] = shape[j] + delta[j]
+    if m.stage_idx < m.T:
+        for k in range(m.cart_idx + 1):         # cascador.cpp:198-209: no regression for the stage in training
+            c = m.carts[m.stage_idx][k]
+            idx = forward(m, c, img, x0, y0, width, height, shape, stp)
+            h = ((h ^ idx) * FNV_MUL) & 0xffffffff
+            score += c.scores[idx]
+            score = (score - c.mean) / c.std
+            n += 1
+            if score < c.th:
+                return False, score, shape, n, h
+    return True, score, shape, n, h
+
+
+def windows_method1(w, h, minimum_size, step, factor):
+    """detectMultiScale1's enumeration (cascador.cpp:332-370): (x, y, win) in scan order."""
+    out = []
+    win_w = win_h = minimum_size
+    while win_w <= w and win_h <= h:
+        y = 0
+        while y <= h - win_h:
+            x = 0
+            while x <= w - win_w:
+                out.append((x, y, win_w))
+                x += step
+            y += step
+        prev = win_w
+        win_w = int(win_w * factor)
+        win_h = int(win_h * factor)
+        if win_w <= prev:
+            break                               # (a factor that does not grow the window loops forever in the reference)
+    return out
+
+
+def nms(rects, scores, overlap):
+    """cascador.cpp:387-429.  std::multimap<double, int>: keys ascending, equal keys in insertion order."""
+    keys, vals = [], []
+    for i, s in enumerate(scores):
+        p = bisect.bisect_right(keys, s)        # insert() puts an equal key at the upper bound
+        keys.insert(p, s); vals.insert(p, i)
+    areas = [float(r[2] * r[3]) for r in rects]
+    picked = []
+    while keys:
+        last = vals[-1]
+        picked.append(last)
+        nk, nv = [], []
+        for s, idx in zip(keys, vals):
+            x1 = float(max(rects[idx][0], rects[last][0]))
+            y1 = float(max(rects[idx][1], rects[last][1]))
+            x2 = float(min(rects[idx][0] + rects[idx][2], rects[last][0] + rects[last][2]))
+            y2 = float(min(rects[idx][1] + rects[idx][3], rects[last][1] + rects[last][3]))
+            ww = max(0.0, x2 - x1)
+            hh = max(0.0, y2 - y1)
+            ov = ww * hh / (areas[idx] + areas[last] - ww * hh)
+            if not ov > overlap:
+                nk.append(s); nv.append(idx)
+        if len(nk) == len(keys):
+            raise RuntimeError("the reference's nms does not terminate for this overlap threshold")
+        keys, vals = nk, nv
+    return picked
+
+
+def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True):
+    """JoinCascador::Detect with fddb.method = 1 -> rects (x, y, w, h), scores, relocated shapes."""
+    h, w = len(img), len(img[0])
+    rects, scores, shapes = [], [], []
+    for (x, y, win) in windows_method1(w, h, minimum_size, step, factor):
+        ok, score, shape, _, _ = validate(m, img, x, y, win, win)
+        if ok:
+            rects.append((x, y, win, win)); scores.append(score); shapes.append(shape)
+    picked = nms(rects, scores, overlap) if do_nms else list(range(len(rects)))
+    out_r, out_s, out_sh = [], [], []
+    for i in picked:
+        r = rects[i]
+        sh = list(shapes[i])
+        for j in range(m.L):                    # cascador.cpp:466-469
+            sh[2 * j] = r[0] + sh[2 * j] * r[2]
+            sh[2 * j + 1] = r[1] + sh[2 * j + 1] * r[3]
+        out_r.append(r); out_s.append(scores[i]); out_sh.append(sh)
+    return out_r, out_s, out_sh

@@ -19,7 +19,13 @@
  * by tests/test_oracle_vs_reference.py, and against the golden vectors under
  * tests/golden/ that were produced by that build.  Dialect CPP cannot be
  * compiled here (needs OpenCV/jsmnpp/liblinear): PARITY UNPINNED for it; it
- * is cross-checked only against dialect C where the two must agree.
+ * is cross-checked against dialect C where the two must agree, and (r06)
+ * against a second restatement made independently from the reference's C++
+ * (oracle/cpp_reading2.py, plain Python; tests/test_cpp_second_reading.py:
+ * bit for bit per window and per image on single-scale models, method 1).
+ * That reading found one divergence, fixed here and in the product: Validate
+ * honours the header's training status (cascador.cpp:177-209), dialect C does
+ * not (c/jda.c:499-505).  Agreement of two readings narrows, it does not pin.
  *
  * Unlike the reference, cascade dimensions are run-time values, and every
  * window reports where and why the walk stopped (carts evaluated, score,
@@ -43,6 +49,7 @@ typedef struct {
 typedef struct {
   int T, K, L, D, node_n, leaf_n, dim;
   int real_bytes;
+  int hdr_stage, hdr_cart;        /* header ints 5, 6: the training status (cascador.cpp:84-104, 136-141) */
   double *mean_shape;             /* [dim]                 */
   orc_node *nodes;                /* [T*K*node_n]          */
   double *leaf, *cth, *cmean, *cstd;
@@ -89,7 +96,7 @@ orc_model *orc_load(const char *path) {
   orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
   (void)rd_i32(&p);
   m->T = rd_i32(&p); m->K = rd_i32(&p); m->L = rd_i32(&p); m->D = rd_i32(&p);
-  (void)rd_i32(&p); (void)rd_i32(&p);
+  m->hdr_stage = rd_i32(&p); m->hdr_cart = rd_i32(&p);
   if (m->T < 1 || m->T > 16 || m->K < 1 || m->L < 1 || m->D < 2 || m->D > 12) { free(buf); free(m); return NULL; }
   int rb = 0;
   if (size == orc_stream_bytes(m->T, m->K, m->L, m->D, 8)) rb = 8;
@@ -601,9 +608,20 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
     shape[2 * j + 1] = m->mean_shape[2 * j + 1] + 0.;
   }
   double *tmp = (double *)malloc(sizeof(double) * 2 * dim);
-  for (int t = 0; t < m->T; t++) {
-    const orc_stp stp = orc_stp_calc(shape, m->mean_shape, m->L, g_orc_similarity, tmp, tmp + dim);   /* cascador.cpp:180 */
-    for (int k = 0; k < m->K; k++) {
+  /* Validate runs stages [0, current_stage_idx) in full and then carts [0, current_cart_idx] of the stage in training
+   * WITHOUT its regression (cascador.cpp:177-209); a finished trainer model carries (T, -1) (cascador.cpp:93-98), a float
+   * file written by the C library (T + 1, -1) (c/jda.c:662-665): both run everything.  (Dialect C reads the two ints and
+   * drops them, c/jda.c:499-505: it always runs T x K.)  Found by the second reading, oracle/cpp_reading2.py. */
+  const int full = m->hdr_stage >= 0 && m->hdr_stage < m->T ? m->hdr_stage : m->T;
+  const int part = full < m->T ? (m->hdr_cart + 1 < m->K ? m->hdr_cart + 1 : m->K) : 0;
+  orc_stp stp_last; memset(&stp_last, 0, sizeof stp_last);
+  stp_last = orc_stp_calc(shape, m->mean_shape, m->L, 0, tmp, tmp + dim);                 /* STParameter's default: the identity */
+  for (int t = 0; t < full + (part > 0 ? 1 : 0); t++) {
+    const int in_training = t == full;                                                    /* cascador.cpp:198-209 */
+    const orc_stp stp = in_training ? stp_last : orc_stp_calc(shape, m->mean_shape, m->L, g_orc_similarity, tmp, tmp + dim);   /* cascador.cpp:180; the stage in training walks with the LAST stage's parameter */
+    stp_last = stp;
+    const int k_end = in_training ? part : m->K;
+    for (int k = 0; k < k_end; k++) {
       const long long c = (long long)t * m->K + k;
       int at = 0; /* 0-based position in the stored node array == reference idx-1 */
       for (int d = 0; d < m->D - 1; d++) {
@@ -639,6 +657,7 @@ static int orc_walk_cpp(const orc_model *m, const orc_patch *pt,
       if (score < m->cth[c]) { *alive = 0; *score_out = score; *hash_out = hash; free(tmp); return n; }
       lbf[k] = k * leaf_n + leaf;
     }
+    if (in_training) break;                  /* no global regression for the stage in training */
     const double *ws = &m->w[(size_t)t * m->K * leaf_n * dim];
     for (int i = 0; i < dim; i++) delta[i] = 0.;
     for (int k = 0; k < m->K; k++) {

@@ -242,3 +242,47 @@ def test_cpp_ragged_rows_entries_equal_the_packed_results(built, gpu, model_file
     cm = api.Cascador(pm)
     want = _pack_d(cm.detect_ragged_cpp_packed(buf, offs, ws, hs), cm.L, frame_offset=3)
     assert same(np.array(cm.detect_ragged_cpp_packed(buf, offs, ws, hs, keep_results="packed", frame_offset=3)), want)
+
+
+@pytest.mark.parametrize("hdr", [(1, 6), (0, 11), (2, -1), (0, -1), (2, 19)])
+def test_cpp_on_a_model_still_in_training_stops_where_validate_stops(built, gpu, tmp_path, hdr):
+    """A trainer snapshot (jda_xxxx_stage_s_cart_c.model) carries its training status in the header, and the reference's
+    Validate honours it: stages [0, s) in full, then carts [0, c] of stage s WITHOUT that stage's regression
+    (cascador.cpp:177-209, 84-104).  Found by the second reading of src/jda (oracle/cpp_reading2.py,
+    tests/test_cpp_second_reading.py): until then both the oracle and the kernels ran all T x K carts in dialect CPP, as
+    dialect C's reference does (c/jda.c:499-505 drops the two ints).  The oracle runs Validate's literal loop bounds; the
+    product pads its fp64 tables with pass-through carts and zero weight rows (model_dev.cpp) -- window by window the reject
+    length, score, leaf path and shape must be the same, and so must every entry's detections.  Dialect C on the same
+    file keeps running everything."""
+    from jda_amd import api, synth
+    from oracle.pyoracle import Oracle
+    dims = (3, 20, 5, 4)
+    mdl = synth.make_model(*dims, seed=3, cart_th=-1.0, norm_every=5)
+    p = str(tmp_path / "snapshot.model")
+    mdl.save(p, 8, header_stage=hdr[0], header_cart=hdr[1])
+    full = str(tmp_path / "full.model")
+    mdl.save(full, 8)
+    imgs = _images([(131, 97), (64, 48), (200, 150)], seed=5)
+    c, o = api.Cascador(p), Oracle(p)
+    ran = hdr[0] * dims[1] + hdr[1] + 1                       # carts Validate runs for a window that passes them all
+    for im in imgs[:2]:
+        got, want = c.trace_cpp(im[None]), o.trace_cpp(im)
+        faces = got["carts_n"] == dims[0] * dims[1]                 # (a face walks the padding too; nothing but this counter sees it)
+        assert (want["carts_n"][faces] == ran).all()                # ... where Validate stopped after every cart it runs
+        assert np.array_equal(got["carts_n"][~faces], want["carts_n"][~faces])      # rejected windows: Validate's n
+        assert np.array_equal(got["path_hash"][~faces], want["path_hash"][~faces])  # ... and the same leaves on the way
+        for k in ("score", "shapes"):
+            assert same(got[k], want[k]), k
+        every = o.detect_cpp(im, nms=False)                         # every face, scan order
+        _eq(c.detect_batch_cpp(im[None], nms=False)[0], every, "nms off")
+        assert 0 < len(every["scores"]) <= faces.sum() and (hdr == (0, -1) or not faces.all())   # (<: a window rejected by the LAST cart also counts T x K)
+    got = c.detect_ragged_cpp(imgs)
+    for i, im in enumerate(imgs):
+        _eq(got[i], o.detect_cpp(im), i)
+        _eq(got[i], c.detect_batch_cpp(im[None])[0], i)
+    # the same file through dialect C: all T x K carts, like the complete model (c/jda.c ignores the status)
+    cf = api.Cascador(full)
+    a, b = c.detect(imgs[2]), cf.detect(imgs[2])
+    for k in ("bboxes", "scores", "shapes"):
+        assert same(a[k], b[k]), k
+    c.close(); cf.close(); o.close()

@@ -1,0 +1,107 @@
+"""Dialect CPP (the reference's fp64 src/jda path) cannot be pinned in this image: src/jda needs OpenCV, jsmnpp and liblinear.
+What CAN be done: a second restatement written independently from the reference's C++ (oracle/cpp_reading2.py, plain Python
+on IEEE doubles) must agree BIT FOR BIT with oracle/jda_oracle.c's dialect CPP -- per window (reject length, score, leaf-path
+hash, shape) and per image (rects, scores, relocated shapes after the multimap NMS).  Agreement narrows the room for a
+misreading of cascador.cpp:166-211 / cart.cpp:392-404 / data.cpp:18-58 / btcart.cpp:407-424 / cascador.cpp:310-477; it
+does not pin the dialect (module docstring of cpp_reading2.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import cpp_reading2 as r2
+from oracle.pyoracle import Oracle
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def _image(w, h, seed):
+    from jda_amd import synth
+    return synth.make_frames(1, w, h, seed=seed)[0]
+
+
+CASES = [((3, 20, 5, 4), dict(seed=3, cart_th=-1.0, norm_every=5), (64, 52)),
+         ((2, 8, 5, 3), dict(seed=1, cart_th=-0.5), (47, 61)),
+         ((2, 6, 4, 6), dict(seed=2, cart_th=-2.0, norm_every=2), (40, 40)),
+         ((1, 4, 3, 2), dict(seed=5, cart_th=-0.2), (33, 25))]
+
+
+@pytest.mark.parametrize("dims,kw,size", CASES)
+def test_two_independent_readings_of_validate_agree_window_by_window(model_file, dims, kw, size):
+    p, _ = model_file(dims, 8, **kw)
+    img = _image(size[0], size[1], seed=7 + dims[1])
+    orc = Oracle(p)
+    tr = orc.trace_cpp(img, minimum_size=20, step=5, factor=1.2)
+    m = r2.Model2(p)
+    assert (m.T, m.K, m.L, m.D) == tuple(dims) and m.stage_idx == m.T and m.cart_idx == -1
+    rows = img.tolist()
+    wins = r2.windows_method1(size[0], size[1], 20, 5, 1.2)
+    assert len(wins) == len(tr["carts_n"]) > 0
+    faces = 0
+    for i, (x, y, win) in enumerate(wins):
+        ok, score, shape, n, h = r2.validate(m, rows, x, y, win, win)
+        faces += ok
+        assert n == tr["carts_n"][i], (i, x, y, win)
+        assert h == tr["path_hash"][i], (i, "leaf path")
+        assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], (i, score, tr["score"][i])
+        assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), (i, "shape")
+    assert 0 < faces < len(wins) or dims[1] <= 4            # (the cases reject some windows and keep some)
+    orc.close()
+
+
+@pytest.mark.parametrize("nms", [True, False])
+def test_two_independent_readings_of_detect_agree(model_file, nms):
+    dims, kw = (3, 20, 5, 4), dict(seed=3, cart_th=-1.0, norm_every=5)
+    p, _ = model_file(dims, 8, **kw)
+    img = _image(70, 58, seed=11)
+    orc = Oracle(p)
+    want = orc.detect_cpp(img, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=nms)
+    m = r2.Model2(p)
+    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, nms)
+    assert len(rects) == len(want["rects"]) > 0
+    assert np.array_equal(np.array(rects, np.int32), want["rects"])
+    assert np.array_equal(_bits(scores), _bits(want["scores"]))
+    assert np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
+
+
+def test_nms_ties_resolve_the_same_way_in_both_readings(model_file):
+    """A constant image: every window of a level sees the same pixels, so whole levels share one score -- the multimap's
+    order among equal keys (insertion order, the LAST inserted is picked first) decides which window survives."""
+    dims = (2, 8, 5, 3)
+    p, _ = model_file(dims, 8, seed=1, cart_th=-1e30)
+    img = np.full((50, 58), 117, np.uint8)
+    orc = Oracle(p)
+    want = orc.detect_cpp(img, minimum_size=20, step=5, factor=1.2, overlap=0.3, nms=True)
+    m = r2.Model2(p)
+    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, True)
+    assert len(set(scores)) == 1 and len(rects) > 1
+    assert np.array_equal(np.array(rects, np.int32), want["rects"])
+    assert np.array_equal(_bits(scores), _bits(want["scores"]))
+    assert np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
+
+
+def test_a_model_still_in_training_runs_its_last_stage_without_regression(model_file, tmp_path):
+    """cascador.cpp:198-209: stages [0, current_stage_idx) in full, then carts [0, current_cart_idx] of the stage in
+    training with NO shape update -- the header fields decide, in both readings."""
+    from jda_amd import synth
+    dims = (3, 20, 5, 4)
+    mdl = synth.make_model(*dims, seed=3, cart_th=-1.0, norm_every=5)
+    p = str(tmp_path / "partial.model")
+    mdl.save(p, 8, header_stage=1, header_cart=6)
+    img = _image(56, 48, seed=4)
+    m = r2.Model2(p)
+    assert (m.stage_idx, m.cart_idx) == (1, 6)
+    try:
+        orc = Oracle(p)
+    except Exception:
+        pytest.skip("jda_oracle.c takes complete models only")
+    tr = orc.trace_cpp(img, minimum_size=20, step=5, factor=1.2)
+    rows = img.tolist()
+    for i, (x, y, win) in enumerate(r2.windows_method1(56, 48, 20, 5, 1.2)):
+        ok, score, shape, n, h = r2.validate(m, rows, x, y, win, win)
+        assert n == tr["carts_n"][i] and h == tr["path_hash"][i], i
+        assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], i
+        assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), i
+    orc.close()
