@@ -5,8 +5,11 @@ Why: src/jda cannot be compiled in this image (OpenCV, jsmnpp and liblinear are 
 the HIP kernels are bit-exact against jda_oracle.c's restatement only.  Two restatements made independently of each other
 from the same source that agree bit for bit (tests/test_cpp_second_reading.py) narrow the room for a misreading; they do
 not pin anything -- a detail both readers got wrong the same way, or one that only the real OpenCV decides (cv::resize for
-multi-scale models, cv::norm inside the similarity transform), stays open.  Covered here: single-scale models
-(Feature::ORIGIN), detect method 1, the identity similarity transform.
+multi-scale models, cv::norm inside the similarity transform), stays open.  Covered here: detect methods 1 and 0, single- and
+multi-scale models, the identity similarity transform.  cv::resize is NOT restated a second time: where the reference resizes
+(the half / quarter images of method 1, the pyramid levels and per-window patches of method 0) the caller hands in a resize
+function -- the tests pass jda_oracle.c's restatement -- so these paths check everything AROUND the resize: which image is
+resized to what, the ROI arithmetic, which patch a feature reads and with which width and height, rect scaling, NMS, relocation.
 
 What it follows, line by line:
   model file       JoinCascador::SerializeFrom  src/jda/cascador.cpp:127-164, Cart::SerializeFrom src/jda/cart.cpp:404-423
@@ -16,7 +19,7 @@ What it follows, line by line:
   feature value    Feature::CalcFeatureValue src/jda/data.cpp:18-58, checkBoundaryOfImage include/jda/common.hpp:227-232
   STParameter      identity when face.similarity_transform is off, src/jda/data.cpp:64-70; Apply include/jda/data.hpp:42-45
   GenDeltaShape    src/jda/btcart.cpp:407-424
-  detectMultiScale1 src/jda/cascador.cpp:310-376
+  detectMultiScale1 src/jda/cascador.cpp:310-376;  detectSingleScale / detectMultiScale (method 0) src/jda/cascador.cpp:215-308
   nms              src/jda/cascador.cpp:387-429 (std::multimap: ascending keys, equal keys in insertion order)
   Detect           src/jda/cascador.cpp:431-477
 """
@@ -86,11 +89,10 @@ def st_apply(stp, x1, y1):
     return s * (r00 * x1 + r01 * y1), s * (r10 * x1 + r11 * y1)
 
 
-def feature_value(c, i, img, x0, y0, width, height, shape, stp):
-    """Feature::CalcFeatureValue on the patch img[y0:y0+height, x0:x0+width] (a cv::Mat ROI: at<uchar>(y, x) is relative
-    to the ROI's origin); only Feature::ORIGIN."""
-    if c.scale[i] != 0:
-        raise NotImplementedError("multi-scale feature (needs cv::resize)")
+def feature_value(c, i, patches, shape, stp):
+    """Feature::CalcFeatureValue.  patches[scale] = (img, x0, y0, width, height): the cv::Mat ROI of the ORIGIN / HALF /
+    QUARTER image this window was given (at<uchar>(y, x) is relative to the ROI's origin; width and height are the ROI's)."""
+    img, x0, y0, width, height = patches[c.scale[i]]        # data.cpp:20-34 (any other value: dieWithMsg)
     o1x, o1y = st_apply(stp, c.o1x[i], c.o1y[i])
     o2x, o2y = st_apply(stp, c.o2x[i], c.o2y[i])
     x1 = (shape[2 * c.lm1[i]] + o1x) * width
@@ -110,10 +112,10 @@ def feature_value(c, i, img, x0, y0, width, height, shape, stp):
     return int(img[y0 + y1_][x0 + x1_]) - int(img[y0 + y2_][x0 + x2_])
 
 
-def forward(m, c, img, x0, y0, width, height, shape, stp):
+def forward(m, c, patches, shape, stp):
     node = 1                                    # cart.cpp:394-403
     for _ in range(m.D - 1):
-        val = feature_value(c, node, img, x0, y0, width, height, shape, stp)
+        val = feature_value(c, node, patches, shape, stp)
         node = 2 * node if val <= c.nth[node] else 2 * node + 1
     return node - (1 << (m.D - 1))
 
@@ -121,8 +123,11 @@ def forward(m, c, img, x0, y0, width, height, shape, stp):
 FNV_SEED, FNV_MUL = 2166136261, 16777619        # the trace's leaf-path hash (a convention of this repo's checkers, not the reference's)
 
 
-def validate(m, img, x0, y0, width, height):
-    """JoinCascador::Validate -> (is_face, score, shape, n, path_hash)."""
+def validate(m, img, x0=None, y0=None, width=None, height=None, patches=None):
+    """JoinCascador::Validate -> (is_face, score, shape, n, path_hash).  Either one ORIGIN patch (img, x0, y0, width, height)
+    or the three patches of a multi-scale call."""
+    if patches is None:
+        patches = ((img, x0, y0, width, height),) * 3     # (a single-scale model only ever reads patches[0])
     shape = list(m.mean_shape)
     score = 0.0
     n = 0
@@ -135,7 +140,7 @@ def validate(m, img, x0, y0, width, height):
         offset = 0
         for k in range(m.K):
             c = m.carts[t][k]
-            idx = forward(m, c, img, x0, y0, width, height, shape, stp)
+            idx = forward(m, c, patches, shape, stp)
             h = ((h ^ idx) * FNV_MUL) & 0xffffffff
             score += c.scores[idx]
             score = (score - c.mean) / c.std
@@ -157,7 +162,7 @@ def validate(m, img, x0, y0, width, height):
     if m.stage_idx < m.T:
         for k in range(m.cart_idx + 1):         # cascador.cpp:198-209: no regression for the stage in training
             c = m.carts[m.stage_idx][k]
-            idx = forward(m, c, img, x0, y0, width, height, shape, stp)
+            idx = forward(m, c, patches, shape, stp)
             h = ((h ^ idx) * FNV_MUL) & 0xffffffff
             score += c.scores[idx]
             score = (score - c.mean) / c.std
@@ -215,14 +220,8 @@ def nms(rects, scores, overlap):
     return picked
 
 
-def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True):
-    """JoinCascador::Detect with fddb.method = 1 -> rects (x, y, w, h), scores, relocated shapes."""
-    h, w = len(img), len(img[0])
-    rects, scores, shapes = [], [], []
-    for (x, y, win) in windows_method1(w, h, minimum_size, step, factor):
-        ok, score, shape, _, _ = validate(m, img, x, y, win, win)
-        if ok:
-            rects.append((x, y, win, win)); scores.append(score); shapes.append(shape)
+def _finish(m, rects, scores, shapes, overlap, do_nms):
+    """Detect's tail (cascador.cpp:445-476): NMS or everything, then the shapes relocated into their rects."""
     picked = nms(rects, scores, overlap) if do_nms else list(range(len(rects)))
     out_r, out_s, out_sh = [], [], []
     for i in picked:
@@ -233,3 +232,70 @@ def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True
             sh[2 * j + 1] = r[1] + sh[2 * j + 1] * r[3]
         out_r.append(r); out_s.append(scores[i]); out_sh.append(sh)
     return out_r, out_s, out_sh
+
+
+def patches_method1(img, img_h, img_q, x, y, win):
+    """The three ROIs detectMultiScale1 cuts for a window (cascador.cpp:340-353)."""
+    r = math.sqrt(2.)
+    return ((img, x, y, win, win),
+            (img_h, int(x / r), int(y / r), int(win / r), int(win / r)),
+            (img_q, x // 2, y // 2, win // 2, win // 2))
+
+
+def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True, resize=None, trace=None):
+    """JoinCascador::Detect with fddb.method = 1 -> rects (x, y, w, h), scores, relocated shapes.
+    resize(img, dw, dh): needed for multi-scale models only (img_h, img_q: cascador.cpp:323-331).  trace: a list that
+    receives every window's (is_face, score, shape, n, path_hash) in scan order."""
+    h, w = len(img), len(img[0])
+    img_h = img_q = img
+    if resize is not None:
+        img_h = resize(img, int(w / math.sqrt(2.)), int(h / math.sqrt(2.)))
+        img_q = resize(img, w // 2, h // 2)
+    rects, scores, shapes = [], [], []
+    for (x, y, win) in windows_method1(w, h, minimum_size, step, factor):
+        res = validate(m, None, patches=patches_method1(img, img_h, img_q, x, y, win))
+        if trace is not None:
+            trace.append(res)
+        ok, score, shape, _, _ = res
+        if ok:
+            rects.append((x, y, win, win)); scores.append(score); shapes.append(shape)
+    return _finish(m, rects, scores, shapes, overlap, do_nms)
+
+
+def detect_pyramid(m, img, resize, origin_size=48, half_size=36, quarter_size=24, step=5, factor=1.2, overlap=0.3, do_nms=True):
+    """JoinCascador::Detect with fddb.method = 0: detectMultiScale (cascador.cpp:271-308) over detectSingleScale
+    (cascador.cpp:215-265).  Windows are origin_size on every level; each window's three patches are cv::resize's of its ROI
+    to image_size.{origin,half,quarter}_size (cascador.cpp:243-245) -- resize() stands in for cv::resize."""
+    width, height = len(img[0]), len(img)
+    win = origin_size
+    scale = 1.
+    cur = img
+    rects, scores, shapes = [], [], []
+    while width >= win and height >= win:
+        lv_r, lv_s, lv_sh = [], [], []
+        x_max, y_max = len(cur[0]) - win, len(cur) - win
+        y = 0
+        while y <= y_max:
+            x = 0
+            while x <= x_max:
+                roi = [row[x:x + win] for row in cur[y:y + win]]
+                p_o = resize(roi, origin_size, origin_size)
+                p_h = resize(roi, half_size, half_size)
+                p_q = resize(roi, quarter_size, quarter_size)
+                ok, score, shape, _, _ = validate(m, None, patches=((p_o, 0, 0, origin_size, origin_size),
+                                                                     (p_h, 0, 0, half_size, half_size),
+                                                                     (p_q, 0, 0, quarter_size, quarter_size)))
+                if ok:
+                    lv_r.append((x, y, win, win)); lv_s.append(score); lv_sh.append(shape)
+                x += step
+            y += step
+        for (rx, ry, rw, rh) in lv_r:           # cascador.cpp:290-294: int *= double
+            rects.append((int(rx * scale), int(ry * scale), int(rw * scale), int(rh * scale)))
+        scores += lv_s; shapes += lv_sh
+        scale *= factor
+        width = int(width / factor)
+        height = int(height / factor)
+        if width <= 0 or height <= 0:
+            break                               # (cv::resize would throw on an empty size; the loop ends on the next test anyway)
+        cur = resize(cur, width, height)
+    return _finish(m, rects, scores, shapes, overlap, do_nms)

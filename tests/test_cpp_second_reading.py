@@ -105,3 +105,55 @@ def test_a_model_still_in_training_runs_its_last_stage_without_regression(model_
         assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], i
         assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), i
     orc.close()
+
+
+def _resize_with(orc):
+    """jda_oracle.c's restatement of cv::resize as the second reading's resize(img, dw, dh) (rows of ints in and out): the
+    second reading covers everything around the resize, not the resize."""
+    def f(img, dw, dh):
+        return orc.resize_cv(np.asarray(img, np.uint8), dw, dh).tolist()
+    return f
+
+
+@pytest.mark.parametrize("dims,kw,size", [((3, 20, 5, 4), dict(seed=3, cart_th=-1.0, norm_every=5, multi_scale=True), (64, 52)),
+                                           ((2, 8, 5, 3), dict(seed=4, cart_th=-0.5, multi_scale=True), (47, 61))])
+def test_multi_scale_models_method_1_which_patch_which_size(model_file, dims, kw, size):
+    """detectMultiScale1 hands Validate three ROIs of three images (cascador.cpp:323-353): the half image is
+    int(cols / sqrt 2) wide, the quarter image cols / 2; a window's half ROI starts at int(x / sqrt 2) and is int(win / sqrt 2)
+    wide -- and a HALF feature scales its offsets by THAT width (data.cpp:37-43).  Both readings must agree on all of it."""
+    p, mdl = model_file(dims, 8, **kw)
+    assert (mdl.scale != 0).any()
+    img = _image(size[0], size[1], seed=21)
+    orc = Oracle(p)
+    tr = orc.trace_cpp(img, minimum_size=20, step=5, factor=1.2)
+    m = r2.Model2(p)
+    mine = []
+    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, True, resize=_resize_with(orc), trace=mine)
+    assert len(mine) == len(tr["carts_n"])
+    for i, (ok, score, shape, n, h) in enumerate(mine):
+        assert n == tr["carts_n"][i] and h == tr["path_hash"][i], i
+        assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], i
+        assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), i
+    want = orc.detect_cpp(img, 20, 5, 1.2, 0.3, True)
+    assert len(rects) == len(want["rects"]) > 0
+    assert np.array_equal(np.array(rects, np.int32), want["rects"])
+    assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_method_0_the_image_pyramid_around_the_resize(model_file, multi):
+    """detectMultiScale / detectSingleScale (cascador.cpp:215-308): fixed 48-pixel windows on an image that is resized level
+    after level FROM THE PREVIOUS LEVEL, rects scaled back with `int *= double` truncation, the scale a running product."""
+    dims = (3, 20, 5, 4)
+    p, _ = model_file(dims, 8, seed=3, cart_th=-1.0, norm_every=5, multi_scale=multi)
+    img = _image(150, 121, seed=9)
+    orc = Oracle(p)
+    m = r2.Model2(p)
+    for nms in (True, False):
+        want = orc.detect_cpp_pyramid(img, 48, 5, 1.2, 0.3, nms, half_size=36 if multi else 0, quarter_size=24 if multi else 0)
+        rects, scores, shapes = r2.detect_pyramid(m, img.tolist(), _resize_with(orc), 48, 36, 24, 5, 1.2, 0.3, nms)
+        assert len(rects) == len(want["rects"]) > 0
+        assert np.array_equal(np.array(rects, np.int32), want["rects"])
+        assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
