@@ -79,6 +79,7 @@ class Model2:
             self.w.append([list(take("%dd" % (2 * self.L))) for _ in range(rows)])
         take("i")
         assert self.pos == len(b), "trailing bytes in the model file"
+        self.multi_scale = any(s != 0 for row in self.carts for c in row for s in c.scale[1:])
 
 
 IDENTITY = (1.0, 1.0, 0.0, 0.0, 1.0)        # scale, rot00, rot01, rot10, rot11 (data.hpp: STParameter's default)
@@ -280,8 +281,9 @@ def detect_pyramid(m, img, resize, origin_size=48, half_size=36, quarter_size=24
             while x <= x_max:
                 roi = [row[x:x + win] for row in cur[y:y + win]]
                 p_o = resize(roi, origin_size, origin_size)
-                p_h = resize(roi, half_size, half_size)
-                p_q = resize(roi, quarter_size, quarter_size)
+                # (the reference resizes all three for every window; a single-scale model never reads the other two)
+                p_h = resize(roi, half_size, half_size) if m.multi_scale else None
+                p_q = resize(roi, quarter_size, quarter_size) if m.multi_scale else None
                 ok, score, shape, _, _ = validate(m, None, patches=((p_o, 0, 0, origin_size, origin_size),
                                                                      (p_h, 0, 0, half_size, half_size),
                                                                      (p_q, 0, 0, quarter_size, quarter_size)))
@@ -299,3 +301,67 @@ def detect_pyramid(m, img, resize, origin_size=48, half_size=36, quarter_size=24
             break                               # (cv::resize would throw on an empty size; the loop ends on the next test anyway)
         cur = resize(cur, width, height)
     return _finish(m, rects, scores, shapes, overlap, do_nms)
+
+
+# ---- cv::resize(src, dst, Size(dw, dh)) for 8-bit gray, INTER_LINEAR: a second restatement, from OpenCV's imgproc/imgwarp.cpp as
+#      the author of this file remembers it (2.4 / 3.x line; not from jda_oracle.c's orc_resize_cv).  Still NOT a pin: no OpenCV
+#      here to run.  What it encodes: float coordinates fx = (float)((dx + 0.5) * scale - 0.5), cvFloor, the border rules
+#      (x: sx < 0 -> 0 with fx 0; sx >= w - 1 -> w - 1 with fx 0; y: coefficients untouched, the two row indices clipped), 11-bit coefficients saturate_cast<short>(c * 2048) with
+#      round-half-to-even, the horizontal pass in ints, the vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16)
+#      + 2) >> 2, and resize()'s switch to the 2x2 area average (a + b + c + d + 2) >> 2 when both scales are exactly 2.
+import numpy as _np
+
+
+def _cv_round_f(v):
+    """cvRound of a float: to nearest, halves to even (lrint in the default rounding mode)."""
+    f = math.floor(v)
+    d = v - f
+    if d > 0.5 or (d == 0.5 and (int(f) & 1)):
+        f += 1
+    return int(f)
+
+
+def resize_cv2(img, dw, dh):
+    src = _np.asarray(img, _np.int64)
+    sh, sw = src.shape
+    if (dw, dh) == (sw, sh):
+        return src.tolist()
+    scale_x, scale_y = 1. / (float(dw) / sw), 1. / (float(dh) / sh)
+    isx, isy = _cv_round_f(scale_x), _cv_round_f(scale_y)           # saturate_cast<int>(double)
+    eps = 2.220446049250313e-16
+    if abs(scale_x - isx) < eps and abs(scale_y - isy) < eps and isx == 2 and isy == 2:
+        out = [[0] * dw for _ in range(dh)]
+        for y in range(dh):
+            for x in range(dw):
+                out[y][x] = int((src[2 * y][2 * x] + src[2 * y][2 * x + 1] + src[2 * y + 1][2 * x] + src[2 * y + 1][2 * x + 1] + 2) >> 2)
+        return out
+    f32 = _np.float32
+
+    def coeffs(n_dst, n_src, scale, clamp):
+        ofs, co = [], []
+        for d in range(n_dst):
+            f = f32((d + 0.5) * scale - 0.5)
+            s = int(math.floor(float(f)))
+            f = f32(f - f32(s))
+            if clamp:                           # the x loop only (xmin / xmax bookkeeping); the y loop keeps (sy, fy) as they are
+                if s < 0:
+                    f, s = f32(0), 0
+                if s >= n_src - 1:
+                    f, s = f32(0), n_src - 1
+            c0, c1 = f32(1) - f, f
+            sat = lambda v: max(-32768, min(32767, _cv_round_f(float(f32(v) * f32(2048)))))
+            ofs.append(s); co.append((sat(c0), sat(c1)))
+        return ofs, co
+    xofs, alpha = coeffs(dw, sw, scale_x, True)
+    yofs, beta = coeffs(dh, sh, scale_y, False)       # ... and clips the two ROW INDICES when it fetches them
+
+    def hrow(y):
+        y = min(max(y, 0), sh - 1)
+        row = src[y]
+        return [int(row[xofs[d]]) * alpha[d][0] + int(row[min(xofs[d] + 1, sw - 1)]) * alpha[d][1] for d in range(dw)]
+    out = []
+    for d in range(dh):
+        r0, r1 = hrow(yofs[d]), hrow(yofs[d] + 1)
+        b0, b1 = beta[d]
+        out.append([(((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2 for x in range(dw)])
+    return out

@@ -128,13 +128,27 @@ def test_multi_scale_models_method_1_which_patch_which_size(model_file, dims, kw
     tr = orc.trace_cpp(img, minimum_size=20, step=5, factor=1.2)
     m = r2.Model2(p)
     mine = []
-    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, True, resize=_resize_with(orc), trace=mine)
+    # (the half / quarter images through the SECOND recollection of cv::resize: nothing of jda_oracle.c on this side)
+    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, True, resize=r2.resize_cv2, trace=mine)
     assert len(mine) == len(tr["carts_n"])
     for i, (ok, score, shape, n, h) in enumerate(mine):
         assert n == tr["carts_n"][i] and h == tr["path_hash"][i], i
         assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], i
         assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), i
     want = orc.detect_cpp(img, 20, 5, 1.2, 0.3, True)
+    assert len(rects) == len(want["rects"]) > 0
+    assert np.array_equal(np.array(rects, np.int32), want["rects"])
+    assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
+
+
+def test_method_0_multi_scale_end_to_end_on_the_second_reading_alone(model_file):
+    """Levels AND per-window patches through cpp_reading2.resize_cv2: no line of jda_oracle.c on this side."""
+    p, _ = model_file((2, 8, 5, 3), 8, seed=4, cart_th=-0.5, multi_scale=True)
+    img = _image(70, 62, seed=13)
+    orc = Oracle(p)
+    want = orc.detect_cpp_pyramid(img, 48, 5, 1.2, 0.3, True, half_size=36, quarter_size=24)
+    rects, scores, shapes = r2.detect_pyramid(r2.Model2(p), img.tolist(), r2.resize_cv2, 48, 36, 24, 5, 1.2, 0.3, True)
     assert len(rects) == len(want["rects"]) > 0
     assert np.array_equal(np.array(rects, np.int32), want["rects"])
     assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
@@ -152,8 +166,28 @@ def test_method_0_the_image_pyramid_around_the_resize(model_file, multi):
     m = r2.Model2(p)
     for nms in (True, False):
         want = orc.detect_cpp_pyramid(img, 48, 5, 1.2, 0.3, nms, half_size=36 if multi else 0, quarter_size=24 if multi else 0)
-        rects, scores, shapes = r2.detect_pyramid(m, img.tolist(), _resize_with(orc), 48, 36, 24, 5, 1.2, 0.3, nms)
+        # (single-scale: every resize through the second recollection -- the levels; multi-scale: 1,900 patch resizes in
+        # pure Python would take a minute, so the first recollection serves them and a smaller image below goes all the way)
+        rects, scores, shapes = r2.detect_pyramid(m, img.tolist(), _resize_with(orc) if multi else r2.resize_cv2, 48, 36, 24, 5, 1.2, 0.3, nms)
         assert len(rects) == len(want["rects"]) > 0
         assert np.array_equal(np.array(rects, np.int32), want["rects"])
         assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
+
+
+@pytest.mark.parametrize("src,dst", [((64, 48), (45, 33)), ((64, 48), (32, 24)), ((47, 61), (33, 43)), ((150, 121), (125, 100)),
+                                     ((48, 48), (36, 36)), ((48, 48), (24, 24)), ((48, 48), (48, 48)), ((31, 20), (40, 29)),
+                                     ((125, 100), (104, 83)), ((20, 20), (14, 14)), ((33, 25), (16, 12)), ((101, 77), (50, 38))])
+def test_two_recollections_of_cv_resize_agree(model_file, src, dst):
+    """cv::resize (8-bit, INTER_LINEAR) twice from memory of OpenCV's imgwarp.cpp -- jda_oracle.c's orc_resize_cv and
+    cpp_reading2.resize_cv2: float coordinates, border rules, 11-bit coefficients rounded half to even, the fixed-point vertical
+    pass, the exact-2x switch to the area average.  Equal on down- and up-scaling, the sizes method 1 and method 0 use, and the
+    identity.  Two memories of a library that is not here: still not a pin."""
+    p, _ = model_file((1, 4, 3, 2), 8, seed=5)
+    orc = Oracle(p)
+    img = _image(src[0], src[1], seed=src[0] * 7 + dst[0])
+    a = orc.resize_cv(img, dst[0], dst[1])
+    b = np.array(r2.resize_cv2(img.tolist(), dst[0], dst[1]), np.uint8)
+    assert a.shape == b.shape == (dst[1], dst[0])
+    assert np.array_equal(a, b), (np.argwhere(a != b)[:5], a[a != b][:5], b[a != b][:5])
     orc.close()
