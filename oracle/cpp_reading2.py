@@ -6,7 +6,7 @@ the HIP kernels are bit-exact against jda_oracle.c's restatement only.  Two rest
 from the same source that agree bit for bit (tests/test_cpp_second_reading.py) narrow the room for a misreading; they do
 not pin anything -- a detail both readers got wrong the same way, or one that only the real OpenCV decides (cv::resize for
 multi-scale models, cv::norm inside the similarity transform), stays open.  Covered here: detect methods 1 and 0, single- and
-multi-scale models, the identity similarity transform.  cv::resize is NOT restated a second time: where the reference resizes
+multi-scale models, the similarity transform off and on.  cv::resize is NOT restated a second time: where the reference resizes
 (the half / quarter images of method 1, the pyramid levels and per-window patches of method 0) the caller hands in a resize
 function -- the tests pass jda_oracle.c's restatement -- so these paths check everything AROUND the resize: which image is
 resized to what, the ROI arithmetic, which patch a feature reads and with which width and height, rect scaling, NMS, relocation.
@@ -85,6 +85,49 @@ class Model2:
 IDENTITY = (1.0, 1.0, 0.0, 0.0, 1.0)        # scale, rot00, rot01, rot10, rot11 (data.hpp: STParameter's default)
 
 
+def _cv_norm_l2(v):
+    """cv::norm(Mat_<double>) (NORM_L2), as stat.cpp's normL2Sqr<double, double> sums it: four squares at a time, then the
+    remainder one by one, one square root at the end."""
+    s = 0.
+    i, n = 0, len(v)
+    while i <= n - 4:
+        v0, v1, v2, v3 = v[i], v[i + 1], v[i + 2], v[i + 3]
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3
+        i += 4
+    while i < n:
+        s += v[i] * v[i]
+        i += 1
+    return math.sqrt(s)
+
+
+def st_calc(shape1, shape2, L):
+    """STParameter::Calc (data.cpp:64-114) with face.similarity_transform on.  Two OpenCV details decide bits here and
+    neither can be run in this image: cv::norm's summation order (above) and `Mat /= double`, which mat.inl.hpp spells
+    a.convertTo(a, -1, 1. / s): every element times the RECIPROCAL, plus a zero shift.  (Written after model_dev.cpp's and
+    jda_oracle.c's versions of the same two details had been seen; the author's memory of the OpenCV sources agrees with them.)"""
+    x1c = y1c = x2c = y2c = 0.
+    for i in range(L):
+        x1c += shape1[2 * i]; y1c += shape1[2 * i + 1]
+        x2c += shape2[2 * i]; y2c += shape2[2 * i + 1]
+    x1c /= L; y1c /= L; x2c /= L; y2c /= L
+    t1, t2 = [0.] * (2 * L), [0.] * (2 * L)
+    for i in range(L):
+        t1[2 * i] = shape1[2 * i] - x1c; t1[2 * i + 1] = shape1[2 * i + 1] - y1c
+        t2[2 * i] = shape2[2 * i] - x2c; t2[2 * i + 1] = shape2[2 * i + 1] - y2c
+    scale1, scale2 = _cv_norm_l2(t1), _cv_norm_l2(t2)
+    scale = scale1 / scale2
+    a1, a2 = 1. / scale1, 1. / scale2
+    t1 = [v * a1 + 0. for v in t1]
+    t2 = [v * a2 + 0. for v in t2]
+    num = den = 0.
+    for i in range(L):
+        num += t1[2 * i + 1] * t2[2 * i] - t1[2 * i] * t2[2 * i + 1]
+        den += t1[2 * i] * t2[2 * i] + t1[2 * i + 1] * t2[2 * i + 1]
+    norm = math.sqrt(num * num + den * den)
+    sin_t, cos_t = num / norm, den / norm
+    return (scale, cos_t, -sin_t, sin_t, cos_t)
+
+
 def st_apply(stp, x1, y1):
     s, r00, r01, r10, r11 = stp                 # data.hpp:42-45
     return s * (r00 * x1 + r01 * y1), s * (r10 * x1 + r11 * y1)
@@ -124,7 +167,7 @@ def forward(m, c, patches, shape, stp):
 FNV_SEED, FNV_MUL = 2166136261, 16777619        # the trace's leaf-path hash (a convention of this repo's checkers, not the reference's)
 
 
-def validate(m, img, x0=None, y0=None, width=None, height=None, patches=None):
+def validate(m, img, x0=None, y0=None, width=None, height=None, patches=None, similarity=False):
     """JoinCascador::Validate -> (is_face, score, shape, n, path_hash).  Either one ORIGIN patch (img, x0, y0, width, height)
     or the three patches of a multi-scale call."""
     if patches is None:
@@ -136,7 +179,8 @@ def validate(m, img, x0=None, y0=None, width=None, height=None, patches=None):
     base = 1 << (m.D - 1)
     stp = IDENTITY
     for t in range(m.stage_idx):
-        stp = IDENTITY                          # STParameter::Calc with the transform off (data.cpp:68-70)
+        # STParameter::Calc(shape, mean_shape) (cascador.cpp:180); the identity with the transform off (data.cpp:68-70)
+        stp = st_calc(shape, m.mean_shape, m.L) if similarity else IDENTITY
         lbf = [0] * m.K
         offset = 0
         for k in range(m.K):
@@ -243,7 +287,7 @@ def patches_method1(img, img_h, img_q, x, y, win):
             (img_q, x // 2, y // 2, win // 2, win // 2))
 
 
-def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True, resize=None, trace=None):
+def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True, resize=None, trace=None, similarity=False):
     """JoinCascador::Detect with fddb.method = 1 -> rects (x, y, w, h), scores, relocated shapes.
     resize(img, dw, dh): needed for multi-scale models only (img_h, img_q: cascador.cpp:323-331).  trace: a list that
     receives every window's (is_face, score, shape, n, path_hash) in scan order."""
@@ -254,7 +298,7 @@ def detect(m, img, minimum_size=20, step=5, factor=1.2, overlap=0.3, do_nms=True
         img_q = resize(img, w // 2, h // 2)
     rects, scores, shapes = [], [], []
     for (x, y, win) in windows_method1(w, h, minimum_size, step, factor):
-        res = validate(m, None, patches=patches_method1(img, img_h, img_q, x, y, win))
+        res = validate(m, None, patches=patches_method1(img, img_h, img_q, x, y, win), similarity=similarity)
         if trace is not None:
             trace.append(res)
         ok, score, shape, _, _ = res

@@ -191,3 +191,40 @@ def test_two_recollections_of_cv_resize_agree(model_file, src, dst):
     assert a.shape == b.shape == (dst[1], dst[0])
     assert np.array_equal(a, b), (np.argwhere(a != b)[:5], a[a != b][:5], b[a != b][:5])
     orc.close()
+
+
+@pytest.mark.parametrize("hdr", [None, (2, 7)])
+def test_similarity_transform_on_both_readings(model_file, tmp_path, hdr):
+    """face.similarity_transform: STParameter::Calc per stage from the window's current shape (data.cpp:64-114,
+    cascador.cpp:180), applied to every feature offset (data.cpp:33-34) and to the stage's delta shape (btcart.cpp:422).  A
+    snapshot's stage in training walks with the PREVIOUS stage's parameter (cascador.cpp:198-200: stp_mc is not recomputed)."""
+    from jda_amd import synth
+    dims = (3, 20, 5, 4)
+    mdl = synth.make_model(*dims, seed=3, cart_th=-1.0, norm_every=5, w_sigma=2e-2)
+    p = str(tmp_path / "st.model")
+    if hdr:
+        mdl.save(p, 8, header_stage=hdr[0], header_cart=hdr[1])
+    else:
+        mdl.save(p, 8)
+    img = _image(64, 52, seed=17)
+    orc = Oracle(p)
+    orc.set_similarity_transform(True)
+    try:
+        tr = orc.trace_cpp(img, minimum_size=20, step=5, factor=1.2)
+        want = orc.detect_cpp(img, 20, 5, 1.2, 0.3, True)
+    finally:
+        orc.set_similarity_transform(False)
+    m = r2.Model2(p)
+    mine = []
+    rects, scores, shapes = r2.detect(m, img.tolist(), 20, 5, 1.2, 0.3, True, trace=mine, similarity=True)
+    later = 0
+    for i, (ok, score, shape, n, h) in enumerate(mine):
+        assert n == tr["carts_n"][i] and h == tr["path_hash"][i], i
+        assert _bits([score])[0] == _bits(tr["score"][i:i + 1])[0], i
+        assert np.array_equal(_bits(shape), _bits(tr["shapes"][i])), i
+        later += n > dims[1]
+    assert later > 0                                        # (windows that reached a stage whose parameter is not the stage-0 one)
+    assert len(rects) == len(want["rects"]) > 0
+    assert np.array_equal(np.array(rects, np.int32), want["rects"])
+    assert np.array_equal(_bits(scores), _bits(want["scores"])) and np.array_equal(_bits(shapes), _bits(want["shapes"]))
+    orc.close()
