@@ -87,6 +87,7 @@ hipStream_t StreamPool::take(Role role, int avoid, int* cls_out) {
   for (int attempt = 0; attempt < 8; attempt++) {
     const int b = best_class(role, avoid);
     const bool all_known = dry >= 4 || (int)rep.size() >= std::min(kMaxCls, hw_queues);
+    if (b < 0 && all_known && !rep.empty()) break;      // (every known queue is the one to keep away from -- a runtime with ONE hardware queue: whatever is at hand)
     if (b >= 0 && (all_known || (mains[b] == 0 && others[b] == 0)))
       for (Item& it : items) if (!it.used && it.cls == b) return hand_out(it);
     // nothing of that queue at hand (or a queue nobody uses may still be out there): one more stream, wherever it lands
@@ -99,8 +100,9 @@ hipStream_t StreamPool::take(Role role, int avoid, int* cls_out) {
   auto load = [&](const Item& it) { return it.cls < 0 ? 0 : (it.cls == avoid ? 1000 : 0) + 10 * mains[it.cls] + others[it.cls]; };
   for (Item& it : items) if (!it.used && (!pick || load(it) < load(*pick))) pick = &it;
   if (pick) return hand_out(*pick);
-  fail("no stream to be had");
-  return nullptr;
+  int cls = kNone;
+  if (!create_one(&cls)) return nullptr;
+  return hand_out(items.back());
 }
 
 void StreamPool::give_back(hipStream_t s) {

@@ -64,7 +64,10 @@ def test_concurrent_callers_share_one_cascador(built, gpu, tmp_path):
         for r in range(reps):
             _eq(got[t][r], want[(t + r) % 16], (t, r))
     print("jdaDetect calls/s: 1 thread %.0f, %d threads on one cascador %.0f (%.1fx)" % (one, n_thr, many, many / one))
-    assert many >= 2.2 * one, (one, many)        # (2.6-3.3x measured over six boxes; 8 lanes share four hardware queues)
+    # (2.6-3.3x measured over six boxes; 8 lanes share four hardware queues -- the runtime's default; under another deal of
+    # queues, GPU_MAX_HW_QUEUES / DEBUG_HIP_DYNAMIC_QUEUES in the environment, only the results are asserted)
+    if not (os.environ.get("GPU_MAX_HW_QUEUES") or os.environ.get("DEBUG_HIP_DYNAMIC_QUEUES")):
+        assert many >= 2.2 * one, (one, many)
 
 
 def test_mixed_entries_run_side_by_side_on_one_cascador(built, gpu, model_file):
