@@ -326,9 +326,10 @@ JDA_API void jdaResultDRelease(jdaResultD result);
  * A trainer snapshot (a double file whose header says the model is still in training: stage s < T, cart c) runs the way the
  * reference's Validate runs it -- stages [0, s) in full, then carts [0, c] of stage s without that stage's regression
  * (src/jda/cascador.cpp:177-209) -- in every dialect-CPP entry; jdaStats::cart_total_n counts the padding carts a face walks,
- * nothing else sees them.  Refused (-1, jdaGetLastError): a training status the reference's loader asserts against
- * (cascador.cpp:138-141), and a snapshot together with jdaSetSimilarityTransform(1).  jdaDetect and the other dialect-C
- * entries ignore the header, like c/jda.c:499-505. */
+ * nothing else sees them.  With jdaSetSimilarityTransform(1) the stage in training walks with the parameter the stage before
+ * it computed (Validate does not recompute stp_mc for it, cascador.cpp:178-200).  Refused (-1, jdaGetLastError): a training
+ * status the reference's loader asserts against (cascador.cpp:138-141).  jdaDetect and the other dialect-C entries ignore
+ * the header, like c/jda.c:499-505. */
 JDA_API int jdaDetectBatchCpp(void *cascador, const unsigned char *const *frames, int n,
                               int width, int height, int minimum_size, int step,
                               double factor, double overlap, int nms,

@@ -27,20 +27,15 @@ bool plan_c_call(Cascador* c, size_t stride, int width, int height, float scale,
 // model carries (T, -1); the float files of the C library carry (T+1, -1) (c/jda.c:662-665), which the reference's own
 // C++ loader would walk out of bounds with -- both mean "every stage" here.  A training snapshot (fewer stages, or a stage
 // cut at a cart) runs like Validate runs it: the fp64 tables are padded with pass-through carts and zero weight rows
-// (model_dev.cpp; r06 -- until then the dialect-CPP entries refused snapshots).  Refused: a status the reference's loader
-// asserts against (cascador.cpp:138-141), and a snapshot with the similarity transform on (the stage in training walks
-// with the PREVIOUS stage's parameter, which padded tables cannot reproduce).  Dialect C ignores the header like
-// c/jda.c:499-505 does.
+// (model_dev.cpp; r06 -- until then the dialect-CPP entries refused snapshots); with the similarity transform on, the stage in
+// training walks with the PREVIOUS stage's parameter (k_finish keeps it, DevModelT::similarity).  Refused: a status the
+// reference's loader asserts against (cascador.cpp:138-141).  Dialect C ignores the header like c/jda.c:499-505 does.
 bool cpp_model_complete(const Cascador* c) {
   const HostModel& h = c->hm;
   if ((h.hdr_stage == h.T || h.hdr_stage == h.T + 1) && h.hdr_cart == -1) return true;
   const std::string status = "header says stage " + std::to_string(h.hdr_stage) + ", cart " + std::to_string(h.hdr_cart) + " of T=" + std::to_string(h.T) +
                              ", K=" + std::to_string(h.K);
-  if (h.hdr_stage >= 0 && h.hdr_stage < h.T && h.hdr_cart >= -1 && h.hdr_cart < h.K) {
-    if (!c->similarity) return true;
-    fail("partial model (training snapshot: " + status + ") with the similarity transform: not supported by the dialect-CPP entries");
-    return false;
-  }
+  if (h.hdr_stage >= 0 && h.hdr_stage < h.T && h.hdr_cart >= -1 && h.hdr_cart < h.K) return true;
   fail("partial model with an impossible training status (" + status + "): refused by the dialect-CPP entries");
   return false;
 }

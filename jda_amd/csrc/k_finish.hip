@@ -114,9 +114,15 @@ __global__ __launch_bounds__(64) void k_finish(const DevPlan* __restrict__ plan,
       Stp<Real> stp;
       stp.scale = 1; stp.r00 = 1; stp.r01 = 0; stp.r10 = 0; stp.r11 = 1;
       if constexpr (ST) {
-        if (lane == 0) {
-          const Stp<double> p = stp_calc((const double*)sh, (const double*)m.mean_shape_raw, m.L, (double*)st_tmp,
-                                         (double*)st_tmp + dim_pad);
+        // m.similarity - 2: the stage in training of a trainer snapshot (negative: a complete model).  Validate does not
+        // recompute stp_mc for that stage (cascador.cpp:178-200): it walks with the parameter the PREVIOUS stage computed --
+        // which the scratch still holds -- or, being the first stage this window runs (the host keeps such a model's
+        // stages in one launch, so that is stage 0), with STParameter's default.
+        const bool stale = t == m.similarity - 2;
+        if (lane == 0 && (!stale || t == t_begin)) {
+          Stp<double> p;
+          p.scale = 1.; p.r00 = 1.; p.r01 = 0.; p.r10 = 0.; p.r11 = 1.;
+          if (!stale) p = stp_calc((const double*)sh, (const double*)m.mean_shape_raw, m.L, (double*)st_tmp, (double*)st_tmp + dim_pad);
           double* o = (double*)st_tmp + 2 * dim_pad;
           o[0] = p.scale; o[1] = p.r00; o[2] = p.r01; o[3] = p.r10; o[4] = p.r11;
         }

@@ -143,7 +143,7 @@ struct DevModelT {
                            // they pass through L2 without evicting the stage's split nodes (3 MB for K=2000, D=6)
   const Real* mean_shape;  // [dim]  (dialect CPP: + 0., the zero random shift of RandomShape)
   const Real* mean_shape_raw;  // [dim]  as stored (second argument of STParameter::Calc)
-  int similarity;          // dialect CPP: Config::with_similarity_transform
+  int similarity;          // dialect CPP: Config::with_similarity_transform -- 0 off, 1 on, 2 + s: on, and stage s of a trainer snapshot is the one in training (it walks with the previous stage's parameter)
 };
 
 // Device buffers of one pass over a sub-batch of frames.

@@ -17,7 +17,9 @@ bool upload_model(Cascador* c) {
   // stage-0 similarity transform, reference data.cpp:64-114 (see stp_calc in k_finish.hip for the
   // restated OpenCV details); identity when off
   double stp0[5] = {1., 1., 0., 0., 1.};
-  if (sizeof(Real) == 8 && c->similarity) {
+  const bool snapshot = h.hdr_stage >= 0 && h.hdr_stage < h.T;      // a trainer file of a model still in training (below)
+  // (a snapshot whose FIRST stage is the one in training walks it with STParameter's default, cascador.cpp:176-200)
+  if (sizeof(Real) == 8 && c->similarity && !(snapshot && h.hdr_stage == 0)) {
     const int L = h.L;
     std::vector<double> s1(dim), t1(dim), t2(dim);
     const std::vector<double>& s2 = h.mean_shape;
@@ -95,13 +97,8 @@ bool upload_model(Cascador* c) {
     // shapes and face decisions are Validate's; only the work counters see the padding.  (Found by the second reading of
     // src/jda, oracle/cpp_reading2.py; the oracle runs Validate's literal loop bounds, tests/test_cpp_second_reading.py
     // and tests/test_cpp_entries.py compare.)
-    if (c->similarity) {
-      // (the stage in training walks with the PREVIOUS stage's similarity parameter, cascador.cpp:178-200: a value the padded
-      // tables cannot give it)
-      fail("dialect CPP with the similarity transform on a model still in training (header stage " + std::to_string(h.hdr_stage) +
-           " of " + std::to_string(h.T) + ") is not supported");
-      return false;
-    }
+    // With the similarity transform on, the stage in training walks with the PREVIOUS stage's parameter (cascador.cpp:178-200
+    // does not recompute stp_mc for it): DevModelT::similarity carries the stage (2 + stage) and k_finish keeps the parameter.
     const int full = h.hdr_stage;
     const int part = std::min(h.K, std::max(0, h.hdr_cart + 1));
     const Real ninf = -std::numeric_limits<Real>::infinity();
@@ -198,7 +195,7 @@ bool upload_model(Cascador* c) {
   m.w_rows = d_w_rows; m.w_pitch = padded ? w_pitch : dim;
   m.w_stream = (c->kn.w_stream_mb > 0 && (size_t)h.K * leaf_n * (size_t)m.w_pitch * sizeof(Real) > (size_t)c->kn.w_stream_mb << 20) ? 1 : 0;
   m.cnorm = d_cnorm; m.w = d_w; m.mean_shape = d_ms; m.mean_shape_raw = d_ms_raw;
-  m.similarity = (sizeof(Real) == 8) ? c->similarity : 0;
+  m.similarity = (sizeof(Real) == 8) ? (c->similarity ? (snapshot ? 2 + h.hdr_stage : 1) : 0) : 0;
   m.par0 = d_par0;
   mo.ready = true;
   return true;

@@ -556,7 +556,10 @@ struct Pass {
       finished = true;
       return true;
     }
-    if (T == 1 || n_grid <= kn().finish_merge) {
+    // (a trainer snapshot with the similarity transform: its stage in training walks with the parameter the stage before it
+    // computed, which k_finish keeps in its scratch -- every stage of a window in ONE launch)
+    const bool st_snapshot = sizeof(Real) == 8 && c->similarity && hm().hdr_stage >= 0 && hm().hdr_stage < T;
+    if (T == 1 || n_grid <= kn().finish_merge || st_snapshot) {
       // few windows left: one launch walks them through every remaining stage (no balance problem,
       // one launch less)
       JDA_HIP(launch_finish<Real>(want_trace(), 0, T, apply_th, th, pe->dp, model(), w, gm, n_grid, s0_tbl(), (int)kn().fin_tile, st));

@@ -244,8 +244,9 @@ def test_cpp_ragged_rows_entries_equal_the_packed_results(built, gpu, model_file
     assert same(np.array(cm.detect_ragged_cpp_packed(buf, offs, ws, hs, keep_results="packed", frame_offset=3)), want)
 
 
+@pytest.mark.parametrize("sim", [False, True])
 @pytest.mark.parametrize("hdr", [(1, 6), (0, 11), (2, -1), (0, -1), (2, 19)])
-def test_cpp_on_a_model_still_in_training_stops_where_validate_stops(built, gpu, tmp_path, hdr):
+def test_cpp_on_a_model_still_in_training_stops_where_validate_stops(built, gpu, tmp_path, hdr, sim):
     """A trainer snapshot (jda_xxxx_stage_s_cart_c.model) carries its training status in the header, and the reference's
     Validate honours it: stages [0, s) in full, then carts [0, c] of stage s WITHOUT that stage's regression
     (cascador.cpp:177-209, 84-104).  Found by the second reading of src/jda (oracle/cpp_reading2.py,
@@ -253,17 +254,20 @@ def test_cpp_on_a_model_still_in_training_stops_where_validate_stops(built, gpu,
     dialect C's reference does (c/jda.c:499-505 drops the two ints).  The oracle runs Validate's literal loop bounds; the
     product pads its fp64 tables with pass-through carts and zero weight rows (model_dev.cpp) -- window by window the reject
     length, score, leaf path and shape must be the same, and so must every entry's detections.  Dialect C on the same
-    file keeps running everything."""
+    file keeps running everything.  sim: with the similarity transform on, the stage in training walks with the parameter the
+    stage before it computed -- Validate does not recompute stp_mc for it (cascador.cpp:178-200) -- or, being the first stage,
+    with STParameter's default; both restatements read it that way (tests/test_cpp_second_reading.py)."""
     from jda_amd import api, synth
     from oracle.pyoracle import Oracle
     dims = (3, 20, 5, 4)
-    mdl = synth.make_model(*dims, seed=3, cart_th=-1.0, norm_every=5)
+    mdl = synth.make_model(*dims, seed=3, cart_th=-1.0, norm_every=5, w_sigma=2e-2 if sim else 2e-3)
     p = str(tmp_path / "snapshot.model")
     mdl.save(p, 8, header_stage=hdr[0], header_cart=hdr[1])
     full = str(tmp_path / "full.model")
     mdl.save(full, 8)
     imgs = _images([(131, 97), (64, 48), (200, 150)], seed=5)
     c, o = api.Cascador(p), Oracle(p)
+    c.set_similarity_transform(sim); o.set_similarity_transform(sim)
     ran = hdr[0] * dims[1] + hdr[1] + 1                       # carts Validate runs for a window that passes them all
     for im in imgs[:2]:
         got, want = c.trace_cpp(im[None]), o.trace_cpp(im)
@@ -280,6 +284,7 @@ def test_cpp_on_a_model_still_in_training_stops_where_validate_stops(built, gpu,
     for i, im in enumerate(imgs):
         _eq(got[i], o.detect_cpp(im), i)
         _eq(got[i], c.detect_batch_cpp(im[None])[0], i)
+    o.set_similarity_transform(False)
     # the same file through dialect C: all T x K carts, like the complete model (c/jda.c ignores the status)
     cf = api.Cascador(full)
     a, b = c.detect(imgs[2]), cf.detect(imgs[2])

@@ -123,8 +123,7 @@ def test_shipped_dims_plumbing_cpu(built, tmp_path):
 def test_impossible_training_status_is_refused_by_the_cpp_entries(built, tmp_path):
     """Header ints 5, 6 (current_stage_idx, current_cart_idx; cascador.cpp:93-104): dialect CPP's Validate stops there
     (cascador.cpp:178,199-209).  A training snapshot is run the way Validate runs it (tests/test_cpp_entries.py, GPU); a
-    status the reference's own loader asserts against (cascador.cpp:138-141) and a snapshot with the similarity transform
-    on are refused, not run to the end silently.  Dialect C ignores the header (c/jda.c:499-505).  No GPU needed: the
+    status the reference's own loader asserts against (cascador.cpp:138-141) is refused, not run to the end silently.  Dialect C ignores the header (c/jda.c:499-505).  No GPU needed: the
     refusal comes before any device work."""
     import numpy as np
     from jda_amd import api, synth
@@ -137,11 +136,6 @@ def test_impossible_training_status_is_refused_by_the_cpp_entries(built, tmp_pat
         for call in (lambda: c.detect_batch_cpp(frame), lambda: c.trace_cpp(frame), lambda: c.detect_batch_cpp_pyramid(frame)):
             with pytest.raises(api.JdaError, match="partial model"):
                 call()
-    snap = str(tmp_path / "snap.model"); m.save(snap, 8, header_stage=1, header_cart=4)     # jda_xxxx_stage_2_cart_5.model
-    c = api.Cascador(snap)
-    c.set_similarity_transform(True)
-    with pytest.raises(api.JdaError, match="similarity"):
-        c.detect_batch_cpp(frame)
     assert api.Cascador(full).T == 3
 
 

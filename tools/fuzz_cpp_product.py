@@ -19,7 +19,7 @@ while time.time() - t0 < secs:
     if rng.integers(0, 2): mdl.off *= float(rng.uniform(1, 4))
     sim = bool(rng.integers(0, 3) == 0)
     hdr = None
-    if not sim and rng.integers(0, 2) == 0: hdr = (int(rng.integers(0, T)), int(rng.integers(-1, K)))
+    if rng.integers(0, 2) == 0: hdr = (int(rng.integers(0, T)), int(rng.integers(-1, K)))
     p = os.path.join(tmp, "m_%d.model" % n)
     mdl.save(p, 8, **({} if hdr is None else dict(header_stage=hdr[0], header_cart=hdr[1])))
     sizes = [(int(rng.integers(20, 160)), int(rng.integers(20, 120))) for _ in range(int(rng.integers(1, 5)))]
